@@ -1,0 +1,191 @@
+"""torch-CPU restatement of the cWGAN-GP training step (autograd gives the gradients).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py; parity unpinned).  Second, independent
+restatement of the reference arithmetic: forward ops through torch.nn.functional with
+explicit TF-style padding, gradients (incl. the gradient-penalty double backward of
+GradientPenalty.call, T:238-241) through torch.autograd.  Must agree with oracle/rdgan_np.py
+on the forward pass and with fp64 finite differences on gradients
+(tests/test_oracle_*.py).  Also timed on the host cores as bench.py's ``cpu_baseline``
+("port": TensorFlow, the reference's runtime, is not installed).
+
+T = gan_train_cwgangp_pixelnorm.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import rdgan_np as onp
+from . import rng as orng
+
+LRELU = onp.LRELU_ALPHA
+
+
+def _conv3d_tf(x, w, b, stride, pad_before, out_dims):
+    """x (B,D,H,W,Cin) NDHWC, w (3,3,3,Cin,Cout) TF layout -> (B,Do,Ho,Wo,Cout)."""
+    B, D, H, W, Cin = x.shape
+    need = [(o - 1) * stride + 3 for o in out_dims]
+    after = [max(nd - n - p, 0) for nd, n, p in zip(need, (D, H, W), pad_before)]
+    xc = x.permute(0, 4, 1, 2, 3)
+    xc = F.pad(xc, (pad_before[2], after[2], pad_before[1], after[1], pad_before[0], after[0]))
+    wc = w.permute(4, 3, 0, 1, 2)
+    y = F.conv3d(xc, wc, b, stride=stride)
+    y = y[:, :, :out_dims[0], :out_dims[1], :out_dims[2]]
+    return y.permute(0, 2, 3, 4, 1)
+
+
+def pixel_norm(x):
+    """T:255-266."""
+    return x / torch.sqrt(torch.mean(x * x, dim=-1, keepdim=True) + onp.PIXELNORM_EPS)
+
+
+def upsample3d(x):
+    """T:330."""
+    return x.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+
+
+def generator_forward(p, z, cond, return_intermediates=False):
+    """T:312-357."""
+    Wd, bd, W1, b1, W2, b2, W3, b3, W4, b4 = p
+    B = z.shape[0]
+    nd = cond.shape[1]
+    s = nd // 8
+    x = torch.cat([z, cond.reshape(B, -1)], dim=1)
+    h0 = F.leaky_relu(x @ Wd + bd, LRELU).reshape(B, 3, s, s, 256)
+    hs = [h0]
+    h = h0
+    for W, b in ((W1, b1), (W2, b2), (W3, b3)):
+        u = upsample3d(h)
+        y = _conv3d_tf(u, W, b, 1, (1, 1, 1), u.shape[1:4])
+        h = F.leaky_relu(pixel_norm(y), LRELU)
+        hs.append(h)
+    logits = _conv3d_tf(h, W4, b4, 1, (1, 1, 1), h.shape[1:4])
+    out = torch.softmax(logits, dim=1)
+    if return_intermediates:
+        return out, dict(h0=hs[0], h1=hs[1], h2=hs[2], h3=hs[3], logits=logits)
+    return out
+
+
+def critic_forward(p, sample, cond, masks=None, return_intermediates=False):
+    """T:272-309.  masks: list of 4 tensors (0 or 1/0.75) or None."""
+    nd = cond.shape[1]
+    geo = onp.critic_geometry(nd)
+    cond_rep = cond[:, None].expand(-1, onp.NHOURS, -1, -1, -1)
+    x = torch.cat([sample, cond_rep], dim=-1)
+    hs = []
+    for li in range(4):
+        _, out_dims, pad = geo[li]
+        a = _conv3d_tf(x, p[2 * li], p[2 * li + 1], 2, pad, out_dims)
+        x = F.leaky_relu(a, LRELU)
+        if masks is not None:
+            x = x * masks[li]
+        hs.append(x)
+    v = x.reshape(x.shape[0], -1) @ p[8] + p[9]
+    if return_intermediates:
+        return v, dict(h=hs)
+    return v
+
+
+def critic_masks(seed, batch, ndomain, dtype=torch.float32):
+    """Dropout masks for a critic pass over ``batch`` samples (flat NDHWC index per layer,
+    streams D1..D4 of oracle/rng.py).  seed == 0 -> None (dropout off)."""
+    if seed == 0:
+        return None
+    geo = onp.critic_geometry(ndomain)
+    chans = (64, 128, 256, 256)
+    out = []
+    for li in range(4):
+        shp = (batch,) + tuple(geo[li][1]) + (chans[li],)
+        out.append(torch.from_numpy(orng.dropout_scale_mask(seed, orng.STREAM_D1 + li, shp)).to(dtype))
+    return out
+
+
+def critic_step_grads(dp, gp, x_real, cond, z, seed):
+    """One critic ``train_on_batch`` graph (T:363-392,472) up to the gradients.
+
+    The three critic passes of the reference (T:372,373,379) are evaluated as ONE batch
+    [real; fake; interpolated] of 3B samples so that dropout-mask element indices match the
+    HIP path; alpha comes from stream ALPHA.  Returns (losses[4] = total, valid, fake, gp
+    as Keras reports them, grads list in critic weight order)."""
+    B = x_real.shape[0]
+    nd = cond.shape[1]
+    dt = x_real.dtype
+    dp = [t.detach().clone().requires_grad_(True) for t in dp]
+    with torch.no_grad():
+        fake = generator_forward(gp, z, cond)                        # generator frozen, T:363
+    alpha = torch.from_numpy(orng.uniform(seed, orng.STREAM_ALPHA, B)).to(dt).reshape(B, 1, 1, 1, 1)
+    xhat = (alpha * x_real + (1 - alpha) * fake).detach().requires_grad_(True)   # T:221-224
+    masks = critic_masks(seed, 3 * B, nd, dt)
+    v = critic_forward(dp, torch.cat([x_real, fake, xhat], 0), torch.cat([cond, cond, cond], 0), masks)
+    v_real, v_fake, v_hat = v[:B], v[B:2 * B], v[2 * B:]
+    g, = torch.autograd.grad(v_hat.sum(), xhat, create_graph=True)   # K.gradients, T:240
+    gpen = torch.sqrt((g * g).reshape(B, -1).sum(1, keepdim=True)) - 1   # T:241
+    l_valid = torch.mean(-1.0 * v_real)                               # W(valid=-1), T:452
+    l_fake = torch.mean(1.0 * v_fake)                                 # W(fake=+1),  T:453
+    l_gp = torch.mean(gpen * gpen)                                    # 'mse' vs dummy 0, T:390,454
+    total = l_valid + l_fake + onp.GP_WEIGHT * l_gp                   # loss_weights, T:392
+    grads = torch.autograd.grad(total, dp, allow_unused=True)
+    grads = [torch.zeros_like(p) if gg is None else gg for p, gg in zip(dp, grads)]
+    losses = torch.stack([total, l_valid, l_fake, l_gp]).detach()
+    return losses, [gg.detach() for gg in grads]
+
+
+def gen_step_grads(dp, gp, z, cond, seed):
+    """One generator ``train_on_batch`` graph (T:395-408,482): loss = mean(-D(G(z,c))),
+    critic frozen but dropout active."""
+    B = z.shape[0]
+    nd = cond.shape[1]
+    gp = [t.detach().clone().requires_grad_(True) for t in gp]
+    img = generator_forward(gp, z, cond)
+    masks = critic_masks(seed, B, nd, z.dtype)
+    v = critic_forward(dp, img, cond, masks)
+    loss = torch.mean(-1.0 * v)
+    grads = torch.autograd.grad(loss, gp)
+    return loss.detach(), [gg.detach() for gg in grads]
+
+
+def adam_update(params, grads, vs, t, lr=1e-4, beta2=0.9, eps=1e-7):
+    """tf.optimizers.Adam(lr=1e-4, beta_1=0, beta_2=0.9) (T:385), Keras optimizer_v2 form:
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = g (beta_1 = 0); v = b2*v + (1-b2)*g^2;
+    p -= lr_t*m/(sqrt(v)+eps) with eps = 1e-7 (Keras default).  ``t`` is the optimizer's
+    shared iteration counter AFTER increment (both models use one optimizer, T:391,408)."""
+    lr_t = lr * float(np.sqrt(1.0 - beta2 ** t))
+    for p, g, v in zip(params, grads, vs):
+        v.mul_(beta2).add_(g * g, alpha=1 - beta2)
+        p.sub_(lr_t * g / (torch.sqrt(v) + eps))
+
+
+class Trainer:
+    """Minimal CPU trainer used for the cpu_baseline timing and for end-to-end parity of a
+    few iterations (T:466-482: n_critic critic steps then one generator step)."""
+
+    def __init__(self, ndomain=16, seed=0, dtype=torch.float32):
+        rng = np.random.default_rng(seed)
+        nd = dtype == torch.float64 and np.float64 or np.float32
+        self.ndomain = ndomain
+        self.gp = [torch.from_numpy(a) for a in onp.init_generator(rng, ndomain, dtype=nd)]
+        self.dp = [torch.from_numpy(a) for a in onp.init_critic(rng, ndomain, dtype=nd)]
+        self.gv = [torch.zeros_like(p) for p in self.gp]
+        self.dv = [torch.zeros_like(p) for p in self.dp]
+        self.t = 0
+
+    def critic_step(self, x_real, cond, z, seed):
+        losses, grads = critic_step_grads(self.dp, self.gp, x_real, cond, z, seed)
+        self.t += 1
+        adam_update(self.dp, grads, self.dv, self.t)
+        return losses
+
+    def gen_step(self, z, cond, seed):
+        loss, grads = gen_step_grads(self.dp, self.gp, z, cond, seed)
+        self.t += 1
+        adam_update(self.gp, grads, self.gv, self.t)
+        return loss
+
+
+def synthetic_batch(batch, ndomain, seed, dtype=np.float32):
+    """Synthetic inputs of SURVEY 8(d): real tiles = softmax over hours of 2*N(0,1) (in [0,1],
+    sum over hours 1, as asserted at T:167-172); cond = Gamma(2, 5 mm)/127.4; z ~ N(0,1)."""
+    r = np.random.default_rng(seed)
+    x = onp.softmax_hours(2.0 * r.standard_normal((batch, 24, ndomain, ndomain, 1))).astype(dtype)
+    cond = (r.gamma(2.0, 5.0, (batch, ndomain, ndomain, 1)) / onp.NORM_SCALE).astype(dtype)
+    z = r.standard_normal((batch, onp.LATENT_DIM)).astype(dtype)
+    return x, cond, z
