@@ -1,0 +1,119 @@
+/* C ABI of librdgan_hip.so -- the MI355X-native (gfx950) cWGAN-GP hot path of RainDisaggGAN.
+ *
+ * The reference (sipposip/pr-disagg-radar-gan) has no native boundary: its hot path is a set of
+ * Keras calls into TensorFlow 2.1.  Each entry point below names the reference call it replaces
+ * (T = gan_train_cwgangp_pixelnorm.py, P = raindisagg_gan_pretrained.py).  The binding a
+ * maintainer would add on the reference side is the ctypes stub in INTEGRATION.md /
+ * pr_disagg_radar_gan_amd/_lib.py.
+ *
+ * Conventions: plain C, no torch types.  Every pointer is a DEVICE pointer owned by the caller
+ * (fp32, 16-byte aligned); `stream` is a hipStream_t passed as void*; calls are asynchronous on
+ * that stream and never allocate (the workspace is sized at rdgan_create).  Return value: 0 = ok,
+ * >0 = hipError_t, -2 = bad argument.  One handle per device and per stream user; a handle is not
+ * thread-safe.  Layouts are the reference's: activations NDHWC, Conv3D kernels
+ * (kd,kh,kw,Cin,Cout), Dense kernels (in,out); parameter slabs are the Keras weights concatenated
+ * in model.get_weights() order (kernel, bias per layer; see rdgan_*_param_layout).
+ */
+#ifndef RDGAN_H
+#define RDGAN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rdgan_handle rdgan_handle;
+
+#define RDGAN_LATENT_DIM 100   /* T:69 */
+#define RDGAN_NHOURS 24        /* T:134 */
+#define RDGAN_LOSS_SLOTS 8     /* floats appended behind the gradients in a gradient slab */
+
+/* Build the per-(ndomain, max_batch) plans and allocate the activation workspace.
+ * Replaces model construction at T:361-362 (create_generator / create_discriminator).
+ * ndomain must be a multiple of 8 (L:324); n_cond_channels must be 1 (T:129). */
+int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels, int max_batch);
+void rdgan_destroy(rdgan_handle* h);
+const char* rdgan_last_error(const rdgan_handle* h);
+long rdgan_gen_param_count(const rdgan_handle* h);      /* 3 974 273 at ndomain 16 */
+long rdgan_critic_param_count(const rdgan_handle* h);   /* 2 880 065 at ndomain 16 */
+long rdgan_workspace_bytes(const rdgan_handle* h);
+
+/* generator.predict([latent, cond]) (P:60, T:205,212; graph T:312-357).
+ * z [B,100], cond [B,nd,nd,1] normalised daily sums -> out [B,24,nd,nd,1] hourly fractions. */
+int rdgan_gen_forward(rdgan_handle* h, const float* gen_params, const float* z, const float* cond,
+                      float* out, int B, void* stream);
+
+/* critic.predict([sample, cond]) (graph T:272-309).  seed == 0: dropout off (inference);
+ * seed != 0: dropout masks of a train_on_batch pass (streams D1..D4 of rdgan_rng.h). out [B,1]. */
+int rdgan_critic_forward(rdgan_handle* h, const float* critic_params, const float* sample,
+                         const float* cond, float* out, int B, uint64_t seed, void* stream);
+
+/* Gradient half of critic_model.train_on_batch([X_real, cond_real, latent], [valid, fake, dummy])
+ * (T:472; graph T:363-392): generator forward (frozen), RandomWeightedAverage, three critic passes
+ * as one 3B batch, the gradient-penalty double backward, loss = mean(-D(x)) + mean(D(G(z))) +
+ * 10*mean((||grad_xhat D(xhat)||-1)^2).  grad_out[0:n_critic_params] = d loss / d critic weights,
+ * grad_out[n .. n+8) = {total, valid, fake, gp, nonfinite_flag, 0, 0, 0}.  The caller all-reduces
+ * grad_out over ranks (RCCL) and then calls rdgan_adam. */
+int rdgan_critic_grad(rdgan_handle* h, const float* critic_params, const float* gen_params,
+                      const float* x_real, const float* cond, const float* z, uint64_t seed,
+                      float* grad_out, int B, void* stream);
+
+/* Gradient half of generator_model.train_on_batch([latent, cond], valid) (T:482; graph T:395-408):
+ * loss = mean(-D(G(z,c))), critic frozen, its dropout active.
+ * grad_out[0:n_gen_params], grad_out[n .. n+8) = {loss, 0, 0, 0, nonfinite_flag, 0, 0, 0}. */
+int rdgan_gen_grad(rdgan_handle* h, const float* critic_params, const float* gen_params,
+                   const float* z, const float* cond, uint64_t seed, float* grad_out, int B,
+                   void* stream);
+
+/* tf.optimizers.Adam(lr, beta_1=0, beta_2) apply step (T:385): v = b2 v + (1-b2) g^2,
+ * p -= lr*sqrt(1-b2^t) * g / (sqrt(v)+eps), g = grad*grad_scale (1/world after the all-reduce sum).
+ * t = the optimizer's shared iteration counter after increment (both models share it, T:391,408). */
+int rdgan_adam(float* params, const float* grad, float* v, long n, int t, float lr, float beta2,
+               float eps, float grad_scale, void* stream);
+
+/* Parameter slab layout: fills offsets[0..10) / sizes with the element offset and size of
+ * {kernel,bias} x 5 layers in Keras weight order; returns the number of tensors (10). */
+int rdgan_gen_param_layout(const rdgan_handle* h, long* offsets, long* sizes);
+int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes);
+
+/* Per-kernel HIP-event timing for bench.py's roofline line.  tag_mask: bit i enables timing of
+ * kernel class i (RDGAN_TAG_*).  rdgan_profile_read synchronises the device. */
+enum {
+  RDGAN_TAG_GCONV_FWD = 0,   /* fused upsample+Conv3D forward GEMMs of the generator */
+  RDGAN_TAG_GCONV_DGRAD = 1,
+  RDGAN_TAG_GCONV_WGRAD = 2,
+  RDGAN_TAG_CRITIC_GEMM = 3,
+  RDGAN_TAG_ELEMENTWISE = 4,
+  RDGAN_TAG_GCONV3_FWD = 5,  /* the single dominant launch: 128->64 block at 24x16x16 */
+  RDGAN_NUM_TAGS = 8
+};
+int rdgan_profile(rdgan_handle* h, unsigned tag_mask);
+int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, long* launches);
+
+/* Op-level entry points used by the parity tests (tests/test_hip_ops.py). */
+/* Conv3D forward, TF semantics.  x [B,D,H,W,Cin] -> y [B,Do,Ho,Wo,Cout]; upsample=1 folds
+ * UpSampling3D(2) in front (T:330-331); pad = zero padding before each axis; Cin%4==0,
+ * Cout%64==0 (or 32). */
+int rdgan_op_conv3d(const float* x, const float* w, const float* bias, float* y, int B, int D, int H,
+                    int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d,
+                    int pad_h, int pad_w, int upsample, void* stream);
+/* input gradient of the above for stride 2 (parity-phase plan) or stride 1: gy -> gx (same dims as x,
+ * on the upsampled grid when the forward had upsample=1: D,H,W are the conv's input extents). */
+int rdgan_op_conv3d_dgrad(const float* gy, const float* w, float* gx, int B, int D, int H, int W,
+                          int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h,
+                          int pad_w, void* stream);
+/* weight gradient dW [3,3,3,Cin,Cout] of the forward above. */
+int rdgan_op_conv3d_wgrad(const float* x, const float* gy, float* dw, int B, int D, int H, int W,
+                          int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h,
+                          int pad_w, int upsample, void* stream);
+/* PixelNormalization + LeakyReLU(0.2) forward (T:255-266, T:333) and its backward. C in {64,128,256}. */
+int rdgan_op_pixelnorm_lrelu(const float* y, float* h, float* rinv, long npix, int C, void* stream);
+int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* rinv, float* dy,
+                                 long npix, int C, void* stream);
+/* dropout keep-scale mask (0 or 1/0.75) and uniforms of the counter RNG, for pinning it to oracle/rng.py */
+int rdgan_op_rng(uint64_t seed, uint32_t stream_id, float* mask_out, float* uniform_out, long n,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -189,3 +189,24 @@ def synthetic_batch(batch, ndomain, seed, dtype=np.float32):
     cond = (r.gamma(2.0, 5.0, (batch, ndomain, ndomain, 1)) / onp.NORM_SCALE).astype(dtype)
     z = r.standard_normal((batch, onp.LATENT_DIM)).astype(dtype)
     return x, cond, z
+
+
+def kink_margin(dp, gp, x_real, cond, z, seed, critic_step=True):
+    """Smallest |LeakyReLU input| (relative to the layer's RMS) met by a step.  The loss is only
+    piecewise smooth in the activations: an fp32 run and this fp64 oracle legitimately pick
+    different slopes for an activation within rounding of zero, which moves gradients by
+    ~1e-3.  Parity tests therefore use inputs whose margin is comfortably above fp32 noise."""
+    B = z.shape[0]
+    with torch.no_grad():
+        fake, inter = generator_forward(gp, z, cond, True)
+        m = min(float((inter[k].abs() / inter[k].pow(2).mean().sqrt()).min()) for k in ("h0", "h1", "h2", "h3"))
+        if critic_step:
+            alpha = torch.from_numpy(orng.uniform(seed, orng.STREAM_ALPHA, B)).to(z.dtype).reshape(B, 1, 1, 1, 1)
+            xs = torch.cat([x_real, fake, alpha * x_real + (1 - alpha) * fake], 0)
+            cs = torch.cat([cond, cond, cond], 0)
+        else:
+            xs, cs = fake, cond
+        _, di = critic_forward(dp, xs, cs, None, True)
+        for h in di["h"]:
+            m = min(m, float((h.abs() / h.pow(2).mean().sqrt()).min()))
+    return m

@@ -1,0 +1,79 @@
+"""ctypes binding of librdgan_hip.so (C ABI: include/rdgan.h).
+
+The product path has NO CPU fallback: if the library is missing or no MI355X is visible,
+every compute entry point raises.  (The CPU oracle lives in /oracle and is test-only.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librdgan_hip.so")
+
+c_f32p = ctypes.c_void_p      # device pointers travel as integers
+c_stream = ctypes.c_void_p
+
+# every symbol include/rdgan.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "rdgan_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "rdgan_destroy": (None, [ctypes.c_void_p]),
+    "rdgan_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "rdgan_gen_param_count": (ctypes.c_long, [ctypes.c_void_p]),
+    "rdgan_critic_param_count": (ctypes.c_long, [ctypes.c_void_p]),
+    "rdgan_workspace_bytes": (ctypes.c_long, [ctypes.c_void_p]),
+    "rdgan_gen_forward": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_stream]),
+    "rdgan_critic_forward": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int,
+                                            ctypes.c_uint64, c_stream]),
+    "rdgan_critic_grad": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_uint64,
+                                         c_f32p, ctypes.c_int, c_stream]),
+    "rdgan_gen_grad": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_uint64, c_f32p,
+                                      ctypes.c_int, c_stream]),
+    "rdgan_adam": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                  ctypes.c_float, ctypes.c_float, c_stream]),
+    "rdgan_gen_param_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
+    "rdgan_critic_param_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
+    "rdgan_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
+    "rdgan_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(ctypes.c_long)]),
+    "rdgan_op_conv3d": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 14 + [c_stream]),
+    "rdgan_op_conv3d_dgrad": (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 13 + [c_stream]),
+    "rdgan_op_conv3d_wgrad": (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 14 + [c_stream]),
+    "rdgan_op_pixelnorm_lrelu": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_long, ctypes.c_int, c_stream]),
+    "rdgan_op_pixelnorm_lrelu_bwd": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_long, ctypes.c_int, c_stream]),
+    "rdgan_op_rng": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, c_f32p, c_f32p, ctypes.c_long, c_stream]),
+}
+
+TAG_GCONV_FWD, TAG_GCONV_DGRAD, TAG_GCONV_WGRAD, TAG_CRITIC_GEMM, TAG_ELEMENTWISE, TAG_GCONV3_FWD = range(6)
+
+_lib = None
+
+
+class RdganError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library and bind every declared symbol.  Raises (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RdganError(
+            f"{LIB_PATH} is missing: build it with `python -m pr_disagg_radar_gan_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None, what=""):
+    if rc == 0:
+        return
+    msg = ""
+    if handle is not None and _lib is not None:
+        m = _lib.rdgan_last_error(handle)
+        msg = m.decode() if m else ""
+    raise RdganError(f"{what} failed with code {rc}" + (f": {msg}" if msg else ""))

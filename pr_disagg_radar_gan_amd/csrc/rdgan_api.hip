@@ -1,0 +1,899 @@
+// Host side of librdgan_hip.so: plans, workspace, step orchestration and the C ABI of
+// include/rdgan.h.  gfx950 only.  T = gan_train_cwgangp_pixelnorm.py,
+// L = alternative_domains/gan_train_cwgangp_pixelnorm_largedomain.py in the reference.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/rdgan.h"
+#include "rdgan_plan.h"
+#include "rdgan_rng.h"
+#include "rdgan_gemm.hip.h"
+#include "rdgan_elem.hip.h"
+
+#define RD_GP_WEIGHT 10.0f   // the literal at T:392
+
+// ------------------------------------------------------------------------------------
+// plan builders
+// ------------------------------------------------------------------------------------
+static void phase_defaults(RdPhase& ph, int LD, int LH, int LW) {
+  memset(&ph, 0, sizeof(ph));
+  ph.LD = LD; ph.LH = LH; ph.LW = LW; ph.L = LD * LH * LW;
+  for (int a = 0; a < 3; ++a) { ph.s_mul[a] = 1; ph.o_mul[a] = 1; ph.o_off[a] = 0; }
+}
+
+// Conv3D forward (T:286-299, T:331-345); D,H,W = source extents before the folded upsample
+static RdPlan plan_conv_fwd(int D, int H, int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride,
+                            int pd, int ph_, int pw, int up) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 1; p.SD = D; p.SH = H; p.SW = W; p.s_shift = up; p.s_cstride = Cin; p.SC = Cin;
+  p.w_rows_per_tap = Cin; p.DD = Do; p.DH = Ho; p.DW = Wo; p.d_cstride = Cout; p.N = Cout;
+  RdPhase& q = p.ph[0];
+  phase_defaults(q, Do, Ho, Wo);
+  for (int a = 0; a < 3; ++a) q.s_mul[a] = stride;
+  q.ntaps = 27;
+  for (int t = 0; t < 27; ++t) {
+    q.tap_off[t][0] = (int8_t)(t / 9 - pd); q.tap_off[t][1] = (int8_t)((t / 3) % 3 - ph_);
+    q.tap_off[t][2] = (int8_t)(t % 3 - pw); q.tap_w[t] = (int16_t)t;
+  }
+  return p;
+}
+
+// D1 (T:286): 2-channel input, stride 2, 'valid'.  (kw, ci) is contiguous in NDHWC with C = 2, so the
+// 27x2 taps are gathered as 9 taps (kd,kh) x 6 contiguous floats.
+static RdPlan plan_d1_fwd(int nd, int Do, int Ho, int Wo) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 1; p.SD = RDGAN_NHOURS; p.SH = nd; p.SW = nd; p.s_shift = 0; p.s_cstride = 2; p.SC = 6;
+  p.w_rows_per_tap = 6; p.DD = Do; p.DH = Ho; p.DW = Wo; p.d_cstride = 64; p.N = 64;
+  RdPhase& q = p.ph[0];
+  phase_defaults(q, Do, Ho, Wo);
+  for (int a = 0; a < 3; ++a) q.s_mul[a] = 2;
+  q.ntaps = 9;
+  for (int t = 0; t < 9; ++t) {
+    q.tap_off[t][0] = (int8_t)(t / 3); q.tap_off[t][1] = (int8_t)(t % 3); q.tap_off[t][2] = 0;
+    q.tap_w[t] = (int16_t)t;
+  }
+  return p;
+}
+
+// input gradient of a stride-1 'same' conv on its own grid: gx[i] = sum_t W[t]^T gy[i + 1 - t]
+static RdPlan plan_conv_dgrad_s1(int D, int H, int W, int Cin, int Cout) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 1; p.SD = D; p.SH = H; p.SW = W; p.s_shift = 0; p.s_cstride = Cout; p.SC = Cout;
+  p.w_rows_per_tap = Cout; p.DD = D; p.DH = H; p.DW = W; p.d_cstride = Cin; p.N = Cin;
+  RdPhase& q = p.ph[0];
+  phase_defaults(q, D, H, W);
+  q.ntaps = 27;
+  for (int t = 0; t < 27; ++t) {
+    q.tap_off[t][0] = (int8_t)(1 - t / 9); q.tap_off[t][1] = (int8_t)(1 - (t / 3) % 3);
+    q.tap_off[t][2] = (int8_t)(1 - t % 3); q.tap_w[t] = (int16_t)t;
+  }
+  return p;
+}
+
+// input gradient of a stride-2 conv, by parity phases: input position i = 2l + c0 receives
+// W[t]^T gy[o] for 2o + t - pad = i, i.e. taps t = pi + 2j (pi = (i+pad)&1) at o = l + base - j.
+static RdPlan plan_conv_dgrad_s2(int D, int H, int W, int Cin, int Do, int Ho, int Wo, int Cout, const int pad[3]) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.SD = Do; p.SH = Ho; p.SW = Wo; p.s_shift = 0; p.s_cstride = Cout; p.SC = Cout; p.w_rows_per_tap = Cout;
+  p.DD = D; p.DH = H; p.DW = W; p.d_cstride = Cin; p.N = Cin;
+  const int n[3] = {D, H, W};
+  int np = 0;
+  for (int cls = 0; cls < 8; ++cls) {
+    int pi[3] = {cls >> 2, (cls >> 1) & 1, cls & 1};
+    int c0[3], cnt[3], base[3], nt[3];
+    bool empty = false;
+    for (int a = 0; a < 3; ++a) {
+      c0[a] = (pi[a] + pad[a]) & 1;
+      cnt[a] = n[a] > c0[a] ? (n[a] - c0[a] + 1) / 2 : 0;
+      base[a] = (c0[a] + pad[a] - pi[a]) / 2;
+      nt[a] = pi[a] == 0 ? 2 : 1;
+      if (cnt[a] == 0) empty = true;
+    }
+    if (empty) continue;
+    RdPhase& q = p.ph[np++];
+    phase_defaults(q, cnt[0], cnt[1], cnt[2]);
+    for (int a = 0; a < 3; ++a) { q.o_mul[a] = 2; q.o_off[a] = c0[a]; }
+    q.ntaps = 0;
+    for (int jd = 0; jd < nt[0]; ++jd)
+      for (int jh = 0; jh < nt[1]; ++jh)
+        for (int jw = 0; jw < nt[2]; ++jw) {
+          int k = q.ntaps++;
+          q.tap_off[k][0] = (int8_t)(base[0] - jd); q.tap_off[k][1] = (int8_t)(base[1] - jh);
+          q.tap_off[k][2] = (int8_t)(base[2] - jw);
+          q.tap_w[k] = (int16_t)(((pi[0] + 2 * jd) * 3 + (pi[1] + 2 * jh)) * 3 + (pi[2] + 2 * jw));
+        }
+  }
+  p.nphases = np;
+  return p;
+}
+
+// plain row GEMM: rows (D,H,W) of `cstride` floats, first SC used -> [rows][dcs], N columns
+static RdPlan plan_rows(int D, int H, int W, int SC, int cstride, int N, int dcs) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 1; p.SD = D; p.SH = H; p.SW = W; p.s_shift = 0; p.s_cstride = cstride; p.SC = SC;
+  p.w_rows_per_tap = SC; p.DD = D; p.DH = H; p.DW = W; p.d_cstride = dcs; p.N = N;
+  RdPhase& q = p.ph[0];
+  phase_defaults(q, D, H, W);
+  q.ntaps = 1;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------
+enum {
+  PL_GDENSE = 0, PL_G1F, PL_G2F, PL_G3F, PL_G9F, PL_G1B, PL_G2B, PL_G3B, PL_G9B,
+  PL_D1F, PL_D2F, PL_D3F, PL_D4F, PL_D2B, PL_D3B, PL_D4B, PL_D1B, PL_COUNT
+};
+
+struct rdgan_handle {
+  int nd, s, MB, NB;
+  std::string err;
+  // layouts
+  long goff[10], gsz[10], doff[10], dsz[10], n_gen, n_critic;
+  int n_in, n_nodes;
+  int gdim[4][3];              // generator grids: h0, h1, h2, h3
+  long gpix[4];
+  int gch[4];                  // channels of h0..h3
+  int ddim[5][3];              // critic: input grid + 4 conv outputs
+  long dL[5];
+  int dch[5];
+  int dpad[4][3];
+  int F;                       // critic Dense fan-in
+  // plans
+  std::vector<RdPlan> plans;
+  RdPlan* d_plans = nullptr;
+  // workspace
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  float *xcat, *h0, *h1, *r1, *h2, *r2, *h3, *r3, *P9, *fake, *dl, *gh3, *gup3, *dy2, *gup2, *dy1, *gup1, *ga0;
+  float *cin, *dh[5], *du[5], *v, *P1, *g0, *gpv;
+  float *wpartial, *cpartial;
+  size_t wpartial_cap = 0, cpartial_cap = 0;
+  float *DWT[5], *W1T, *GWT[4], *W9T;
+  int* d_flag;
+  // profiling
+  unsigned prof_mask = 0;
+  std::vector<hipEvent_t> ev_start[RDGAN_NUM_TAGS], ev_stop[RDGAN_NUM_TAGS];
+  size_t ev_used[RDGAN_NUM_TAGS] = {0};
+};
+
+#define RD_CHECK(h, call)                                                        \
+  do {                                                                           \
+    hipError_t e_ = (call);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      char b_[512];                                                              \
+      snprintf(b_, sizeof b_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      if (h) (h)->err = b_;                                                      \
+      return (int)e_;                                                            \
+    }                                                                            \
+  } while (0)
+#define RD_TRY(expr)            \
+  do {                          \
+    int r_ = (expr);            \
+    if (r_ != 0) return r_;     \
+  } while (0)
+
+static int bad_arg(rdgan_handle* h, const char* msg) {
+  if (h) h->err = msg;
+  return -2;
+}
+
+struct ProfScope {
+  rdgan_handle* h; int tag; hipStream_t st; bool on;
+  ProfScope(rdgan_handle* h_, int tag_, hipStream_t st_) : h(h_), tag(tag_), st(st_), on(false) {
+    if (h && tag >= 0 && (h->prof_mask >> tag & 1u) && h->ev_used[tag] < h->ev_start[tag].size()) {
+      on = true;
+      (void)hipEventRecord(h->ev_start[tag][h->ev_used[tag]], st);
+    }
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(h->ev_stop[tag][h->ev_used[tag]], st); h->ev_used[tag]++; }
+  }
+};
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------
+static long plan_tiles(const RdPlan& p, int B, int BM) {
+  long t = 0;
+  for (int i = 0; i < p.nphases; ++i) t += ((long)B * p.ph[i].L + BM - 1) / BM;
+  return t;
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
+static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
+                           const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
+  constexpr int AST = BK + 4, BST = BN + 4;
+  constexpr size_t lds = 2 * (size_t)(BM * AST + BK * BST) * sizeof(float);
+  static bool attr_done = false;
+  auto kern = k_conv_gemm<BM, BN, WM, WN, BK>;
+  if (!attr_done) {
+    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  long tm = plan_tiles(hp, B, BM);
+  if (tm <= 0) return 0;
+  dim3 grid((unsigned)tm, (unsigned)(hp.N / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, W, ldw, dst, epi);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* W,
+                       int ldw, float* dst, const RdEpi& epi, hipStream_t st, int tag) {
+  ProfScope ps(h, tag, st);
+  if (hp.SC < 32 && hp.SC != 27) {   // small-K taps (D1): BK = 8
+    if (hp.N % 64) return bad_arg(h, "conv: N % 64 != 0 for BK=8 path");
+    return launch_conv_cfg<128, 64, 2, 2, 8>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  }
+  if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200)
+    return launch_conv_cfg<128, 128, 2, 2, 32>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  if (hp.N % 64 == 0) {
+    if (plan_tiles(hp, B, 128) * (hp.N / 64) >= 200)
+      return launch_conv_cfg<128, 64, 2, 2, 32>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    return launch_conv_cfg<64, 64, 2, 2, 32>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  }
+  if (hp.N == 32) return launch_conv_cfg<128, 32, 4, 1, 32>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  return bad_arg(h, "conv: unsupported N");
+}
+
+static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int& nsplit) {
+  RdWgradTiling T; memset(&T, 0, sizeof(T));
+  const RdPhase& q = p.ph[0];
+  BR = p.SC >= 128 ? 128 : 64;
+  BN = (p.N % 128 == 0) ? 128 : 64;
+  if (p.SC >= BR) {
+    T.tiles_per_tap = (p.SC + BR - 1) / BR; T.cw = BR; T.taps_per_tile = 1; T.RT = q.ntaps * T.tiles_per_tap;
+  } else {
+    T.cw = next_pow2(std::max(p.SC, 4)); T.taps_per_tile = BR / T.cw; T.tiles_per_tap = 0;
+    T.RT = (q.ntaps + T.taps_per_tile - 1) / T.taps_per_tile;
+  }
+  T.NT = p.N / BN;
+  long rows = (long)B * q.L;
+  long tiles = (long)T.RT * T.NT;
+  long want = std::max(1L, (1024 + tiles - 1) / tiles);
+  long maxs = std::max(1L, (rows + 127) / 128);
+  long s = std::min(want, maxs);
+  long rps = (rows + s - 1) / s;
+  rps = (rps + 31) / 32 * 32;
+  T.rows_per_split = (int)rps;
+  nsplit = (int)((rows + rps - 1) / rps);
+  return T;
+}
+
+template <int BR, int BN>
+static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int B, const float* src, const float* dy,
+                            float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
+  constexpr size_t lds = 2 * (size_t)(32 * (BR + 4) + 32 * (BN + 4)) * sizeof(float);
+  static bool attr_done = false;
+  auto kern = k_wgrad_gemm<BR, BN>;
+  if (!attr_done) {
+    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(T.RT * T.NT), (unsigned)nsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, dy, partial, T);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+// dW (rows tap_w*wrpt + c, leading dimension ldw = N) from src (gathered through the plan) and dy
+static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* dy,
+                        float* dW, float* partial, size_t partial_cap, hipStream_t st, int tag) {
+  ProfScope ps(h, tag, st);
+  if (hp.nphases != 1 || hp.N % 64) return bad_arg(h, "wgrad: needs a single-phase plan and N % 64 == 0");
+  int BR, BN, nsplit;
+  RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
+  size_t need = (size_t)nsplit * T.RT * BR * hp.N;
+  if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
+  if (BR == 128 && BN == 128) RD_TRY((launch_wgrad_cfg<128, 128>(h, dp, B, src, dy, partial, T, nsplit, st)));
+  else if (BR == 128) RD_TRY((launch_wgrad_cfg<128, 64>(h, dp, B, src, dy, partial, T, nsplit, st)));
+  else if (BN == 128) RD_TRY((launch_wgrad_cfg<64, 128>(h, dp, B, src, dy, partial, T, nsplit, st)));
+  else RD_TRY((launch_wgrad_cfg<64, 64>(h, dp, B, src, dy, partial, T, nsplit, st)));
+  long total = (long)T.RT * BR * (hp.N / 4);
+  int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, dp, partial, nsplit, T, BR, dW, hp.N);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+static size_t wgrad_partial_need(const RdPlan& hp, int B) {
+  int BR, BN, nsplit;
+  RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
+  return (size_t)nsplit * T.RT * BR * hp.N;
+}
+
+static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>((n + per - 1) / per, 8192); }
+
+// out[c] = sum over rows of src[rows][C]
+static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, float* out, hipStream_t st) {
+  ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+  long nblk = std::min<long>(1024, std::max<long>(1, rows / 64));
+  if ((size_t)nblk * C > h->cpartial_cap) nblk = std::max<long>(1, (long)(h->cpartial_cap / C));
+  long rpb = (rows + nblk - 1) / nblk;
+  nblk = (rows + rpb - 1) / rpb;
+  int threads = std::max(64, std::min(256, (C + 63) / 64 * 64));
+  hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)nblk), dim3(threads), 0, st, src, rows, C, h->cpartial, rpb);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 255) / 256), dim3(256), 0, st, h->cpartial, (int)nblk, C, out);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+static int launch_transpose(rdgan_handle* h, const float* in, float* out, int T, int R, int C, int ldo, hipStream_t st) {
+  dim3 grid((C + 31) / 32, (std::max(R, ldo) + 31) / 32, T);
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, in, out, R, C, ldo);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+static int launch_pn_fwd(rdgan_handle* h, const float* y, float* hout, float* rinv, long npix, int C, hipStream_t st) {
+  long threads = npix * (C / 4);
+  dim3 grid((unsigned)((threads + 255) / 256));
+  if (C == 256) hipLaunchKernelGGL(k_pixelnorm_lrelu_fwd<64>, grid, dim3(256), 0, st, y, hout, rinv, npix);
+  else if (C == 128) hipLaunchKernelGGL(k_pixelnorm_lrelu_fwd<32>, grid, dim3(256), 0, st, y, hout, rinv, npix);
+  else if (C == 64) hipLaunchKernelGGL(k_pixelnorm_lrelu_fwd<16>, grid, dim3(256), 0, st, y, hout, rinv, npix);
+  else return bad_arg(h, "pixelnorm: C must be 64/128/256");
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+static int launch_pn_bwd(rdgan_handle* h, const float* g, const float* hh, const float* rinv, float* dy, long npix, int C,
+                         int pool, int D, int H, int W, hipStream_t st) {
+  long threads = npix * (C / 4);
+  dim3 grid((unsigned)((threads + 255) / 256));
+#define RD_PNB(LP, PO) hipLaunchKernelGGL((k_pn_lrelu_bwd<LP, PO>), grid, dim3(256), 0, st, g, hh, rinv, dy, npix, D, H, W)
+  if (C == 256) { if (pool) RD_PNB(64, 1); else RD_PNB(64, 0); }
+  else if (C == 128) { if (pool) RD_PNB(32, 1); else RD_PNB(32, 0); }
+  else if (C == 64) { if (pool) RD_PNB(16, 1); else RD_PNB(16, 0); }
+  else return bad_arg(h, "pixelnorm bwd: C must be 64/128/256");
+#undef RD_PNB
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------
+static void tf_same(int n, int& out, int& before) {
+  out = (n + 1) / 2;
+  int total = std::max((out - 1) * 2 + 3 - n, 0);
+  before = total / 2;   // the extra pad goes at the END
+}
+
+extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels, int max_batch) {
+  if (!out) return -2;
+  *out = nullptr;
+  if (ndomain < 8 || ndomain % 8 || ndomain > 120 || n_cond_channels != 1 || max_batch < 1) return -2;
+  rdgan_handle* h = new rdgan_handle();
+  h->nd = ndomain; h->s = ndomain / 8; h->MB = max_batch; h->NB = 3 * max_batch;
+  const int nd = ndomain, s = h->s;
+  h->n_in = RDGAN_LATENT_DIM + nd * nd;            // T:322-323
+  h->n_nodes = 256 * s * s * 3;                    // T:318, L:325
+  // generator grids (T:328-341)
+  const int gch[4] = {256, 256, 128, 64};
+  for (int l = 0; l < 4; ++l) {
+    h->gdim[l][0] = 3 << l; h->gdim[l][1] = s << l; h->gdim[l][2] = s << l;
+    h->gpix[l] = (long)h->gdim[l][0] * h->gdim[l][1] * h->gdim[l][2];
+    h->gch[l] = gch[l];
+  }
+  // critic grids (T:286-299)
+  const int dch[5] = {2, 64, 128, 256, 256};
+  h->ddim[0][0] = RDGAN_NHOURS; h->ddim[0][1] = nd; h->ddim[0][2] = nd;
+  for (int l = 1; l <= 4; ++l)
+    for (int a = 0; a < 3; ++a) {
+      if (l == 1) { h->ddim[1][a] = (h->ddim[0][a] - 3) / 2 + 1; h->dpad[0][a] = 0; }
+      else tf_same(h->ddim[l - 1][a], h->ddim[l][a], h->dpad[l - 1][a]);
+    }
+  for (int l = 0; l <= 4; ++l) { h->dL[l] = (long)h->ddim[l][0] * h->ddim[l][1] * h->ddim[l][2]; h->dch[l] = dch[l]; }
+  h->F = (int)(h->dL[4] * 256);
+  // parameter layouts (Keras weight order)
+  {
+    long gs[10] = {(long)h->n_in * h->n_nodes, h->n_nodes, 27L * 256 * 256, 256, 27L * 256 * 128, 128,
+                   27L * 128 * 64, 64, 27L * 64, 1};
+    long ds[10] = {27L * 2 * 64, 64, 27L * 64 * 128, 128, 27L * 128 * 256, 256, 27L * 256 * 256, 256, h->F, 1};
+    long o = 0;
+    for (int i = 0; i < 10; ++i) { h->goff[i] = o; h->gsz[i] = gs[i]; o += gs[i]; }
+    h->n_gen = o; o = 0;
+    for (int i = 0; i < 10; ++i) { h->doff[i] = o; h->dsz[i] = ds[i]; o += ds[i]; }
+    h->n_critic = o;
+  }
+  // plans
+  h->plans.resize(PL_COUNT);
+  h->plans[PL_GDENSE] = plan_rows(1, 1, 1, h->n_in, h->n_in, h->n_nodes, h->n_nodes);
+  for (int l = 1; l <= 3; ++l) {
+    const int* sd = h->gdim[l - 1]; const int* od = h->gdim[l];
+    h->plans[PL_G1F + l - 1] = plan_conv_fwd(sd[0], sd[1], sd[2], gch[l - 1], gch[l], od[0], od[1], od[2], 1, 1, 1, 1, 1);
+    h->plans[PL_G1B + l - 1] = plan_conv_dgrad_s1(od[0], od[1], od[2], gch[l - 1], gch[l]);
+  }
+  {
+    const int* g3 = h->gdim[3];
+    h->plans[PL_G9F] = plan_rows(g3[0], g3[1], g3[2], 64, 64, 32, 32);
+    h->plans[PL_G9B] = plan_rows(g3[0], g3[1], g3[2], 27, 32, 64, 64);
+  }
+  h->plans[PL_D1F] = plan_d1_fwd(nd, h->ddim[1][0], h->ddim[1][1], h->ddim[1][2]);
+  for (int l = 2; l <= 4; ++l) {
+    const int* id = h->ddim[l - 1]; const int* od = h->ddim[l]; const int* pd = h->dpad[l - 1];
+    h->plans[PL_D2F + l - 2] = plan_conv_fwd(id[0], id[1], id[2], dch[l - 1], dch[l], od[0], od[1], od[2], 2, pd[0], pd[1], pd[2], 0);
+    h->plans[PL_D2B + l - 2] = plan_conv_dgrad_s2(id[0], id[1], id[2], dch[l - 1], od[0], od[1], od[2], dch[l], pd);
+  }
+  h->plans[PL_D1B] = plan_rows(h->ddim[1][0], h->ddim[1][1], h->ddim[1][2], 64, 64, 64, 64);
+  hipError_t e = hipMalloc((void**)&h->d_plans, sizeof(RdPlan) * PL_COUNT);
+  if (e == hipSuccess) e = hipMemcpy(h->d_plans, h->plans.data(), sizeof(RdPlan) * PL_COUNT, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { delete h; return (int)e; }
+
+  // workspace carve (two passes: size, then assign)
+  const long MB = h->MB, NB = h->NB;
+  size_t wneed = 0;
+  {
+    const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B};
+    for (int id : wg) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)MB));
+    const int wd[] = {PL_D1F, PL_D2F, PL_D3F, PL_D4F};
+    for (int id : wd) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)NB));
+  }
+  h->wpartial_cap = wneed;
+  h->cpartial_cap = (size_t)1024 * std::max(h->n_nodes, 256);
+  for (int pass = 0; pass < 2; ++pass) {
+    size_t off = 0;
+    auto carve = [&](float*& p, size_t nfloats) {
+      off = (off + 255) & ~(size_t)255;
+      if (pass == 1) p = (float*)(h->ws + off);
+      off += nfloats * sizeof(float);
+    };
+    carve(h->xcat, MB * h->n_in);
+    carve(h->h0, MB * h->gpix[0] * 256);
+    carve(h->h1, MB * h->gpix[1] * 256); carve(h->r1, MB * h->gpix[1]);
+    carve(h->h2, MB * h->gpix[2] * 128); carve(h->r2, MB * h->gpix[2]);
+    carve(h->h3, MB * h->gpix[3] * 64); carve(h->r3, MB * h->gpix[3]);
+    carve(h->P9, MB * h->gpix[3] * 32);
+    carve(h->fake, MB * h->gpix[3]);
+    carve(h->dl, MB * h->gpix[3]);
+    carve(h->gh3, MB * h->gpix[3] * 64);
+    carve(h->gup3, MB * h->gpix[3] * 128);
+    carve(h->dy2, MB * h->gpix[2] * 128);
+    carve(h->gup2, MB * h->gpix[2] * 256);
+    carve(h->dy1, MB * h->gpix[1] * 256);
+    carve(h->gup1, MB * h->gpix[1] * 256);
+    carve(h->ga0, MB * h->gpix[0] * 256);
+    carve(h->cin, NB * h->dL[0] * 2);
+    h->dh[0] = nullptr; h->du[0] = nullptr;
+    for (int l = 1; l <= 4; ++l) { carve(h->dh[l], NB * h->dL[l] * dch[l]); carve(h->du[l], NB * h->dL[l] * dch[l]); }
+    carve(h->v, NB);
+    carve(h->P1, MB * h->dL[1] * 64);
+    carve(h->g0, MB * h->dL[0]);
+    carve(h->gpv, MB);
+    carve(h->wpartial, h->wpartial_cap);
+    carve(h->cpartial, h->cpartial_cap);
+    h->DWT[0] = h->DWT[1] = nullptr;
+    for (int l = 2; l <= 4; ++l) carve(h->DWT[l], 27L * dch[l - 1] * dch[l]);
+    carve(h->W1T, 64 * 64);
+    h->GWT[0] = nullptr;
+    for (int l = 1; l <= 3; ++l) carve(h->GWT[l], 27L * gch[l - 1] * gch[l]);
+    carve(h->W9T, 64 * 32);
+    { float* f = nullptr; carve(f, 64); if (pass == 1) h->d_flag = (int*)f; }
+    if (pass == 0) {
+      h->ws_bytes = off + 256;
+      e = hipMalloc((void**)&h->ws, h->ws_bytes);
+      if (e != hipSuccess) { (void)hipFree(h->d_plans); delete h; return (int)e; }
+      (void)hipMemset(h->ws, 0, h->ws_bytes);
+    }
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" void rdgan_destroy(rdgan_handle* h) {
+  if (!h) return;
+  for (int t = 0; t < RDGAN_NUM_TAGS; ++t) {
+    for (auto e : h->ev_start[t]) (void)hipEventDestroy(e);
+    for (auto e : h->ev_stop[t]) (void)hipEventDestroy(e);
+  }
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->d_plans) (void)hipFree(h->d_plans);
+  delete h;
+}
+
+extern "C" const char* rdgan_last_error(const rdgan_handle* h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" long rdgan_gen_param_count(const rdgan_handle* h) { return h ? h->n_gen : -1; }
+extern "C" long rdgan_critic_param_count(const rdgan_handle* h) { return h ? h->n_critic : -1; }
+extern "C" long rdgan_workspace_bytes(const rdgan_handle* h) { return h ? (long)h->ws_bytes : -1; }
+extern "C" int rdgan_gen_param_layout(const rdgan_handle* h, long* offsets, long* sizes) {
+  if (!h) return -2;
+  for (int i = 0; i < 10; ++i) { if (offsets) offsets[i] = h->goff[i]; if (sizes) sizes[i] = h->gsz[i]; }
+  return 10;
+}
+extern "C" int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes) {
+  if (!h) return -2;
+  for (int i = 0; i < 10; ++i) { if (offsets) offsets[i] = h->doff[i]; if (sizes) sizes[i] = h->dsz[i]; }
+  return 10;
+}
+
+extern "C" int rdgan_profile(rdgan_handle* h, unsigned tag_mask) {
+  if (!h) return -2;
+  h->prof_mask = tag_mask;
+  for (int t = 0; t < RDGAN_NUM_TAGS; ++t) {
+    h->ev_used[t] = 0;
+    if ((tag_mask >> t & 1u) && h->ev_start[t].empty()) {
+      h->ev_start[t].resize(4096); h->ev_stop[t].resize(4096);
+      for (size_t i = 0; i < 4096; ++i) {
+        RD_CHECK(h, hipEventCreate(&h->ev_start[t][i]));
+        RD_CHECK(h, hipEventCreate(&h->ev_stop[t][i]));
+      }
+    }
+  }
+  return 0;
+}
+extern "C" int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, long* launches) {
+  if (!h || tag < 0 || tag >= RDGAN_NUM_TAGS) return -2;
+  RD_CHECK(h, hipDeviceSynchronize());
+  double tot = 0;
+  for (size_t i = 0; i < h->ev_used[tag]; ++i) {
+    float ms = 0;
+    RD_CHECK(h, hipEventElapsedTime(&ms, h->ev_start[tag][i], h->ev_stop[tag][i]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (long)h->ev_used[tag];
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// generator forward (T:312-357)
+// ------------------------------------------------------------------------------------
+static RdEpi epi_make(int mode, const float* bias = nullptr, const float* aux = nullptr, int use_drop = 0,
+                      uint32_t key = 0, uint32_t idx_base = 0) {
+  RdEpi e; e.mode = mode; e.use_drop = use_drop; e.key = key; e.idx_base = idx_base; e.bias = bias; e.aux = aux;
+  return e;
+}
+
+static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, const float* cond, float* out, int B,
+                            hipStream_t st) {
+  const int nd = h->nd;
+  // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
+  RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, st));
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    hipLaunchKernelGGL(k_concat, dim3(ew_blocks((long)B * h->n_in)), dim3(256), 0, st, z, cond, h->xcat, B,
+                       RDGAN_LATENT_DIM, nd * nd);
+  }
+  // Dense + LeakyReLU (T:326-327); the Reshape (T:328) is a view
+  RD_TRY(launch_conv(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, gp + h->goff[0], h->n_nodes, h->h0,
+                     epi_make(RD_EPI_BIAS_LRELU, gp + h->goff[1]), st, -1));
+  float* hs[4] = {h->h0, h->h1, h->h2, h->h3};
+  float* rs[4] = {nullptr, h->r1, h->r2, h->r3};
+  for (int l = 1; l <= 3; ++l) {
+    // UpSampling3D + Conv3D + bias (T:330-331), then PixelNorm + LeakyReLU (T:332-333)
+    RD_TRY(launch_conv(h, h->plans[PL_G1F + l - 1], h->d_plans + PL_G1F + l - 1, B, hs[l - 1], gp + h->goff[2 * l],
+                       h->gch[l], hs[l], epi_make(RD_EPI_BIAS, gp + h->goff[2 * l + 1]), st,
+                       l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st));
+  }
+  // Conv3D 64->1 (T:345) as column GEMM + gather, bias, Softmax(axis=1) (T:347), check_numerics (T:349-350)
+  RD_TRY(launch_conv(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, epi_make(RD_EPI_PLAIN), st, -1));
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    long ncol = (long)B * nd * nd;
+    hipLaunchKernelGGL(k_colgather_softmax, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->P9, gp + h->goff[9],
+                       out, B, RDGAN_NHOURS, nd, nd, h->d_flag);
+  }
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" int rdgan_gen_forward(rdgan_handle* h, const float* gen_params, const float* z, const float* cond,
+                                 float* out, int B, void* stream) {
+  if (!h || !gen_params || !z || !cond || !out) return bad_arg(h, "gen_forward: null pointer");
+  if (B < 1 || B > h->MB) return bad_arg(h, "gen_forward: B outside [1, max_batch]");
+  return gen_forward_impl(h, gen_params, z, cond, out, B, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------
+// critic
+// ------------------------------------------------------------------------------------
+static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st) {
+  for (int l = 2; l <= 4; ++l)   // [27][Cin][Cout] -> [27][Cout][Cin]
+    RD_TRY(launch_transpose(h, dp + h->doff[2 * (l - 1)], h->DWT[l], 27, h->dch[l - 1], h->dch[l], h->dch[l - 1], st));
+  // W1 [54][64] -> W1T [64][64] (columns (tap,ci), zero padded 54..63)
+  RD_TRY(launch_transpose(h, dp + h->doff[0], h->W1T, 1, 54, 64, 64, st));
+  return 0;
+}
+
+// forward over NBt samples already laid out in h->cin; writes h->dh[1..4], h->v
+static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64_t seed, hipStream_t st) {
+  const int use_drop = seed != 0;
+  const float* in = h->cin;
+  for (int l = 1; l <= 4; ++l) {
+    int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
+    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, in, dp + h->doff[2 * (l - 1)], h->dch[l], h->dh[l],
+                       epi_make(RD_EPI_BIAS_LRELU_DROP, dp + h->doff[2 * (l - 1) + 1], nullptr, use_drop,
+                                rd_make_key(seed, RD_STREAM_D1 + l - 1), 0),
+                       st, RDGAN_TAG_CRITIC_GEMM));
+    in = h->dh[l];
+  }
+  ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+  hipLaunchKernelGGL(k_critic_dense_fwd, dim3(NBt), dim3(256), 0, st, h->dh[4], dp + h->doff[8], dp + h->doff[9], h->v, h->F);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+// input-gradient chain u4 -> u1 over NBt samples (mode 0: critic step 3B batch, 1: generator step)
+static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, int mode, uint64_t seed, hipStream_t st) {
+  const int use_drop = seed != 0;
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    hipLaunchKernelGGL(k_critic_top_bwd, dim3(ew_blocks((long)NBt * h->F)), dim3(256), 0, st, h->dh[4], dp + h->doff[8],
+                       h->du[4], NBt, h->F, B, mode, use_drop, rd_make_key(seed, RD_STREAM_D1 + 3));
+  }
+  for (int l = 4; l >= 2; --l) {
+    int pl = PL_D2B + l - 2;
+    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->DWT[l], h->dch[l - 1], h->du[l - 1],
+                       epi_make(RD_EPI_GATE_AUX, nullptr, h->dh[l - 1], use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 2), 0),
+                       st, RDGAN_TAG_CRITIC_GEMM));
+  }
+  return 0;
+}
+
+// dD/d(sample channel) for `B` samples whose u1 starts at u1: column GEMM + col2im -> h->g0
+static int critic_input_grad(rdgan_handle* h, const float* u1, int B, hipStream_t st) {
+  RD_TRY(launch_conv(h, h->plans[PL_D1B], h->d_plans + PL_D1B, B, u1, h->W1T, 64, h->P1, epi_make(RD_EPI_PLAIN), st,
+                     RDGAN_TAG_CRITIC_GEMM));
+  ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+  hipLaunchKernelGGL(k_d1_col2im, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, h->P1, h->g0, B, h->ddim[0][0],
+                     h->ddim[0][1], h->ddim[0][2], h->ddim[1][0], h->ddim[1][1], h->ddim[1][2]);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params, const float* sample, const float* cond,
+                                    float* out, int B, uint64_t seed, void* stream) {
+  if (!h || !critic_params || !sample || !cond || !out) return bad_arg(h, "critic_forward: null pointer");
+  if (B < 1 || B > h->NB) return bad_arg(h, "critic_forward: B outside [1, 3*max_batch]");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_build_critic_input1, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, sample, cond, h->cin,
+                     B, h->ddim[0][0], h->nd * h->nd);
+  RD_TRY(critic_forward_impl(h, critic_params, B, seed, st));
+  RD_CHECK(h, hipMemcpyAsync(out, h->v, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* gp, const float* x_real,
+                                 const float* cond, const float* z, uint64_t seed, float* grad, int B, void* stream) {
+  if (!h || !dp || !gp || !x_real || !cond || !z || !grad) return bad_arg(h, "critic_grad: null pointer");
+  if (B < 1 || B > h->MB) return bad_arg(h, "critic_grad: B outside [1, max_batch]");
+  hipStream_t st = (hipStream_t)stream;
+  const int NBt = 3 * B;
+  const int use_drop = seed != 0;
+  RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
+  RD_TRY(prep_critic_weights(h, dp, st));
+  // fake = G(z, cond), generator frozen (T:363,370)
+  RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st));
+  // [real; fake; alpha*real + (1-alpha)*fake] with the condition as 2nd channel (T:275-282, T:376)
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, x_real, h->fake, cond,
+                       h->cin, B, h->ddim[0][0], h->nd * h->nd, 0, rd_make_key(seed, RD_STREAM_ALPHA));
+  }
+  RD_TRY(critic_forward_impl(h, dp, NBt, seed, st));           // T:372,373,379 as one batch
+  RD_TRY(critic_dgrad_chain(h, dp, NBt, B, 0, seed, st));       // dL/dh for real|fake, dD/dh for x_hat
+  // gradient penalty (T:238-241, T:382): g0 = dD/dx_hat, n = ||g0||, r0 = d(10 mean((n-1)^2))/dg0
+  RD_TRY(critic_input_grad(h, h->du[1] + (long)2 * B * h->dL[1] * 64, B, st));
+  float* cin_hat = h->cin + (long)2 * B * h->dL[0] * 2;
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    hipLaunchKernelGGL(k_gp_norm_r0, dim3(B), dim3(256), 0, st, h->g0, cin_hat, h->gpv, (int)h->dL[0], B, RD_GP_WEIGHT);
+  }
+  // second forward sweep of the double backward: r_l = gate_l * conv_l(r_{l-1}), in place over the x_hat third
+  {
+    const float* in = cin_hat;
+    for (int l = 1; l <= 4; ++l) {
+      int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
+      long third = (long)2 * B * h->dL[l] * h->dch[l];
+      float* dst = h->dh[l] + third;
+      RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, in, dp + h->doff[2 * (l - 1)], h->dch[l], dst,
+                         epi_make(RD_EPI_GATE_AUX, nullptr, dst, use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 1),
+                                  (uint32_t)third),
+                         st, RDGAN_TAG_CRITIC_GEMM));
+      in = dst;
+    }
+  }
+  // weight gradients over the 3B batch: inputs [h_real; h_fake; r_hat], output grads [u_real; u_fake; u_hat]
+  for (int l = 1; l <= 4; ++l) {
+    int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
+    const float* in = l == 1 ? h->cin : h->dh[l - 1];
+    RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], grad + h->doff[2 * (l - 1)], h->wpartial,
+                        h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM));
+    // bias gradient: only the real|fake passes reach the loss through the bias (the penalty term does not)
+    RD_TRY(launch_colsum(h, h->du[l], (long)2 * B * h->dL[l], h->dch[l], grad + h->doff[2 * (l - 1) + 1], st));
+  }
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    hipLaunchKernelGGL(k_critic_dense_wgrad, dim3((h->F + 255) / 256), dim3(256), 0, st, h->dh[4], grad + h->doff[8], NBt,
+                       h->F, B);
+    RD_CHECK(h, hipMemsetAsync(grad + h->doff[9], 0, sizeof(float), st));   // sum of dv over real|fake = 0
+    RD_CHECK(h, hipMemsetAsync(grad + h->n_critic, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));
+    hipLaunchKernelGGL(k_critic_losses, dim3(1), dim3(256), 0, st, h->v, h->gpv, grad + h->n_critic, B, RD_GP_WEIGHT);
+  }
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// generator step gradients (T:395-408)
+// ------------------------------------------------------------------------------------
+extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp, const float* z, const float* cond,
+                              uint64_t seed, float* grad, int B, void* stream) {
+  if (!h || !dp || !gp || !z || !cond || !grad) return bad_arg(h, "gen_grad: null pointer");
+  if (B < 1 || B > h->MB) return bad_arg(h, "gen_grad: B outside [1, max_batch]");
+  hipStream_t st = (hipStream_t)stream;
+  const int nd = h->nd;
+  RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
+  RD_TRY(prep_critic_weights(h, dp, st));
+  for (int l = 1; l <= 3; ++l)
+    RD_TRY(launch_transpose(h, gp + h->goff[2 * l], h->GWT[l], 27, h->gch[l - 1], h->gch[l], h->gch[l - 1], st));
+  RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st));
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, (const float*)nullptr,
+                       h->fake, cond, h->cin, B, h->ddim[0][0], nd * nd, 1, 0u);
+  }
+  RD_TRY(critic_forward_impl(h, dp, B, seed, st));              // critic frozen, dropout active (T:395,405)
+  RD_TRY(critic_dgrad_chain(h, dp, B, B, 1, seed, st));
+  RD_TRY(critic_input_grad(h, h->du[1], B, st));                 // g0 = dL/d fake
+  const long npix3 = (long)B * h->gpix[3];
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    long ncol = (long)B * nd * nd;
+    hipLaunchKernelGGL(k_softmax_bwd, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->fake, h->g0, h->dl, B,
+                       RDGAN_NHOURS, nd, nd);
+    hipLaunchKernelGGL(k_dl_im2col, dim3(ew_blocks(npix3 * 8)), dim3(256), 0, st, h->dl, h->P9, B, RDGAN_NHOURS, nd, nd);
+  }
+  // last conv (64 -> 1, T:345): weight grad [27][64], bias grad, input grad
+  RD_TRY(launch_wgrad(h, h->plans[PL_G9B], h->d_plans + PL_G9B, B, h->P9, h->h3, grad + h->goff[8], h->wpartial,
+                      h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
+  RD_TRY(launch_colsum(h, h->dl, npix3 / 64, 64, h->ga0, st));   // 64 partial sums of dl (npix3 % 64 == 0)
+  RD_TRY(launch_colsum(h, h->ga0, 64, 1, grad + h->goff[9], st));
+  RD_TRY(launch_conv(h, h->plans[PL_G9B], h->d_plans + PL_G9B, B, h->P9, gp + h->goff[8], 64, h->gh3,
+                     epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
+  // three [upsample, conv, pixelnorm, lrelu] blocks, last to first
+  float* hs[4] = {h->h0, h->h1, h->h2, h->h3};
+  float* rs[4] = {nullptr, h->r1, h->r2, h->r3};
+  float* dys[4] = {nullptr, h->dy1, h->dy2, h->gh3};
+  float* gups[4] = {nullptr, h->gup1, h->gup2, h->gup3};
+  for (int l = 3; l >= 1; --l) {
+    {
+      ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+      if (l == 3) RD_TRY(launch_pn_bwd(h, h->gh3, hs[3], rs[3], dys[3], npix3, 64, 0, 0, 0, 0, st));
+      else RD_TRY(launch_pn_bwd(h, gups[l + 1], hs[l], rs[l], dys[l], (long)B * h->gpix[l], h->gch[l], 1, h->gdim[l][0],
+                                h->gdim[l][1], h->gdim[l][2], st));
+    }
+    int plf = PL_G1F + l - 1, plb = PL_G1B + l - 1;
+    RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], grad + h->goff[2 * l], h->wpartial,
+                        h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
+    RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
+    RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWT[l], h->gch[l - 1], gups[l],
+                       epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
+  }
+  // Dense (T:326): pool the upsample adjoint, LeakyReLU', then dW = xcat^T ga0, db = colsum(ga0)
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    hipLaunchKernelGGL(k_pool_lrelu_bwd, dim3(ew_blocks((long)B * h->gpix[0] * 64)), dim3(256), 0, st, h->gup1, h->h0,
+                       h->ga0, (long)B * h->gpix[0], h->gdim[0][0], h->gdim[0][1], h->gdim[0][2], 256);
+  }
+  RD_TRY(launch_wgrad(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, h->ga0, grad + h->goff[0], h->wpartial,
+                      h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
+  RD_TRY(launch_colsum(h, h->ga0, B, h->n_nodes, grad + h->goff[1], st));
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    RD_CHECK(h, hipMemsetAsync(grad + h->n_gen, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));
+    hipLaunchKernelGGL(k_gen_loss, dim3(1), dim3(256), 0, st, h->v, grad + h->n_gen, B);
+  }
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" int rdgan_adam(float* params, const float* grad, float* v, long n, int t, float lr, float beta2, float eps,
+                          float grad_scale, void* stream) {
+  if (!params || !grad || !v || n < 1 || t < 1) return -2;
+  float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)t));
+  hipLaunchKernelGGL(k_adam, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, params, grad, v, n, lr_t, beta2,
+                     eps, grad_scale);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// op-level entry points for the parity tests
+// ------------------------------------------------------------------------------------
+struct TmpPlan {
+  RdPlan host; RdPlan* dev = nullptr;
+  int upload() {
+    hipError_t e = hipMalloc((void**)&dev, sizeof(RdPlan));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpy(dev, &host, sizeof(RdPlan), hipMemcpyHostToDevice);
+  }
+  ~TmpPlan() { if (dev) (void)hipFree(dev); }
+};
+
+extern "C" int rdgan_op_conv3d(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W,
+                               int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h, int pad_w,
+                               int upsample, void* stream) {
+  if (!x || !w || !y || Cin % 4 || (Cout % 64 && Cout != 32)) return -2;
+  TmpPlan tp;
+  tp.host = plan_conv_fwd(D, H, W, Cin, Cout, Do, Ho, Wo, stride, pad_d, pad_h, pad_w, upsample);
+  RD_TRY(tp.upload());
+  hipStream_t st = (hipStream_t)stream;
+  RD_TRY(launch_conv(nullptr, tp.host, tp.dev, B, x, w, Cout, y, epi_make(bias ? RD_EPI_BIAS : RD_EPI_PLAIN, bias), st, -1));
+  return (int)hipStreamSynchronize(st);
+}
+
+extern "C" int rdgan_op_conv3d_dgrad(const float* gy, const float* w, float* gx, int B, int D, int H, int W, int Cin,
+                                     int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h, int pad_w,
+                                     void* stream) {
+  if (!gy || !w || !gx || Cout % 4 || Cin % 64) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  float* wt = nullptr;
+  hipError_t e = hipMalloc((void**)&wt, sizeof(float) * 27 * Cin * Cout);
+  if (e != hipSuccess) return (int)e;
+  int rc = launch_transpose(nullptr, w, wt, 27, Cin, Cout, Cin, st);
+  TmpPlan tp;
+  if (stride == 1) {
+    if (pad_d != 1 || pad_h != 1 || pad_w != 1 || Do != D || Ho != H || Wo != W) { (void)hipFree(wt); return -2; }
+    tp.host = plan_conv_dgrad_s1(D, H, W, Cin, Cout);
+  } else {
+    int pad[3] = {pad_d, pad_h, pad_w};
+    tp.host = plan_conv_dgrad_s2(D, H, W, Cin, Do, Ho, Wo, Cout, pad);
+  }
+  if (rc == 0) rc = tp.upload();
+  if (rc == 0) rc = launch_conv(nullptr, tp.host, tp.dev, B, gy, wt, Cin, gx, epi_make(RD_EPI_PLAIN), st, -1);
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  (void)hipFree(wt);
+  return rc;
+}
+
+extern "C" int rdgan_op_conv3d_wgrad(const float* x, const float* gy, float* dw, int B, int D, int H, int W, int Cin,
+                                     int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h, int pad_w,
+                                     int upsample, void* stream) {
+  if (!x || !gy || !dw || Cin % 4 || Cout % 64) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  TmpPlan tp;
+  tp.host = plan_conv_fwd(D, H, W, Cin, Cout, Do, Ho, Wo, stride, pad_d, pad_h, pad_w, upsample);
+  RD_TRY(tp.upload());
+  size_t need = wgrad_partial_need(tp.host, B);
+  float* partial = nullptr;
+  hipError_t e = hipMalloc((void**)&partial, need * sizeof(float));
+  if (e != hipSuccess) return (int)e;
+  int rc = launch_wgrad(nullptr, tp.host, tp.dev, B, x, gy, dw, partial, need, st, -1);
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  (void)hipFree(partial);
+  return rc;
+}
+
+extern "C" int rdgan_op_pixelnorm_lrelu(const float* y, float* hout, float* rinv, long npix, int C, void* stream) {
+  if (!y || !hout) return -2;
+  RD_TRY(launch_pn_fwd(nullptr, y, hout, rinv, npix, C, (hipStream_t)stream));
+  return (int)hipStreamSynchronize((hipStream_t)stream);
+}
+extern "C" int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* hh, const float* rinv, float* dy, long npix, int C,
+                                            void* stream) {
+  if (!gh || !hh || !rinv || !dy) return -2;
+  RD_TRY(launch_pn_bwd(nullptr, gh, hh, rinv, dy, npix, C, 0, 0, 0, 0, (hipStream_t)stream));
+  return (int)hipStreamSynchronize((hipStream_t)stream);
+}
+
+__global__ void k_rng_probe(uint32_t key, float* mask, float* uni, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (mask) mask[i] = rd_drop_scale(key, (uint32_t)i);
+    if (uni) uni[i] = rd_uniform(key, (uint32_t)i);
+  }
+}
+extern "C" int rdgan_op_rng(uint64_t seed, uint32_t stream_id, float* mask_out, float* uniform_out, long n, void* stream) {
+  hipLaunchKernelGGL(k_rng_probe, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, rd_make_key(seed, stream_id),
+                     mask_out, uniform_out, n);
+  return (int)hipStreamSynchronize((hipStream_t)stream);
+}

@@ -1,0 +1,445 @@
+// HBM-bound elementwise / reduction kernels of the cWGAN-GP step (gfx950, wave64).
+// T = gan_train_cwgangp_pixelnorm.py in the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rdgan_gemm.hip.h"
+
+#define RD_PIXELNORM_EPS 1.0e-8f
+
+__device__ __forceinline__ float rd_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LP>
+__device__ __forceinline__ float rd_seg_sum(float v) {   // sum over aligned groups of LP lanes
+#pragma unroll
+  for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// block-wide sum, result valid in thread 0 (256 threads)
+__device__ __forceinline__ float rd_block_sum(float v, float* red) {
+  v = rd_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  __syncthreads();
+  return s;
+}
+
+// G0 (T:322-323): out[b] = [z[b] (nz) | cond[b].flatten (nc)]
+__global__ void k_concat(const float* __restrict__ z, const float* __restrict__ cond, float* __restrict__ out,
+                         int B, int nz, int nc) {
+  const int w = nz + nc;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)B * w; i += (long)gridDim.x * blockDim.x) {
+    int b = (int)(i / w), j = (int)(i - (long)b * w);
+    out[i] = j < nz ? z[(long)b * nz + j] : cond[(long)b * nc + (j - nz)];
+  }
+}
+
+// G7+G8 (T:255-266, T:333): h = LeakyReLU(y / sqrt(mean_c(y^2) + 1e-8)); rinv = 1/sqrt(..) kept for backward.
+// In place allowed (h == y).  LP = C/4 lanes per pixel.
+template <int LP>
+__global__ void k_pixelnorm_lrelu_fwd(const float* __restrict__ y, float* __restrict__ h, float* __restrict__ rinv,
+                                      long npix) {
+  constexpr int C = LP * 4;
+  const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long pix = gid / LP;
+  const int sub = (int)(gid % LP);
+  const bool ok = pix < npix;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (ok) v = *(const f32x4*)(y + pix * C + sub * 4);
+  float ss = rd_seg_sum<LP>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+  float l2 = sqrtf(ss * (1.0f / C) + RD_PIXELNORM_EPS);
+  if (ok) {
+    f32x4 o;
+    o.x = rd_lrelu(v.x / l2); o.y = rd_lrelu(v.y / l2); o.z = rd_lrelu(v.z / l2); o.w = rd_lrelu(v.w / l2);
+    *(f32x4*)(h + pix * C + sub * 4) = o;
+    if (rinv && sub == 0) rinv[pix] = 1.0f / l2;
+  }
+}
+
+// backward of [PixelNorm -> LeakyReLU] given h (the block output) and rinv:
+//   n = h>0 ? h : h/alpha ; gn = gh*slope(h) ; dy = rinv*(gn - n*mean_c(gn*n))
+// gh is either given on the same grid (POOL=0) or as the gradient on the 2x upsampled grid of the
+// next block's conv input, in which case the 8 children are summed first (adjoint of UpSampling3D, T:335).
+template <int LP, int POOL>
+__global__ void k_pn_lrelu_bwd(const float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ rinv,
+                               float* __restrict__ dy, long npix, int D, int H, int W) {
+  constexpr int C = LP * 4;
+  const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long pix = gid / LP;
+  const int sub = (int)(gid % LP);
+  const bool ok = pix < npix;
+  f32x4 gh = {0.f, 0.f, 0.f, 0.f}, hv = {0.f, 0.f, 0.f, 0.f};
+  float ri = 0.f;
+  if (ok) {
+    hv = *(const f32x4*)(h + pix * C + sub * 4);
+    ri = rinv[pix];
+    if (POOL) {
+      long t = pix;
+      int w = (int)(t % W); t /= W;
+      int hh = (int)(t % H); t /= H;
+      int d = (int)(t % D);
+      long b = t / D;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        long up = (((b * (2 * D) + 2 * d + (e >> 2)) * (2 * H) + 2 * hh + ((e >> 1) & 1)) * (2 * W) + 2 * w + (e & 1));
+        gh += *(const f32x4*)(g + up * C + sub * 4);
+      }
+    } else {
+      gh = *(const f32x4*)(g + pix * C + sub * 4);
+    }
+  }
+  f32x4 n, gn;
+  n.x = hv.x > 0.f ? hv.x : hv.x * (1.0f / RD_LRELU_ALPHA);
+  n.y = hv.y > 0.f ? hv.y : hv.y * (1.0f / RD_LRELU_ALPHA);
+  n.z = hv.z > 0.f ? hv.z : hv.z * (1.0f / RD_LRELU_ALPHA);
+  n.w = hv.w > 0.f ? hv.w : hv.w * (1.0f / RD_LRELU_ALPHA);
+  gn.x = gh.x * rd_lrelu_slope_from_out(hv.x);
+  gn.y = gh.y * rd_lrelu_slope_from_out(hv.y);
+  gn.z = gh.z * rd_lrelu_slope_from_out(hv.z);
+  gn.w = gh.w * rd_lrelu_slope_from_out(hv.w);
+  float dot = rd_seg_sum<LP>(gn.x * n.x + gn.y * n.y + gn.z * n.z + gn.w * n.w) * (1.0f / C);
+  if (ok) {
+    f32x4 o;
+    o.x = ri * (gn.x - n.x * dot); o.y = ri * (gn.y - n.y * dot);
+    o.z = ri * (gn.z - n.z * dot); o.w = ri * (gn.w - n.w * dot);
+    *(f32x4*)(dy + pix * C + sub * 4) = o;
+  }
+}
+
+// gradient wrt the Dense pre-activation (T:326-328): sum the 8 children of the first block's
+// upsampled-grid gradient and apply LeakyReLU' from the stored output h0.  C = 256.
+__global__ void k_pool_lrelu_bwd(const float* __restrict__ gup, const float* __restrict__ h0, float* __restrict__ out,
+                                 long npix, int D, int H, int W, int C) {
+  const int c4s = C / 4;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < npix * c4s; f += (long)gridDim.x * blockDim.x) {
+    long pix = f / c4s;
+    int c = (int)(f - pix * c4s) * 4;
+    long t = pix;
+    int w = (int)(t % W); t /= W;
+    int hh = (int)(t % H); t /= H;
+    int d = (int)(t % D);
+    long b = t / D;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      long up = (((b * (2 * D) + 2 * d + (e >> 2)) * (2 * H) + 2 * hh + ((e >> 1) & 1)) * (2 * W) + 2 * w + (e & 1));
+      s += *(const f32x4*)(gup + up * C + c);
+    }
+    f32x4 hv = *(const f32x4*)(h0 + pix * C + c);
+    s.x *= rd_lrelu_slope_from_out(hv.x); s.y *= rd_lrelu_slope_from_out(hv.y);
+    s.z *= rd_lrelu_slope_from_out(hv.z); s.w *= rd_lrelu_slope_from_out(hv.w);
+    *(f32x4*)(out + pix * C + c) = s;
+  }
+}
+
+// G9+G10+G11 (T:345-350): logits[pos] = bias + sum_tap P[pos+tap-1][tap] from the column GEMM
+// P[pos][32] = h3[pos][:] . W9[:, tap]; then softmax over the 24 hours of each grid point.
+// One thread per (sample, h, w) column.  Sets *nonfinite if any output is NaN/Inf.
+__global__ void k_colgather_softmax(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ out,
+                                    int B, int D, int H, int W, int* __restrict__ nonfinite) {
+  const long ncol = (long)B * H * W;
+  const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (gid >= ncol) return;
+  const int w = (int)(gid % W), h = (int)((gid / W) % H);
+  const long b = gid / ((long)W * H);
+  const float bv = bias[0];
+  const long hw = (long)H * W;
+  float* o = out + b * D * hw + (long)h * W + w;
+  float mx = -3.0e38f;
+  for (int d = 0; d < D; ++d) {
+    float s = bv;
+    for (int td = 0; td < 3; ++td) {
+      int sd = d + td - 1;
+      if ((unsigned)sd >= (unsigned)D) continue;
+      for (int th = 0; th < 3; ++th) {
+        int shh = h + th - 1;
+        if ((unsigned)shh >= (unsigned)H) continue;
+        for (int tw = 0; tw < 3; ++tw) {
+          int sw = w + tw - 1;
+          if ((unsigned)sw >= (unsigned)W) continue;
+          long pos = ((b * D + sd) * H + shh) * W + sw;
+          s += P[pos * 32 + (td * 3 + th) * 3 + tw];
+        }
+      }
+    }
+    o[d * hw] = s;               // raw logit, re-read by this same thread below
+    mx = fmaxf(mx, s);
+  }
+  float den = 0.f;
+  for (int d = 0; d < D; ++d) { float e = expf(o[d * hw] - mx); o[d * hw] = e; den += e; }
+  bool bad = false;
+  for (int d = 0; d < D; ++d) {
+    float p = o[d * hw] / den;
+    bad |= !(fabsf(p) <= 3.0e38f);
+    o[d * hw] = p;
+  }
+  if (bad) atomicOr(nonfinite, 1);
+}
+
+// softmax-over-hours backward: dl = p * (g - sum_d p*g), one thread per (sample,h,w) column.
+__global__ void k_softmax_bwd(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ dl,
+                              int B, int D, int H, int W) {
+  const long ncol = (long)B * H * W;
+  const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (gid >= ncol) return;
+  const long hw = (long)H * W;
+  const long b = gid / hw, r = gid - b * hw;
+  const long base = b * D * hw + r;
+  float pv[24], dot = 0.f;
+#pragma unroll
+  for (int d = 0; d < 24; ++d) { pv[d] = p[base + d * hw]; dot += pv[d] * g[base + d * hw]; }
+#pragma unroll
+  for (int d = 0; d < 24; ++d) dl[base + d * hw] = pv[d] * (g[base + d * hw] - dot);
+}
+
+// im2col of the 1-channel dlogits for the G9 input/weight gradients:
+// col[pos][tap] = dl[pos + 1 - tap] (zero outside), columns 27..31 zero.
+__global__ void k_dl_im2col(const float* __restrict__ dl, float* __restrict__ col, int B, int D, int H, int W) {
+  const long total = (long)B * D * H * W * 8;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+    long pos = f >> 3;
+    int t0 = (int)(f & 7) * 4;
+    long t = pos;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H); t /= H;
+    int d = (int)(t % D);
+    long b = t / D;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int tap = t0 + e;
+      float v = 0.f;
+      if (tap < 27) {
+        int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+        int sd = d + 1 - td, shh = h + 1 - th, sw = w + 1 - tw;
+        if ((unsigned)sd < (unsigned)D && (unsigned)shh < (unsigned)H && (unsigned)sw < (unsigned)W)
+          v = dl[((b * D + sd) * H + shh) * W + sw];
+      }
+      o[e] = v;
+    }
+    *(f32x4*)(col + pos * 32 + t0) = o;
+  }
+}
+
+// D0 + X1 (T:275-282, T:221-224): 2-channel critic input (sample | cond repeated over the 24 hours).
+// mode 0: out[0:B] = real, out[B:2B] = fake, out[2B:3B] = alpha*real + (1-alpha)*fake, alpha = uniform(key, b)
+// mode 1: out[0:B] = fake only (generator step).
+__global__ void k_build_critic_input(const float* __restrict__ real, const float* __restrict__ fake,
+                                     const float* __restrict__ cond, float* __restrict__ out, int B, int D, int HW,
+                                     int mode, uint32_t alpha_key) {
+  const long per = (long)D * HW;
+  const long total = (long)B * per;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+    long b = f / per;
+    long r = f - b * per;
+    int hw = (int)(r % HW);
+    float c = cond[b * HW + hw];
+    float fk = fake[f];
+    if (mode == 0) {
+      float rl = real[f];
+      float a = rd_uniform(alpha_key, (uint32_t)b);
+      float xh = a * rl + (1.0f - a) * fk;
+      *(float2*)(out + 2 * f) = make_float2(rl, c);
+      *(float2*)(out + 2 * (total + f)) = make_float2(fk, c);
+      *(float2*)(out + 2 * (2 * total + f)) = make_float2(xh, c);
+    } else {
+      *(float2*)(out + 2 * f) = make_float2(fk, c);
+    }
+  }
+}
+// 2-channel critic input from an arbitrary sample (critic_forward entry point)
+__global__ void k_build_critic_input1(const float* __restrict__ x, const float* __restrict__ cond,
+                                      float* __restrict__ out, int B, int D, int HW) {
+  const long per = (long)D * HW, total = (long)B * per;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+    long b = f / per;
+    int hw = (int)((f - b * per) % HW);
+    *(float2*)(out + 2 * f) = make_float2(x[f], cond[b * HW + hw]);
+  }
+}
+
+// D6 (T:303-304): v[b] = h4[b,:] . w + bias; one block per sample.
+__global__ void k_critic_dense_fwd(const float* __restrict__ h4, const float* __restrict__ w, const float* __restrict__ bias,
+                                   float* __restrict__ v, int F) {
+  __shared__ float red[4];
+  const long b = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < F; i += blockDim.x) s += h4[b * F + i] * w[i];
+  s = rd_block_sum(s, red);
+  if (threadIdx.x == 0) v[b] = s + bias[0];
+}
+
+// per-sample output gradient of the three critic passes (T:388-392, T:452-454):
+// real: d(mean(-v))/dv = -1/B ; fake: +1/B ; interpolated: 1 (dD/dx_hat for the penalty) ;
+// generator step (mode 1): d(mean(-v))/dv = -1/B.
+__device__ __forceinline__ float rd_dv(int b, int B, int mode) {
+  if (mode == 1) return -1.0f / B;
+  return b < B ? -1.0f / B : (b < 2 * B ? 1.0f / B : 1.0f);
+}
+
+// top of the critic's input-gradient chain: u4 = gate(h4) * w6 * dv(sample)
+__global__ void k_critic_top_bwd(const float* __restrict__ h4, const float* __restrict__ w, float* __restrict__ u4,
+                                 int NB, int F, int B, int mode, int use_drop, uint32_t key) {
+  const long total = (long)NB * F;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+    int b = (int)(f / F), i = (int)(f - (long)b * F);
+    float g = rd_lrelu_slope_from_out(h4[f]);
+    if (use_drop) g *= rd_drop_scale(key, (uint32_t)f);
+    u4[f] = g * w[i] * rd_dv(b, B, mode);
+  }
+}
+
+// dW6[i] = sum_b buf[b][i] * dv(b) over the 3B batch whose last third holds r4
+__global__ void k_critic_dense_wgrad(const float* __restrict__ buf, float* __restrict__ dw, int NB, int F, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F) return;
+  float s = 0.f;
+  for (int b = 0; b < NB; ++b) s += buf[(long)b * F + i] * rd_dv(b, B, 0);
+  dw[i] = s;
+}
+
+// column sums of rows [0,rows) of a [rows][C] matrix: stage 1 writes partial[blk][C]
+__global__ void k_colsum_partial(const float* __restrict__ src, long rows, int C, float* __restrict__ partial,
+                                 long rows_per_blk) {
+  const long r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += src[r * C + c];
+    partial[(long)blockIdx.x * C + c] = s;
+  }
+}
+__global__ void k_reduce_partials(const float* __restrict__ partial, int nsplit, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + i];
+  out[i] = s;
+}
+
+// col2im of the D1 input gradient restricted to the sample channel (channel 0):
+// g0[b][pos] = sum over taps t with (pos - t) even and o = (pos - t)/2 inside D1's output of
+// P[b][o][(t, ci=0)], where P[row][tap*2+ci] = u1[row][:] . W1[tap][ci][:]   (D1: stride 2, 'valid', T:286)
+__global__ void k_d1_col2im(const float* __restrict__ P, float* __restrict__ g0, int B, int D, int H, int W, int Do,
+                            int Ho, int Wo) {
+  const long total = (long)B * D * H * W;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+    long t = f;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H); t /= H;
+    int d = (int)(t % D);
+    long b = t / D;
+    float s = 0.f;
+    for (int td = (d & 1); td < 3; td += 2) {
+      int od = (d - td) >> 1;
+      if (d - td < 0 || od >= Do) continue;
+      for (int th = (h & 1); th < 3; th += 2) {
+        int oh = (h - th) >> 1;
+        if (h - th < 0 || oh >= Ho) continue;
+        for (int tw = (w & 1); tw < 3; tw += 2) {
+          int ow = (w - tw) >> 1;
+          if (w - tw < 0 || ow >= Wo) continue;
+          long row = ((b * Do + od) * Ho + oh) * Wo + ow;
+          s += P[row * 64 + ((td * 3 + th) * 3 + tw) * 2];
+        }
+      }
+    }
+    g0[f] = s;
+  }
+}
+
+// X2 (T:238-241): per-sample n = ||g0||_2 ; gp = n - 1.  Then r0 = d(10*mean(gp^2))/dg0 =
+// (10/B) * 2 (n-1)/n * g0, written as the 2-channel (r0, 0) input of the second forward sweep into the
+// interpolated third of the critic-input buffer.  One block per sample.
+__global__ void k_gp_norm_r0(const float* __restrict__ g0, float* __restrict__ cin_hat, float* __restrict__ gp_out,
+                             int per, int B, float gp_weight) {
+  __shared__ float red[4];
+  __shared__ float coef_s;
+  const long b = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < per; i += blockDim.x) { float v = g0[b * per + i]; s += v * v; }
+  s = rd_block_sum(s, red);
+  if (threadIdx.x == 0) {
+    float n = sqrtf(s);
+    gp_out[b] = n - 1.0f;
+    coef_s = (gp_weight / B) * 2.0f * (n - 1.0f) / n;
+  }
+  __syncthreads();
+  const float coef = coef_s;
+  for (int i = threadIdx.x; i < per; i += blockDim.x)
+    *(float2*)(cin_hat + 2 * (b * per + i)) = make_float2(coef * g0[b * per + i], 0.f);
+}
+
+// X3 (T:215-216, T:388-392): losses of the critic step as Keras reports them:
+// out[0] = total, out[1] = mean(-v_real), out[2] = mean(v_fake), out[3] = mean(gp^2); out[4] = non-finite flag
+__global__ void k_critic_losses(const float* __restrict__ v, const float* __restrict__ gp, float* __restrict__ out,
+                                int B, float gp_weight) {
+  __shared__ float red[4];
+  float a = 0.f, f = 0.f, g = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) { a -= v[i]; f += v[B + i]; g += gp[i] * gp[i]; }
+  a = rd_block_sum(a, red); f = rd_block_sum(f, red); g = rd_block_sum(g, red);
+  if (threadIdx.x == 0) {
+    a /= B; f /= B; g /= B;
+    float tot = a + f + gp_weight * g;
+    out[0] = tot; out[1] = a; out[2] = f; out[3] = g;
+    out[4] = (fabsf(tot) <= 3.0e38f) ? 0.f : 1.f;
+  }
+}
+// generator step loss (T:408): out[0] = mean(-v); out[4] = non-finite flag
+__global__ void k_gen_loss(const float* __restrict__ v, float* __restrict__ out, int B) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) a -= v[i];
+  a = rd_block_sum(a, red);
+  if (threadIdx.x == 0) {
+    a /= B;
+    out[0] = a; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f;
+    out[4] = (fabsf(a) <= 3.0e38f) ? 0.f : 1.f;
+  }
+}
+
+// X4 (T:385): Keras Adam with beta_1 = 0 (m = g, no m slab): v = b2 v + (1-b2) g^2 ;
+// p -= lr_t * g / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t) supplied by the host; g is first scaled by
+// grad_scale (1/world after the RCCL sum).
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v, long n, float lr_t,
+                       float beta2, float eps, float grad_scale) {
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 gv = *(const f32x4*)(g + 4 * i) * grad_scale;
+    f32x4 vv = *(const f32x4*)(v + 4 * i);
+    f32x4 pv = *(const f32x4*)(p + 4 * i);
+    vv = beta2 * vv + (1.0f - beta2) * gv * gv;
+    pv.x -= lr_t * gv.x / (sqrtf(vv.x) + eps); pv.y -= lr_t * gv.y / (sqrtf(vv.y) + eps);
+    pv.z -= lr_t * gv.z / (sqrtf(vv.z) + eps); pv.w -= lr_t * gv.w / (sqrtf(vv.w) + eps);
+    *(f32x4*)(v + 4 * i) = vv;
+    *(f32x4*)(p + 4 * i) = pv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    long i = (n4 << 2) + threadIdx.x;
+    float gv = g[i] * grad_scale;
+    float vv = beta2 * v[i] + (1.0f - beta2) * gv * gv;
+    v[i] = vv;
+    p[i] -= lr_t * gv / (sqrtf(vv) + eps);
+  }
+}
+
+// out[t][c][r] (row stride ldo, zero padded) = in[t][r][c]; 32x32 tiles through LDS
+__global__ void k_transpose(const float* __restrict__ in, float* __restrict__ out, int R, int C, int ldo) {
+  __shared__ float tile[32][33];
+  const long t = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? in[(t * R + r) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, r = r0 + tx;
+    if (c < C && r < ldo) out[(t * C + c) * ldo + r] = tile[tx][i];
+  }
+}

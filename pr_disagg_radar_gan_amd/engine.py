@@ -1,0 +1,154 @@
+"""Python object over the C ABI of include/rdgan.h: one Engine per GPU.
+
+PyTorch is plumbing only (device memory, streams, torch.distributed); every FLOP and byte
+of the step goes through librdgan_hip.so.  No CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as W
+
+LOSS_SLOTS = 8
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.RdganError("no MI355X/ROCm device visible: the cWGAN-GP hot path runs only on the HIP "
+                              "library (there is deliberately no CPU fallback)")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk_tensor(t, shape, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous float32 CUDA tensor")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+class Engine:
+    def __init__(self, ndomain=16, max_batch=256, n_cond_channels=1, device=None):
+        require_gpu()
+        self.lib = _lib.load()
+        self.ndomain = int(ndomain)
+        self.max_batch = int(max_batch)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.rdgan_create(ctypes.byref(self._h), self.ndomain, int(n_cond_channels), self.max_batch)
+        if rc != 0:
+            raise _lib.RdganError(f"rdgan_create(ndomain={ndomain}, max_batch={max_batch}) failed with code {rc}")
+        self.n_gen = int(self.lib.rdgan_gen_param_count(self._h))
+        self.n_critic = int(self.lib.rdgan_critic_param_count(self._h))
+        self.gen_shapes = W.gen_param_shapes(self.ndomain)
+        self.critic_shapes = W.critic_param_shapes(self.ndomain)
+        assert self.n_gen == W.param_count(self.gen_shapes) and self.n_critic == W.param_count(self.critic_shapes)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.rdgan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace_bytes(self):
+        return int(self.lib.rdgan_workspace_bytes(self._h))
+
+    def to_slab(self, arrays):
+        return torch.from_numpy(W.flatten(arrays)).to(self.device)
+
+    def _check_batch(self, B, cap):
+        if not (1 <= B <= cap):
+            raise ValueError(f"batch {B} outside [1, {cap}] (engine created with max_batch={self.max_batch})")
+
+    # ---- entry points
+    def gen_forward(self, gen_params, z, cond, out=None):
+        B = z.shape[0]
+        nd = self.ndomain
+        self._check_batch(B, self.max_batch)
+        _chk_tensor(gen_params, (self.n_gen,), "gen_params")
+        _chk_tensor(z, (B, W.LATENT_DIM), "z")
+        _chk_tensor(cond, (B, nd, nd, 1), "cond")
+        if out is None:
+            out = torch.empty((B, W.NHOURS, nd, nd, 1), dtype=torch.float32, device=self.device)
+        _chk_tensor(out, (B, W.NHOURS, nd, nd, 1), "out")
+        _lib.check(self.lib.rdgan_gen_forward(self._h, _ptr(gen_params), _ptr(z), _ptr(cond), _ptr(out), B, self._stream()),
+                   self._h, "rdgan_gen_forward")
+        return out
+
+    def critic_forward(self, critic_params, sample, cond, seed=0):
+        B = sample.shape[0]
+        nd = self.ndomain
+        self._check_batch(B, 3 * self.max_batch)
+        _chk_tensor(critic_params, (self.n_critic,), "critic_params")
+        _chk_tensor(sample, (B, W.NHOURS, nd, nd, 1), "sample")
+        _chk_tensor(cond, (B, nd, nd, 1), "cond")
+        out = torch.empty((B, 1), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.rdgan_critic_forward(self._h, _ptr(critic_params), _ptr(sample), _ptr(cond), _ptr(out), B,
+                                                 ctypes.c_uint64(seed), self._stream()), self._h, "rdgan_critic_forward")
+        return out
+
+    def critic_grad(self, critic_params, gen_params, x_real, cond, z, seed, grad_out=None):
+        B = x_real.shape[0]
+        nd = self.ndomain
+        self._check_batch(B, self.max_batch)
+        _chk_tensor(critic_params, (self.n_critic,), "critic_params")
+        _chk_tensor(gen_params, (self.n_gen,), "gen_params")
+        _chk_tensor(x_real, (B, W.NHOURS, nd, nd, 1), "x_real")
+        _chk_tensor(cond, (B, nd, nd, 1), "cond")
+        _chk_tensor(z, (B, W.LATENT_DIM), "z")
+        if grad_out is None:
+            grad_out = torch.empty(self.n_critic + LOSS_SLOTS, dtype=torch.float32, device=self.device)
+        _chk_tensor(grad_out, (self.n_critic + LOSS_SLOTS,), "grad_out")
+        _lib.check(self.lib.rdgan_critic_grad(self._h, _ptr(critic_params), _ptr(gen_params), _ptr(x_real), _ptr(cond),
+                                              _ptr(z), ctypes.c_uint64(seed), _ptr(grad_out), B, self._stream()),
+                   self._h, "rdgan_critic_grad")
+        return grad_out
+
+    def gen_grad(self, critic_params, gen_params, z, cond, seed, grad_out=None):
+        B = z.shape[0]
+        nd = self.ndomain
+        self._check_batch(B, self.max_batch)
+        _chk_tensor(critic_params, (self.n_critic,), "critic_params")
+        _chk_tensor(gen_params, (self.n_gen,), "gen_params")
+        _chk_tensor(z, (B, W.LATENT_DIM), "z")
+        _chk_tensor(cond, (B, nd, nd, 1), "cond")
+        if grad_out is None:
+            grad_out = torch.empty(self.n_gen + LOSS_SLOTS, dtype=torch.float32, device=self.device)
+        _chk_tensor(grad_out, (self.n_gen + LOSS_SLOTS,), "grad_out")
+        _lib.check(self.lib.rdgan_gen_grad(self._h, _ptr(critic_params), _ptr(gen_params), _ptr(z), _ptr(cond),
+                                           ctypes.c_uint64(seed), _ptr(grad_out), B, self._stream()),
+                   self._h, "rdgan_gen_grad")
+        return grad_out
+
+    def adam(self, params, grad, v, t, lr=1e-4, beta2=0.9, eps=1e-7, grad_scale=1.0):
+        n = params.numel()
+        _chk_tensor(params, (n,), "params")
+        _chk_tensor(v, (n,), "v")
+        if grad.numel() < n:
+            raise ValueError("grad slab shorter than params")
+        _chk_tensor(grad, None, "grad")
+        _lib.check(self.lib.rdgan_adam(_ptr(params), _ptr(grad), _ptr(v), n, int(t), float(lr), float(beta2), float(eps),
+                                       float(grad_scale), self._stream()), self._h, "rdgan_adam")
+
+    def profile(self, tag_mask):
+        _lib.check(self.lib.rdgan_profile(self._h, int(tag_mask)), self._h, "rdgan_profile")
+
+    def profile_read(self, tag):
+        ms, n = ctypes.c_double(), ctypes.c_long()
+        _lib.check(self.lib.rdgan_profile_read(self._h, int(tag), ctypes.byref(ms), ctypes.byref(n)), self._h,
+                   "rdgan_profile_read")
+        return ms.value, n.value

@@ -1,0 +1,113 @@
+"""-m gpu: op-level parity of the HIP kernels (through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rdgan_torch as ot
+from oracle import rng as orng
+from tests.hip_util import dev, lib, ptr, rel_err, stream
+
+pytestmark = pytest.mark.gpu
+
+# (name, B, D,H,W (conv input before upsample), Cin, Cout, out dims, stride, pad, upsample)
+GEOMS = [
+    ("G1", 2, (3, 2, 2), 256, 256, (6, 4, 4), 1, (1, 1, 1), 1),
+    ("G2", 2, (6, 4, 4), 256, 128, (12, 8, 8), 1, (1, 1, 1), 1),
+    ("G3", 3, (12, 8, 8), 128, 64, (24, 16, 16), 1, (1, 1, 1), 1),
+    ("D2", 5, (11, 7, 7), 64, 128, (6, 4, 4), 2, (1, 1, 1), 0),
+    ("D3", 5, (6, 4, 4), 128, 256, (3, 2, 2), 2, (0, 0, 0), 0),
+    ("D4", 7, (3, 2, 2), 256, 256, (2, 1, 1), 2, (1, 0, 0), 0),
+    ("D2_nd64", 1, (11, 31, 31), 64, 128, (6, 16, 16), 2, (1, 1, 1), 0),
+    ("plain_s1", 2, (5, 6, 7), 64, 64, (5, 6, 7), 1, (1, 1, 1), 0),
+]
+
+
+def _oracle_conv(x, w, b, g):
+    _, B, dims, cin, cout, od, stride, pad, up = g
+    xt = torch.from_numpy(x).double()
+    if up:
+        xt = ot.upsample3d(xt)
+    return ot._conv3d_tf(xt, torch.from_numpy(w).double(), None if b is None else torch.from_numpy(b).double(),
+                         stride, pad, od)
+
+
+@pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
+def test_conv3d_forward(g):
+    name, B, dims, cin, cout, od, stride, pad, up = g
+    rng = np.random.default_rng(hash(name) % 1000)
+    x = rng.standard_normal((B,) + dims + (cin,)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = _oracle_conv(x, w, b, g).numpy()
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.full((B,) + od + (cout,), float("nan"), device="cuda")
+    rc = lib().rdgan_op_conv3d(ptr(xd), ptr(wd), ptr(bd), ptr(y), B, *dims, cin, cout, *od, stride, *pad, up, stream())
+    assert rc == 0
+    assert rel_err(y.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
+def test_conv3d_dgrad(g):
+    name, B, dims, cin, cout, od, stride, pad, up = g
+    rng = np.random.default_rng(hash(name) % 1000 + 1)
+    in_dims = tuple(2 * d for d in dims) if up else dims       # the conv's own input grid
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cout)).astype(np.float32)
+    gy = rng.standard_normal((B,) + od + (cout,)).astype(np.float32)
+    xt = torch.zeros((B,) + in_dims + (cin,), dtype=torch.float64, requires_grad=True)
+    yt = ot._conv3d_tf(xt, torch.from_numpy(w).double(), None, stride, pad, od)
+    ref, = torch.autograd.grad(yt, xt, torch.from_numpy(gy).double())
+    gx = torch.full((B,) + in_dims + (cin,), float("nan"), device="cuda")
+    gyd, wd = dev(gy), dev(w)            # keep the device tensors alive across the call
+    rc = lib().rdgan_op_conv3d_dgrad(ptr(gyd), ptr(wd), ptr(gx), B, *in_dims, cin, cout, *od, stride, *pad, stream())
+    assert rc == 0
+    assert rel_err(gx.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
+def test_conv3d_wgrad(g):
+    name, B, dims, cin, cout, od, stride, pad, up = g
+    rng = np.random.default_rng(hash(name) % 1000 + 2)
+    x = rng.standard_normal((B,) + dims + (cin,)).astype(np.float32)
+    gy = rng.standard_normal((B,) + od + (cout,)).astype(np.float32)
+    wt = torch.zeros((3, 3, 3, cin, cout), dtype=torch.float64, requires_grad=True)
+    xt = torch.from_numpy(x).double()
+    if up:
+        xt = ot.upsample3d(xt)
+    yt = ot._conv3d_tf(xt, wt, None, stride, pad, od)
+    ref, = torch.autograd.grad(yt, wt, torch.from_numpy(gy).double())
+    dw = torch.full((3, 3, 3, cin, cout), float("nan"), device="cuda")
+    xd, gyd = dev(x), dev(gy)
+    rc = lib().rdgan_op_conv3d_wgrad(ptr(xd), ptr(gyd), ptr(dw), B, *dims, cin, cout, *od, stride, *pad, up, stream())
+    assert rc == 0
+    assert rel_err(dw.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_pixelnorm_lrelu_fwd_bwd(C):
+    rng = np.random.default_rng(C)
+    npix = 1001
+    y = rng.standard_normal((npix, C)).astype(np.float32)
+    y[7] = 0.0                                           # KAT: zero vector -> 0, no NaN
+    gh = rng.standard_normal((npix, C)).astype(np.float32)
+    yt = torch.from_numpy(y).double().requires_grad_(True)
+    ht = torch.nn.functional.leaky_relu(ot.pixel_norm(yt), 0.2)
+    ref_dy, = torch.autograd.grad(ht, yt, torch.from_numpy(gh).double())
+    yd = dev(y); h = torch.empty_like(yd); rinv = torch.empty(npix, device="cuda")
+    assert lib().rdgan_op_pixelnorm_lrelu(ptr(yd), ptr(h), ptr(rinv), npix, C, stream()) == 0
+    hn = h.cpu().numpy()
+    assert np.all(np.isfinite(hn)) and np.all(hn[7] == 0)
+    assert rel_err(hn, ht.detach().numpy()) < 1e-6
+    dy = torch.empty_like(yd)
+    ghd = dev(gh)
+    assert lib().rdgan_op_pixelnorm_lrelu_bwd(ptr(ghd), ptr(h), ptr(rinv), ptr(dy), npix, C, stream()) == 0
+    mask = np.ones(npix, bool); mask[7] = False          # the zero row has an eps-dominated (1e4) slope
+    assert rel_err(dy.cpu().numpy()[mask], ref_dy.numpy()[mask]) < 2e-5
+
+
+def test_rng_bit_exact():
+    n = 100003
+    for seed, sid in ((1, 1), (0x1234567890ABCDEF, 3), (2 ** 63 + 5, 5)):
+        m = torch.empty(n, device="cuda"); u = torch.empty(n, device="cuda")
+        assert lib().rdgan_op_rng(seed, sid, ptr(m), ptr(u), n, stream()) == 0
+        assert np.array_equal(m.cpu().numpy(), orng.dropout_scale_mask(seed, sid, (n,)))
+        assert np.array_equal(u.cpu().numpy(), orng.uniform(seed, sid, n))

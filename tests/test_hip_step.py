@@ -1,0 +1,200 @@
+"""-m gpu: parity of the generator forward, critic forward and both training-step gradients
+(HIP, through the C ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rdgan_np as onp
+from oracle import rdgan_torch as ot
+from pr_disagg_radar_gan_amd import Engine
+from pr_disagg_radar_gan_amd import weights as W
+from tests.hip_util import dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(nd, seed, bias_scale=0.05):
+    rng = np.random.default_rng(seed)
+    g = W.init_generator(rng, nd)
+    d = W.init_critic(rng, nd)
+    g = [p if p.ndim > 1 else (bias_scale * rng.standard_normal(p.shape)).astype(np.float32) for p in g]
+    d = [p if p.ndim > 1 else (bias_scale * rng.standard_normal(p.shape)).astype(np.float32) for p in d]
+    return g, d
+
+
+def _t64(arrs):
+    return [torch.from_numpy(a).double() for a in arrs]
+
+
+@pytest.fixture(scope="module")
+def eng16():
+    e = Engine(ndomain=16, max_batch=8)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("B", [1, 2, 5])
+def test_generator_forward_parity(eng16, B):
+    g, _ = _params(16, 11)
+    x, cond, z = ot.synthetic_batch(B, 16, 3)
+    ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
+    out = eng16.gen_forward(eng16.to_slab(g), dev(z), dev(cond)).cpu().numpy()
+    assert out.shape == (B, 24, 16, 16, 1)
+    # north_star tolerance: 1e-4 relative in fp32
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-7)
+    assert rel_err(out, ref) < 2e-5
+    np.testing.assert_allclose(out.sum(axis=1), 1.0, rtol=0, atol=2e-6)     # softmax over hours (T:347)
+
+
+def test_generator_kat_zero_weights(eng16):
+    g = [np.zeros(s, np.float32) for _, s in W.gen_param_shapes(16)]
+    x, cond, z = ot.synthetic_batch(3, 16, 4)
+    out = eng16.gen_forward(eng16.to_slab(g), dev(z), dev(cond)).cpu().numpy()
+    np.testing.assert_allclose(out, 1.0 / 24.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("seed", [0, 77])
+def test_critic_forward_parity(eng16, seed):
+    _, d = _params(16, 12)
+    B = 4
+    x, cond, z = ot.synthetic_batch(B, 16, 5)
+    masks = ot.critic_masks(seed, B, 16, torch.float64)
+    ref = ot.critic_forward(_t64(d), torch.from_numpy(x).double(), torch.from_numpy(cond).double(), masks).numpy()
+    out = eng16.critic_forward(eng16.to_slab(d), dev(x), dev(cond), seed=seed).cpu().numpy()
+    assert rel_err(out, ref) < 2e-5
+
+
+def _grad_errors(got, ref_list, shapes):
+    """per-tensor max-abs error relative to the tensor's max-abs gradient"""
+    off = 0
+    errs = {}
+    for (name, s), r in zip(shapes, ref_list):
+        n = int(np.prod(s))
+        if name == "conv3d_3/bias:0":
+            # d/d(bias in front of a softmax over hours) is analytically zero (shift invariance): the
+            # oracle value is fp64 noise, so this one is checked absolutely
+            assert abs(float(got[off])) < 1e-6, got[off]
+            off += n
+            continue
+        errs[name] = rel_err(got[off:off + n].reshape(s), r.numpy())
+        off += n
+    return errs
+
+
+TIGHT, LOOSE = 5e-5, 1e-2
+
+
+def _parity_over_batches(run_case):
+    """The loss is only piecewise smooth: a LeakyReLU input within fp32 rounding of zero takes
+    slope 1 in one precision and 0.2 in the other (the fp32 torch oracle shows the same ~1e-3
+    jumps against the fp64 one; see oracle.rdgan_torch.kink_margin).  With ~2e6 activations per
+    step that happens for a fraction of random batches.  So: every batch must agree loosely
+    (a real indexing/algebra bug gives O(1) errors), and the first batch without such a flip must
+    agree to TIGHT.  HIP results are run-to-run deterministic (no atomics), so this is not flaky."""
+    history = []
+    for data_seed in range(100, 106):
+        errs = run_case(data_seed)
+        worst = max(errs.values())
+        history.append((data_seed, float(f"{worst:.2e}")))
+        assert worst < LOOSE, (data_seed, errs)
+        if worst < TIGHT:
+            print("grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()}, "history", history)
+            return
+    raise AssertionError(f"no batch reached the tight tolerance: {history}")
+
+
+@pytest.mark.parametrize("B,seed", [(2, 1234), (3, 0), (4, 99)])
+def test_critic_step_grads_parity(eng16, B, seed):
+    g, d = _params(16, 13)
+
+    def run_case(data_seed):
+        x, cond, z = ot.synthetic_batch(B, 16, data_seed)
+        losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
+                                             torch.from_numpy(cond).double(), torch.from_numpy(z).double(), seed)
+        slab = eng16.critic_grad(eng16.to_slab(d), eng16.to_slab(g), dev(x), dev(cond), dev(z), seed).cpu().numpy()
+        n = eng16.n_critic
+        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+        assert slab[n + 4] == 0.0
+        return _grad_errors(slab[:n], grads, eng16.critic_shapes)
+
+    _parity_over_batches(run_case)
+
+
+@pytest.mark.parametrize("B,seed", [(2, 4321), (3, 0)])
+def test_gen_step_grads_parity(eng16, B, seed):
+    g, d = _params(16, 14)
+
+    def run_case(data_seed):
+        x, cond, z = ot.synthetic_batch(B, 16, data_seed)
+        loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), seed)
+        slab = eng16.gen_grad(eng16.to_slab(d), eng16.to_slab(g), dev(z), dev(cond), seed).cpu().numpy()
+        n = eng16.n_gen
+        np.testing.assert_allclose(slab[n], loss.item(), rtol=2e-4, atol=1e-6)
+        return _grad_errors(slab[:n], grads, eng16.gen_shapes)
+
+    _parity_over_batches(run_case)
+
+
+def test_adam_parity(eng16):
+    rng = np.random.default_rng(3)
+    n = 100003
+    p = rng.standard_normal(n).astype(np.float32); v = np.abs(rng.standard_normal(n)).astype(np.float32) * 1e-3
+    gr = rng.standard_normal(n + 8).astype(np.float32)
+    pt = [torch.from_numpy(p.copy()).double()]; vt = [torch.from_numpy(v.copy()).double()]
+    ot.adam_update(pt, [torch.from_numpy(gr[:n]).double() * 0.5], vt, 7)
+    pd, vd = dev(p), dev(v)
+    eng16.adam(pd, dev(gr), vd, 7, grad_scale=0.5)
+    np.testing.assert_allclose(pd.cpu().numpy(), pt[0].numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(vd.cpu().numpy(), vt[0].numpy(), rtol=1e-6, atol=1e-12)
+
+
+def test_nd64_forward_and_grads():
+    """largedomain variant (L:59,325,335): ndomain=64, single sample."""
+    eng = Engine(ndomain=64, max_batch=1)
+    try:
+        g, d = _params(64, 15)
+        x, cond, z = ot.synthetic_batch(1, 64, 8)
+        ref = ot.generator_forward([torch.from_numpy(a) for a in g], torch.from_numpy(z), torch.from_numpy(cond)).numpy()
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        out = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+        assert rel_err(out, ref) < 5e-5
+        losses, grads = ot.critic_step_grads([torch.from_numpy(a) for a in d], [torch.from_numpy(a) for a in g],
+                                             torch.from_numpy(x), torch.from_numpy(cond), torch.from_numpy(z), 5)
+        slab = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 5).cpu().numpy()
+        n = eng.n_critic
+        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=1e-3, atol=1e-5)
+        off = 0
+        for (name, s), r in zip(eng.critic_shapes, grads):
+            k = int(np.prod(s))
+            assert rel_err(slab[off:off + k].reshape(s), r.numpy()) < 1e-3, name
+            off += k
+    finally:
+        eng.close()
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (bs=256): size-independent properties instead of an oracle run."""
+    eng = Engine(ndomain=16, max_batch=256)
+    try:
+        g, d = _params(16, 16)
+        x, cond, z = ot.synthetic_batch(256, 16, 9)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        out = eng.gen_forward(gs, dev(z), dev(cond))
+        o = out.cpu().numpy()
+        assert np.all(np.isfinite(o)) and o.min() >= 0
+        np.testing.assert_allclose(o.sum(axis=1), 1.0, atol=3e-6)
+        # batch independence: sample 17 alone equals sample 17 in the batch
+        one = eng.gen_forward(gs, dev(z[17:18]), dev(cond[17:18])).cpu().numpy()
+        np.testing.assert_allclose(one[0], o[17], rtol=1e-5, atol=1e-8)
+        # linearity of the gradient slab in the per-sample mean: grads of a batch made of two equal halves
+        # equal the grads of one half (critic: seed 0 = no dropout, alpha differs per sample -> use gen step)
+        zz = np.concatenate([z[:128], z[:128]]); cc = np.concatenate([cond[:128], cond[:128]])
+        ga = eng.gen_grad(ds, gs, dev(zz), dev(cc), 0).cpu().numpy()
+        gb = eng.gen_grad(ds, gs, dev(z[:128]), dev(cond[:128]), 0).cpu().numpy()
+        n = eng.n_gen
+        assert rel_err(ga[:n], gb[:n]) < 1e-4
+        np.testing.assert_allclose(ga[n], gb[n], rtol=1e-5)
+        sl = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 31337).cpu().numpy()
+        assert np.all(np.isfinite(sl)) and sl[eng.n_critic + 4] == 0
+    finally:
+        eng.close()
