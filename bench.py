@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the cWGAN-GP training iteration on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one training iteration of the reference's loop body
+(gan_train_cwgangp_pixelnorm.py:468-482) on synthetic 24x16x16 tiles: n_critic critic
+updates + 1 generator update, fp32, batch 256 per GPU (BASELINE.json configs[1]: "ndomain=16,
+24h, bs=256 fp32, 1 critic step + 1 gen step, single MI355X").  For N > 1 (one process per GPU,
+launched by torch.distributed.run) the minibatch dimension is sharded: every rank processes its
+own 256 samples and the gradient slabs are summed by RCCL (weak scaling).  Inputs are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NDOMAIN = 16
+BATCH_PER_GPU = 256
+N_CRITIC = 1
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def gconv3_flops(batch, nd=NDOMAIN):
+    """Algorithmic FLOPs of ONE launch of the dominant kernel: the generator's third
+    UpSampling3D+Conv3D block (128 -> 64 channels on the 24 x nd x nd grid, 27 taps), direct
+    form: 2 * B * (24*nd*nd) * 27*128 * 64  (2 717.9 MFLOP per sample at nd=16)."""
+    return 2.0 * batch * 24 * nd * nd * 27 * 128 * 64
+
+
+def cpu_baseline(iters=3, batch=32):
+    """The oracle's torch-CPU restatement of the same iteration (kind "port": the reference's own
+    runtime, TensorFlow 2.1, is not installed and no reference code travels to the GPU box),
+    timed on the host cores on a bounded sample."""
+    import torch
+    from oracle import rdgan_torch as ot
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    tr = ot.Trainer(ndomain=NDOMAIN, seed=0)
+    batches = []
+    for i in range(N_CRITIC + 1):
+        x, c, z = ot.synthetic_batch(batch, NDOMAIN, 50 + i)
+        batches.append((torch.from_numpy(x), torch.from_numpy(c), torch.from_numpy(z)))
+
+    def iteration(k):
+        for j in range(N_CRITIC):
+            x, c, z = batches[j]
+            tr.critic_step(x, c, z, seed=1000 + k * 7 + j)
+        x, c, z = batches[N_CRITIC]
+        tr.gen_step(z, c, seed=2000 + k)
+
+    iteration(0)                                   # warm-up
+    t0 = time.perf_counter()
+    for k in range(iters):
+        iteration(k + 1)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 3), "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"{iters} iterations (n_critic={N_CRITIC} critic + 1 generator update) at bs={batch}, "
+                      f"torch-CPU fp32 restatement of the reference arithmetic, after 1 warm-up iteration"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="samples per GPU per iteration")
+    ap.add_argument("--n-critic", type=int, default=N_CRITIC)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pr_disagg_radar_gan_amd import Engine, weights as W, _lib
+    from pr_disagg_radar_gan_amd.trainer import WGANGPTrainer, synthetic_batch_device
+    import numpy as np
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        pg = dist.group.WORLD
+
+    B = args.batch
+    eng = Engine(ndomain=NDOMAIN, max_batch=B, device=dev)
+    rng = np.random.default_rng(0)                  # identical initial weights on every rank
+    trainer = WGANGPTrainer(eng, W.init_generator(rng, NDOMAIN), W.init_critic(rng, NDOMAIN), n_disc=args.n_critic,
+                            process_group=pg, world_size=world, rank=rank, base_seed=1234 + 1000 * 2)
+    # synthetic inputs resident in HBM; per-rank seeds 1234 + 1000*config + rank
+    nbuf = 4
+    data = []
+    for i in range(nbuf):
+        crit = [synthetic_batch_device(B, NDOMAIN, 1234 + 2000 + rank + 97 * (i * (args.n_critic + 1) + j), dev)
+                for j in range(args.n_critic)]
+        _, c, z = synthetic_batch_device(B, NDOMAIN, 1234 + 2000 + rank + 97 * (i * (args.n_critic + 1) + args.n_critic) + 13, dev)
+        data.append((crit, (z, c)))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    flags = []
+    for k in range(args.warmup):
+        crit, gen = data[k % nbuf]
+        trainer.iteration(crit, gen)
+    sync()
+    eng.profile(1 << _lib.TAG_GCONV3_FWD)            # HIP events around the dominant kernel, on the launch stream
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        crit, gen = data[k % nbuf]
+        d_loss, g_loss, bad = trainer.iteration(crit, gen)
+        flags.append(bad)
+    sync()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_n = eng.profile_read(_lib.TAG_GCONV3_FWD)
+    eng.profile(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    nonfinite = float(torch.stack(flags).max().item()) if flags else 0.0
+    d_loss, g_loss = float(d_loss.item()), float(g_loss.item())
+    if nonfinite != 0 or not (np.isfinite(d_loss) and np.isfinite(g_loss)):
+        raise SystemExit(f"non-finite loss encountered (d_loss={d_loss}, g_loss={g_loss})")   # reference :487-488
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        avg_ms = kern_ms / max(kern_n, 1)
+        achieved = gconv3_flops(B) / (avg_ms * 1e-3) / 1e12 if kern_n else None
+        out = {
+            "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ndomain=16, 24h, bs={B} fp32 per GPU, {args.n_critic} critic step + 1 gen step "
+                                   "(BASELINE configs[1])",
+                       "global_batch": world * B, "n_critic": args.n_critic, "parallelism": f"dp{world}",
+                       "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
+            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm<128,64> generator block 3 forward (upsample+Conv3D 128->64)",
+                         "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
+                         "flops_per_launch": gconv3_flops(B)},
+            "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""The training iteration of the reference's ``train()`` (gan_train_cwgangp_pixelnorm.py:466-482)
+on the HIP engine, data-parallel over ranks.
+
+One iteration = ``n_disc`` critic ``train_on_batch`` calls then one generator
+``train_on_batch`` (reference :468-482).  Each rank computes the gradient slab of its
+minibatch shard with librdgan_hip.so, the slabs are summed with ONE RCCL all-reduce per
+optimizer update (torch.distributed backend "nccl" is RCCL on ROCm; the four loss scalars
+ride in the slab's tail), and the fused Adam kernel applies 1/world.  Weights and Adam state
+are replicated and stay bit-identical across ranks.  Both models share one Adam iteration
+counter, as the single ``tf.optimizers.Adam`` object of the reference does (:385,:391,:408).
+"""
+import numpy as np
+import torch
+
+LOSS_SLOTS = 8
+
+
+class WGANGPTrainer:
+    def __init__(self, engine, gen_arrays, critic_arrays, n_disc=5, lr=1e-4, beta2=0.9, eps=1e-7,
+                 process_group=None, world_size=1, rank=0, base_seed=1234):
+        self.eng = engine
+        self.n_disc = int(n_disc)
+        self.lr, self.beta2, self.eps = lr, beta2, eps
+        self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
+        self.gparams = engine.to_slab(gen_arrays)
+        self.dparams = engine.to_slab(critic_arrays)
+        self.gv = torch.zeros_like(self.gparams)
+        self.dv = torch.zeros_like(self.dparams)
+        self.ggrad = torch.zeros(self.gparams.numel() + LOSS_SLOTS, dtype=torch.float32, device=self.gparams.device)
+        self.dgrad = torch.zeros(self.dparams.numel() + LOSS_SLOTS, dtype=torch.float32, device=self.dparams.device)
+        self.t = 0                      # shared optimizer.iterations
+        self.base_seed = int(base_seed)
+        self.calls = 0
+
+    # every stochastic draw inside a step (dropout masks, alpha) is keyed by (base_seed, call index, rank)
+    def _next_seed(self):
+        self.calls += 1
+        s = (self.base_seed * 0x9E3779B97F4A7C15 + self.calls * 0xD1B54A32D192ED03 + self.rank * 0x94D049BB133111EB)
+        s &= 0xFFFFFFFFFFFFFFFF
+        return s or 1
+
+    def _allreduce(self, slab):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def critic_step(self, x_real, cond, z, seed=None):
+        """critic_model.train_on_batch([X_real, cond_real, latent], [valid, fake, dummy]) (reference :472).
+        Returns the device tensor [total, valid, fake, gp, nonfinite] averaged over ranks."""
+        seed = self._next_seed() if seed is None else seed
+        self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self.dgrad)
+        self._allreduce(self.dgrad)
+        self.t += 1
+        self.eng.adam(self.dparams, self.dgrad, self.dv, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
+        return self.dgrad[-LOSS_SLOTS:-LOSS_SLOTS + 5] / self.world
+
+    def gen_step(self, z, cond, seed=None):
+        """generator_model.train_on_batch([latent, cond], valid) (reference :482)."""
+        seed = self._next_seed() if seed is None else seed
+        self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self.ggrad)
+        self._allreduce(self.ggrad)
+        self.t += 1
+        self.eng.adam(self.gparams, self.ggrad, self.gv, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
+        return self.ggrad[-LOSS_SLOTS:-LOSS_SLOTS + 5] / self.world
+
+    def iteration(self, critic_batches, gen_batch):
+        """critic_batches: n_disc tuples (x_real, cond, z); gen_batch: (z, cond).  Returns (d_loss, g_loss)
+        device scalars with the reference's reporting: d_loss = mean(valid_loss, fake_loss) of the LAST
+        critic step (reference :475), g_loss = generator loss."""
+        assert len(critic_batches) == self.n_disc
+        for (x, c, z) in critic_batches:
+            dl = self.critic_step(x, c, z)
+        gl = self.gen_step(*gen_batch)
+        return 0.5 * (dl[1] + dl[2]), gl[0], torch.maximum(dl[4], gl[4])
+
+    def state_arrays(self):
+        """(generator arrays, critic arrays) in Keras weight order, as numpy."""
+        from . import weights as W
+        return (W.unflatten(self.gparams.cpu().numpy(), self.eng.gen_shapes),
+                W.unflatten(self.dparams.cpu().numpy(), self.eng.critic_shapes))
+
+
+def shard_slice(global_batch, world, rank):
+    """rank r takes samples [r*B/W, (r+1)*B/W) -- equal shards so the global mean is the mean of local means"""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} not divisible by world size {world}")
+    per = global_batch // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def synthetic_batch_device(batch, ndomain, seed, device):
+    """Synthetic inputs of SURVEY 8(d), generated on the device by torch (plumbing): real tiles =
+    softmax over hours of 2*N(0,1) (values in [0,1], sum over hours 1, as the reference asserts at
+    :167-172), cond = Gamma(2, 5 mm)/127.4, z ~ N(0,1)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    x = torch.softmax(2.0 * torch.randn((batch, 24, ndomain, ndomain, 1), generator=g, device=device), dim=1).contiguous()
+    shape = (batch, ndomain, ndomain, 1)
+    # Gamma(k=2, theta=5) = -5*(log u1 + log u2)
+    u = torch.rand((2,) + shape, generator=g, device=device).clamp_min(1e-12)
+    cond = (-5.0 * (u[0].log() + u[1].log()) / 127.4).contiguous()
+    z = torch.randn((batch, 100), generator=g, device=device)
+    return x, cond, z
