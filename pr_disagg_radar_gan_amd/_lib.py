@@ -31,6 +31,7 @@ SIGNATURES = {
                                   ctypes.c_float, ctypes.c_float, c_stream]),
     "rdgan_gen_param_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "rdgan_critic_param_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
+    "rdgan_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),
     "rdgan_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
     "rdgan_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_long)]),

@@ -112,6 +112,52 @@ static RdPlan plan_conv_dgrad_s2(int D, int H, int W, int Cin, int Do, int Ho, i
   return p;
 }
 
+// UpSampling3D(2)+Conv3D 3^3 'same' collapsed onto the un-upsampled grid:
+// 8 output-parity phases x 8 taps; weights Wc[phase*8 + tap][Cin][Cout] from k_collapse_weights.
+static RdPlan plan_upconv_fwd_collapsed(int D, int H, int W, int Cin, int Cout) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 8; p.SD = D; p.SH = H; p.SW = W; p.s_shift = 0; p.s_cstride = Cin; p.SC = Cin;
+  p.w_rows_per_tap = Cin; p.DD = 2 * D; p.DH = 2 * H; p.DW = 2 * W; p.d_cstride = Cout; p.N = Cout;
+  for (int ph = 0; ph < 8; ++ph) {
+    RdPhase& q = p.ph[ph];
+    phase_defaults(q, D, H, W);
+    const int par[3] = {ph >> 2, (ph >> 1) & 1, ph & 1};
+    for (int a = 0; a < 3; ++a) { q.o_mul[a] = 2; q.o_off[a] = par[a]; }
+    q.ntaps = 8;
+    for (int t = 0; t < 8; ++t) {
+      q.tap_off[t][0] = (int8_t)(par[0] - 1 + (t >> 2)); q.tap_off[t][1] = (int8_t)(par[1] - 1 + ((t >> 1) & 1));
+      q.tap_off[t][2] = (int8_t)(par[2] - 1 + (t & 1));
+      q.tap_w[t] = (int16_t)(ph * 8 + t);
+    }
+  }
+  return p;
+}
+// its input gradient straight onto the un-upsampled grid (upsample adjoint included): per axis the four
+// upsampled-grid positions o = 2j + q - 1, q = 0..3, i.e. (phase,tap) = (1,1),(0,1),(1,0),(0,0);
+// weights Wd[q3][Cout][Cin] from k_transpose_map.  D,H,W = un-upsampled extents.
+static void collapsed_dgrad_slice_map(int16_t map[64]) {
+  const int qp[4] = {1, 0, 1, 0}, qa[4] = {1, 1, 0, 0};
+  for (int q = 0; q < 64; ++q) {
+    int qd = q >> 4, qh = (q >> 2) & 3, qw = q & 3;
+    int ph = qp[qd] * 4 + qp[qh] * 2 + qp[qw], tp = qa[qd] * 4 + qa[qh] * 2 + qa[qw];
+    map[q] = (int16_t)(ph * 8 + tp);
+  }
+}
+static RdPlan plan_upconv_dgrad_collapsed(int D, int H, int W, int Cin, int Cout) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 1; p.SD = 2 * D; p.SH = 2 * H; p.SW = 2 * W; p.s_shift = 0; p.s_cstride = Cout; p.SC = Cout;
+  p.w_rows_per_tap = Cout; p.DD = D; p.DH = H; p.DW = W; p.d_cstride = Cin; p.N = Cin;
+  RdPhase& q = p.ph[0];
+  phase_defaults(q, D, H, W);
+  for (int a = 0; a < 3; ++a) q.s_mul[a] = 2;
+  q.ntaps = 64;
+  for (int t = 0; t < 64; ++t) {
+    q.tap_off[t][0] = (int8_t)((t >> 4) - 1); q.tap_off[t][1] = (int8_t)(((t >> 2) & 3) - 1);
+    q.tap_off[t][2] = (int8_t)((t & 3) - 1); q.tap_w[t] = (int16_t)t;
+  }
+  return p;
+}
+
 // plain row GEMM: rows (D,H,W) of `cstride` floats, first SC used -> [rows][dcs], N columns
 static RdPlan plan_rows(int D, int H, int W, int SC, int cstride, int N, int dcs) {
   RdPlan p; memset(&p, 0, sizeof(p));
@@ -128,7 +174,8 @@ static RdPlan plan_rows(int D, int H, int W, int SC, int cstride, int N, int dcs
 // ------------------------------------------------------------------------------------
 enum {
   PL_GDENSE = 0, PL_G1F, PL_G2F, PL_G3F, PL_G9F, PL_G1B, PL_G2B, PL_G3B, PL_G9B,
-  PL_D1F, PL_D2F, PL_D3F, PL_D4F, PL_D2B, PL_D3B, PL_D4B, PL_D1B, PL_COUNT
+  PL_D1F, PL_D2F, PL_D3F, PL_D4F, PL_D2B, PL_D3B, PL_D4B, PL_D1B,
+  PL_G1FC, PL_G2FC, PL_G3FC, PL_G1BC, PL_G2BC, PL_G3BC, PL_COUNT
 };
 
 struct rdgan_handle {
@@ -156,6 +203,8 @@ struct rdgan_handle {
   float *wpartial, *cpartial;
   size_t wpartial_cap = 0, cpartial_cap = 0;
   float *DWT[5], *W1T, *GWT[4], *W9T;
+  float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
+  int collapse = 1;               // 1: 8-tap collapsed generator blocks (default); 0: direct 27-tap form
   int* d_flag;
   // profiling
   unsigned prof_mask = 0;
@@ -258,7 +307,7 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   }
   T.NT = p.N / BN;
   long rows = (long)B * q.L;
-  long tiles = (long)T.RT * T.NT;
+  long tiles = (long)T.RT * T.NT * p.nphases;
   long want = std::max(1L, (1024 + tiles - 1) / tiles);
   long maxs = std::max(1L, (rows + 127) / 128);
   long s = std::min(want, maxs);
@@ -270,7 +319,7 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
 }
 
 template <int BR, int BN>
-static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int B, const float* src, const float* dy,
+static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int B, const float* src, const float* dy,
                             float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(32 * (BR + 4) + 32 * (BN + 4)) * sizeof(float);
   static bool attr_done = false;
@@ -279,7 +328,7 @@ static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int B, const floa
     RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  dim3 grid((unsigned)(T.RT * T.NT), (unsigned)nsplit);
+  dim3 grid((unsigned)(T.RT * T.NT), (unsigned)nsplit, (unsigned)nphases);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, dy, partial, T);
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -289,18 +338,21 @@ static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int B, const floa
 static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* dy,
                         float* dW, float* partial, size_t partial_cap, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
-  if (hp.nphases != 1 || hp.N % 64) return bad_arg(h, "wgrad: needs a single-phase plan and N % 64 == 0");
+  if (hp.N % 64) return bad_arg(h, "wgrad: N % 64 != 0");
+  for (int i = 1; i < hp.nphases; ++i)
+    if (hp.ph[i].ntaps != hp.ph[0].ntaps || hp.ph[i].L != hp.ph[0].L) return bad_arg(h, "wgrad: phases must be congruent");
   int BR, BN, nsplit;
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
-  size_t need = (size_t)nsplit * T.RT * BR * hp.N;
+  size_t need = (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
   if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
-  if (BR == 128 && BN == 128) RD_TRY((launch_wgrad_cfg<128, 128>(h, dp, B, src, dy, partial, T, nsplit, st)));
-  else if (BR == 128) RD_TRY((launch_wgrad_cfg<128, 64>(h, dp, B, src, dy, partial, T, nsplit, st)));
-  else if (BN == 128) RD_TRY((launch_wgrad_cfg<64, 128>(h, dp, B, src, dy, partial, T, nsplit, st)));
-  else RD_TRY((launch_wgrad_cfg<64, 64>(h, dp, B, src, dy, partial, T, nsplit, st)));
+  const int np = hp.nphases;
+  if (BR == 128 && BN == 128) RD_TRY((launch_wgrad_cfg<128, 128>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
+  else if (BR == 128) RD_TRY((launch_wgrad_cfg<128, 64>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
+  else if (BN == 128) RD_TRY((launch_wgrad_cfg<64, 128>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
+  else RD_TRY((launch_wgrad_cfg<64, 64>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
   long total = (long)T.RT * BR * (hp.N / 4);
   int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, st, dp, partial, nsplit, T, BR, dW, hp.N);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks, np), dim3(256), 0, st, dp, partial, nsplit, T, BR, dW, hp.N);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -308,7 +360,7 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
 static size_t wgrad_partial_need(const RdPlan& hp, int B) {
   int BR, BN, nsplit;
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
-  return (size_t)nsplit * T.RT * BR * hp.N;
+  return (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
 }
 
 static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>((n + per - 1) / per, 8192); }
@@ -411,6 +463,8 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     const int* sd = h->gdim[l - 1]; const int* od = h->gdim[l];
     h->plans[PL_G1F + l - 1] = plan_conv_fwd(sd[0], sd[1], sd[2], gch[l - 1], gch[l], od[0], od[1], od[2], 1, 1, 1, 1, 1);
     h->plans[PL_G1B + l - 1] = plan_conv_dgrad_s1(od[0], od[1], od[2], gch[l - 1], gch[l]);
+    h->plans[PL_G1FC + l - 1] = plan_upconv_fwd_collapsed(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
+    h->plans[PL_G1BC + l - 1] = plan_upconv_dgrad_collapsed(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
   }
   {
     const int* g3 = h->gdim[3];
@@ -432,7 +486,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
   const long MB = h->MB, NB = h->NB;
   size_t wneed = 0;
   {
-    const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B};
+    const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B, PL_G1FC, PL_G2FC, PL_G3FC};
     for (int id : wg) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)MB));
     const int wd[] = {PL_D1F, PL_D2F, PL_D3F, PL_D4F};
     for (int id : wd) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)NB));
@@ -476,6 +530,9 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->GWT[0] = nullptr;
     for (int l = 1; l <= 3; ++l) carve(h->GWT[l], 27L * gch[l - 1] * gch[l]);
     carve(h->W9T, 64 * 32);
+    h->GWC[0] = h->GWD[0] = nullptr;
+    for (int l = 1; l <= 3; ++l) { carve(h->GWC[l], 64L * gch[l - 1] * gch[l]); carve(h->GWD[l], 64L * gch[l - 1] * gch[l]); }
+    carve(h->dWc, 64L * 256 * 256);
     { float* f = nullptr; carve(f, 64); if (pass == 1) h->d_flag = (int*)f; }
     if (pass == 0) {
       h->ws_bytes = off + 256;
@@ -512,6 +569,12 @@ extern "C" int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, l
   if (!h) return -2;
   for (int i = 0; i < 10; ++i) { if (offsets) offsets[i] = h->doff[i]; if (sizes) sizes[i] = h->dsz[i]; }
   return 10;
+}
+
+extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
+  if (!h || !name) return -2;
+  if (!strcmp(name, "collapse")) { h->collapse = value ? 1 : 0; return 0; }
+  return bad_arg(h, "set_option: unknown option");
 }
 
 extern "C" int rdgan_profile(rdgan_handle* h, unsigned tag_mask) {
@@ -569,8 +632,16 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   float* rs[4] = {nullptr, h->r1, h->r2, h->r3};
   for (int l = 1; l <= 3; ++l) {
     // UpSampling3D + Conv3D + bias (T:330-331), then PixelNorm + LeakyReLU (T:332-333)
-    RD_TRY(launch_conv(h, h->plans[PL_G1F + l - 1], h->d_plans + PL_G1F + l - 1, B, hs[l - 1], gp + h->goff[2 * l],
-                       h->gch[l], hs[l], epi_make(RD_EPI_BIAS, gp + h->goff[2 * l + 1]), st,
+    const float* Wl = gp + h->goff[2 * l];
+    int pl = PL_G1F + l - 1;
+    if (h->collapse) {
+      hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * h->gch[l - 1] * h->gch[l])), dim3(256), 0, st, Wl,
+                         h->GWC[l], h->gch[l - 1] * h->gch[l]);
+      Wl = h->GWC[l];
+      pl = PL_G1FC + l - 1;
+    }
+    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], Wl, h->gch[l], hs[l],
+                       epi_make(RD_EPI_BIAS, gp + h->goff[2 * l + 1]), st,
                        l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st));
@@ -735,8 +806,9 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
   const int nd = h->nd;
   RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
   RD_TRY(prep_critic_weights(h, dp, st));
-  for (int l = 1; l <= 3; ++l)
-    RD_TRY(launch_transpose(h, gp + h->goff[2 * l], h->GWT[l], 27, h->gch[l - 1], h->gch[l], h->gch[l - 1], st));
+  if (!h->collapse)
+    for (int l = 1; l <= 3; ++l)
+      RD_TRY(launch_transpose(h, gp + h->goff[2 * l], h->GWT[l], 27, h->gch[l - 1], h->gch[l], h->gch[l - 1], st));
   RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st));
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
@@ -765,26 +837,50 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
   float* hs[4] = {h->h0, h->h1, h->h2, h->h3};
   float* rs[4] = {nullptr, h->r1, h->r2, h->r3};
   float* dys[4] = {nullptr, h->dy1, h->dy2, h->gh3};
-  float* gups[4] = {nullptr, h->gup1, h->gup2, h->gup3};
+  float* gups[4] = {nullptr, h->gup1, h->gup2, h->gup3};   // direct: gradient on the upsampled grid; collapsed: on the source grid
+  const int col = h->collapse;
+  if (col) {
+    RdSliceMap map;
+    collapsed_dgrad_slice_map(map.src);
+    for (int l = 1; l <= 3; ++l)   // Wd[q][Cout][Cin] <- Wc (written by gen_forward_impl above)
+      hipLaunchKernelGGL(k_transpose_map, dim3((h->gch[l] + 31) / 32, (h->gch[l - 1] + 31) / 32, 64), dim3(256), 0, st,
+                         h->GWC[l], h->GWD[l], h->gch[l - 1], h->gch[l], map);
+  }
   for (int l = 3; l >= 1; --l) {
     {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
       if (l == 3) RD_TRY(launch_pn_bwd(h, h->gh3, hs[3], rs[3], dys[3], npix3, 64, 0, 0, 0, 0, st));
-      else RD_TRY(launch_pn_bwd(h, gups[l + 1], hs[l], rs[l], dys[l], (long)B * h->gpix[l], h->gch[l], 1, h->gdim[l][0],
-                                h->gdim[l][1], h->gdim[l][2], st));
+      else RD_TRY(launch_pn_bwd(h, gups[l + 1], hs[l], rs[l], dys[l], (long)B * h->gpix[l], h->gch[l], col ? 0 : 1,
+                                h->gdim[l][0], h->gdim[l][1], h->gdim[l][2], st));
     }
-    int plf = PL_G1F + l - 1, plb = PL_G1B + l - 1;
-    RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], grad + h->goff[2 * l], h->wpartial,
-                        h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
-    RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
-    RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWT[l], h->gch[l - 1], gups[l],
-                       epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
+    const long cc = (long)h->gch[l - 1] * h->gch[l];
+    if (col) {
+      int plf = PL_G1FC + l - 1, plb = PL_G1BC + l - 1;
+      RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap,
+                          st, RDGAN_TAG_GCONV_WGRAD));
+      hipLaunchKernelGGL(k_fold_collapsed_wgrad, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->dWc,
+                         grad + h->goff[2 * l], (int)cc);
+      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
+      RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWD[l], h->gch[l - 1], gups[l],
+                         epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
+    } else {
+      int plf = PL_G1F + l - 1, plb = PL_G1B + l - 1;
+      RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], grad + h->goff[2 * l], h->wpartial,
+                          h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
+      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
+      RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWT[l], h->gch[l - 1], gups[l],
+                         epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
+    }
   }
-  // Dense (T:326): pool the upsample adjoint, LeakyReLU', then dW = xcat^T ga0, db = colsum(ga0)
+  // Dense (T:326): (pool the upsample adjoint,) LeakyReLU', then dW = xcat^T ga0, db = colsum(ga0)
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_pool_lrelu_bwd, dim3(ew_blocks((long)B * h->gpix[0] * 64)), dim3(256), 0, st, h->gup1, h->h0,
-                       h->ga0, (long)B * h->gpix[0], h->gdim[0][0], h->gdim[0][1], h->gdim[0][2], 256);
+    if (col)
+      hipLaunchKernelGGL(k_lrelu_bwd, dim3(ew_blocks((long)B * h->gpix[0] * 64)), dim3(256), 0, st, h->gup1, h->h0, h->ga0,
+                         (long)B * h->gpix[0] * 64);
+    else
+      hipLaunchKernelGGL(k_pool_lrelu_bwd, dim3(ew_blocks((long)B * h->gpix[0] * 64)), dim3(256), 0, st, h->gup1, h->h0,
+                         h->ga0, (long)B * h->gpix[0], h->gdim[0][0], h->gdim[0][1], h->gdim[0][2], 256);
   }
   RD_TRY(launch_wgrad(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, h->ga0, grad + h->goff[0], h->wpartial,
                       h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));

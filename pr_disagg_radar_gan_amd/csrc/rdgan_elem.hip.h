@@ -443,3 +443,82 @@ __global__ void k_transpose(const float* __restrict__ in, float* __restrict__ ou
     if (c < C && r < ldo) out[(t * C + c) * ldo + r] = tile[tx][i];
   }
 }
+
+// ------------------------------------------------------------------------------------
+// Upsample collapse (exact algebra): UpSampling3D(2) followed by a 3-tap 'same'
+// conv equals, per output parity p and per axis, a 2-tap conv on the un-upsampled grid with taps
+// p=0: (W0 | W1+W2) at offsets (-1, 0);  p=1: (W0+W1 | W2) at offsets (0, +1).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void rd_collapse_range(int p, int a, int& lo, int& hi) {
+  lo = a == 0 ? 0 : (p == 0 ? 1 : 2);
+  hi = a == 1 ? 2 : (p == 0 ? 0 : 1);
+}
+// Wc[phase(pd,ph,pw)*8 + tap(ad,ah,aw)][ci][co] = sum of the original taps that fall on the same source voxel
+__global__ void k_collapse_weights(const float* __restrict__ W, float* __restrict__ Wc, int CC /* Cin*Cout */) {
+  const int c4s = CC / 4;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < 64L * c4s; f += (long)gridDim.x * blockDim.x) {
+    int pa = (int)(f / c4s);
+    int e = (int)(f - (long)pa * c4s) * 4;
+    int ph = pa >> 3, tp = pa & 7;
+    int lo[3], hi[3];
+    rd_collapse_range(ph >> 2, tp >> 2, lo[0], hi[0]);
+    rd_collapse_range((ph >> 1) & 1, (tp >> 1) & 1, lo[1], hi[1]);
+    rd_collapse_range(ph & 1, tp & 1, lo[2], hi[2]);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int td = lo[0]; td <= hi[0]; ++td)
+      for (int th = lo[1]; th <= hi[1]; ++th)
+        for (int tw = lo[2]; tw <= hi[2]; ++tw) s += *(const f32x4*)(W + (long)((td * 3 + th) * 3 + tw) * CC + e);
+    *(f32x4*)(Wc + (long)pa * CC + e) = s;
+  }
+}
+// adjoint of the above: dW[t] = sum over the 8 collapsed entries (p,a) whose range contains t on every axis
+__global__ void k_fold_collapsed_wgrad(const float* __restrict__ dWc, float* __restrict__ dW, int CC) {
+  const int c4s = CC / 4;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < 27L * c4s; f += (long)gridDim.x * blockDim.x) {
+    int t = (int)(f / c4s);
+    int e = (int)(f - (long)t * c4s) * 4;
+    int tt[3] = {t / 9, (t / 3) % 3, t % 3};
+    // per axis the two (p,a) pairs containing tap t: t=0: (0,0),(1,0); t=1: (0,1),(1,0); t=2: (0,1),(1,1)
+    int pp[3][2], aa[3][2];
+    for (int x = 0; x < 3; ++x) {
+      pp[x][0] = 0; aa[x][0] = tt[x] == 0 ? 0 : 1;
+      pp[x][1] = 1; aa[x][1] = tt[x] == 2 ? 1 : 0;
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 2; ++k) {
+          int ph = pp[0][i] * 4 + pp[1][j] * 2 + pp[2][k];
+          int tp = aa[0][i] * 4 + aa[1][j] * 2 + aa[2][k];
+          s += *(const f32x4*)(dWc + (long)(ph * 8 + tp) * CC + e);
+        }
+    *(f32x4*)(dW + (long)t * CC + e) = s;
+  }
+}
+// out[q][c][r] = in[map[q]][r][c] for q < 64 (per-slice transpose through LDS); builds the collapsed
+// input-gradient weights Wd[q][Cout][Cin] from Wc
+struct RdSliceMap { int16_t src[64]; };
+__global__ void k_transpose_map(const float* __restrict__ in, float* __restrict__ out, int R, int C, RdSliceMap map) {
+  __shared__ float tile[32][33];
+  const long q = blockIdx.z, t = map.src[blockIdx.z];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? in[(t * R + r) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) out[(q * C + c) * R + r] = tile[tx][i];
+  }
+}
+// out = g * LeakyReLU'(h) (from the stored output h)
+__global__ void k_lrelu_bwd(const float* __restrict__ g, const float* __restrict__ h, float* __restrict__ out, long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 gv = *(const f32x4*)(g + 4 * i), hv = *(const f32x4*)(h + 4 * i);
+    gv.x *= rd_lrelu_slope_from_out(hv.x); gv.y *= rd_lrelu_slope_from_out(hv.y);
+    gv.z *= rd_lrelu_slope_from_out(hv.z); gv.w *= rd_lrelu_slope_from_out(hv.w);
+    *(f32x4*)(out + 4 * i) = gv;
+  }
+}

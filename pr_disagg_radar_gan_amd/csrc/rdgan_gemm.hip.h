@@ -219,8 +219,8 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 
 // ------------------------------------------------------------------------------------
 // weight gradient: dW[tap_w*wrpt + c][n] = sum_m A_gather[m][tap][c] * dY[m][n]
-// grid.x = r_tile * NT + n_tile, grid.y = split over rows m; partial sums per split go to
-// `partial[split][RT*BR][N]` and are folded by k_wgrad_reduce (deterministic, no atomics).
+// grid.x = r_tile * NT + n_tile, grid.y = split over rows m, grid.z = plan phase; partial sums go to
+// `partial[phase][split][RT*BR][N]` and are folded by k_wgrad_reduce (deterministic, no atomics).
 // ------------------------------------------------------------------------------------
 struct RdWgradTiling {
   int RT, NT;            // tiles over (tap,c) rows and over N
@@ -256,7 +256,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhalf = lane >> 5;
-  const RdPhase& P = plan->ph[0];
+  const RdPhase& P = plan->ph[blockIdx.z];
   const int rows = B * P.L;
   const int rt = blockIdx.x / T.NT, ntile = blockIdx.x - rt * T.NT;
   const int n0 = ntile * BN;
@@ -357,7 +357,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   }
 
   const int N = plan->N;
-  float* out = partial + ((long)blockIdx.y * T.RT + rt) * BR * N;
+  float* out = partial + (((long)blockIdx.z * gridDim.y + blockIdx.y) * T.RT + rt) * BR * N;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -374,18 +374,17 @@ __global__ void k_wgrad_reduce(const RdPlan* __restrict__ plan, const float* __r
   const int N = plan->N;
   const int n4s = N / 4;
   const long total = (long)T.RT * BR * n4s;
-  const RdPhase& P = plan->ph[0];
+  const RdPhase& P = plan->ph[blockIdx.y];
+  const long stride = (long)T.RT * BR * N;
+  const float* pbase = partial + (long)blockIdx.y * nsplit * stride;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     int R = (int)(f / n4s), n = (int)(f - (long)R * n4s) * 4;
     int rt = R / BR, r = R - rt * BR, tap, c;
     rd_wgrad_tile_row(T, BR, rt, r, tap, c);
     if (tap >= P.ntaps || c >= plan->SC) continue;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const long stride = (long)T.RT * BR * N;
-    const float* p = partial + (long)R * N + n;
+    const float* p = pbase + (long)R * N + n;
     for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(p + k * stride);
-    float* o = dW + ((long)P.tap_w[tap] * plan->w_rows_per_tap + c) * ldw + n;
-    // ldw may be < 4-aligned (Cout = 1 handled elsewhere); N % 4 == 0 here
-    *(f32x4*)o = s;
+    *(f32x4*)(dW + P.w_off + ((long)P.tap_w[tap] * plan->w_rows_per_tap + c) * ldw + n) = s;
   }
 }

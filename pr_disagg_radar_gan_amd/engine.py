@@ -144,6 +144,10 @@ class Engine:
         _lib.check(self.lib.rdgan_adam(_ptr(params), _ptr(grad), _ptr(v), n, int(t), float(lr), float(beta2), float(eps),
                                        float(grad_scale), self._stream()), self._h, "rdgan_adam")
 
+    def set_option(self, name, value):
+        """"collapse": 1 (default) = 8-tap collapsed generator blocks, 0 = the reference's direct 27-tap form"""
+        _lib.check(self.lib.rdgan_set_option(self._h, name.encode(), int(value)), self._h, "rdgan_set_option")
+
     def profile(self, tag_mask):
         _lib.check(self.lib.rdgan_profile(self._h, int(tag_mask)), self._h, "rdgan_profile")
 

@@ -33,8 +33,10 @@ def eng16():
     e.close()
 
 
+@pytest.mark.parametrize("collapse", [1, 0])
 @pytest.mark.parametrize("B", [1, 2, 5])
-def test_generator_forward_parity(eng16, B):
+def test_generator_forward_parity(eng16, B, collapse):
+    eng16.set_option("collapse", collapse)      # 8-tap collapsed blocks (default) vs the direct 27-tap form
     g, _ = _params(16, 11)
     x, cond, z = ot.synthetic_batch(B, 16, 3)
     ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
@@ -47,6 +49,7 @@ def test_generator_forward_parity(eng16, B):
 
 
 def test_generator_kat_zero_weights(eng16):
+    eng16.set_option("collapse", 1)
     g = [np.zeros(s, np.float32) for _, s in W.gen_param_shapes(16)]
     x, cond, z = ot.synthetic_batch(3, 16, 4)
     out = eng16.gen_forward(eng16.to_slab(g), dev(z), dev(cond)).cpu().numpy()
@@ -105,6 +108,7 @@ def _parity_over_batches(run_case):
 
 @pytest.mark.parametrize("B,seed", [(2, 1234), (3, 0), (4, 99)])
 def test_critic_step_grads_parity(eng16, B, seed):
+    eng16.set_option("collapse", 1)
     g, d = _params(16, 13)
 
     def run_case(data_seed):
@@ -120,8 +124,10 @@ def test_critic_step_grads_parity(eng16, B, seed):
     _parity_over_batches(run_case)
 
 
+@pytest.mark.parametrize("collapse", [1, 0])
 @pytest.mark.parametrize("B,seed", [(2, 4321), (3, 0)])
-def test_gen_step_grads_parity(eng16, B, seed):
+def test_gen_step_grads_parity(eng16, B, seed, collapse):
+    eng16.set_option("collapse", collapse)
     g, d = _params(16, 14)
 
     def run_case(data_seed):
