@@ -38,7 +38,7 @@ static RdPlan plan_conv_fwd(int D, int H, int W, int Cin, int Cout, int Do, int 
   q.ntaps = 27;
   for (int t = 0; t < 27; ++t) {
     q.tap_off[t][0] = (int8_t)(t / 9 - pd); q.tap_off[t][1] = (int8_t)((t / 3) % 3 - ph_);
-    q.tap_off[t][2] = (int8_t)(t % 3 - pw); q.tap_w[t] = (int16_t)t;
+    q.tap_off[t][2] = (int8_t)(t % 3 - pw); q.tap_w[t] = t;
   }
   return p;
 }
@@ -55,7 +55,7 @@ static RdPlan plan_d1_fwd(int nd, int Do, int Ho, int Wo) {
   q.ntaps = 9;
   for (int t = 0; t < 9; ++t) {
     q.tap_off[t][0] = (int8_t)(t / 3); q.tap_off[t][1] = (int8_t)(t % 3); q.tap_off[t][2] = 0;
-    q.tap_w[t] = (int16_t)t;
+    q.tap_w[t] = t;
   }
   return p;
 }
@@ -70,7 +70,7 @@ static RdPlan plan_conv_dgrad_s1(int D, int H, int W, int Cin, int Cout) {
   q.ntaps = 27;
   for (int t = 0; t < 27; ++t) {
     q.tap_off[t][0] = (int8_t)(1 - t / 9); q.tap_off[t][1] = (int8_t)(1 - (t / 3) % 3);
-    q.tap_off[t][2] = (int8_t)(1 - t % 3); q.tap_w[t] = (int16_t)t;
+    q.tap_off[t][2] = (int8_t)(1 - t % 3); q.tap_w[t] = t;
   }
   return p;
 }
@@ -105,7 +105,7 @@ static RdPlan plan_conv_dgrad_s2(int D, int H, int W, int Cin, int Do, int Ho, i
           int k = q.ntaps++;
           q.tap_off[k][0] = (int8_t)(base[0] - jd); q.tap_off[k][1] = (int8_t)(base[1] - jh);
           q.tap_off[k][2] = (int8_t)(base[2] - jw);
-          q.tap_w[k] = (int16_t)(((pi[0] + 2 * jd) * 3 + (pi[1] + 2 * jh)) * 3 + (pi[2] + 2 * jw));
+          q.tap_w[k] = ((pi[0] + 2 * jd) * 3 + (pi[1] + 2 * jh)) * 3 + (pi[2] + 2 * jw);
         }
   }
   p.nphases = np;
@@ -127,7 +127,7 @@ static RdPlan plan_upconv_fwd_collapsed(int D, int H, int W, int Cin, int Cout) 
     for (int t = 0; t < 8; ++t) {
       q.tap_off[t][0] = (int8_t)(par[0] - 1 + (t >> 2)); q.tap_off[t][1] = (int8_t)(par[1] - 1 + ((t >> 1) & 1));
       q.tap_off[t][2] = (int8_t)(par[2] - 1 + (t & 1));
-      q.tap_w[t] = (int16_t)(ph * 8 + t);
+      q.tap_w[t] = ph * 8 + t;
     }
   }
   return p;
@@ -153,7 +153,7 @@ static RdPlan plan_upconv_dgrad_collapsed(int D, int H, int W, int Cin, int Cout
   q.ntaps = 64;
   for (int t = 0; t < 64; ++t) {
     q.tap_off[t][0] = (int8_t)((t >> 4) - 1); q.tap_off[t][1] = (int8_t)(((t >> 2) & 3) - 1);
-    q.tap_off[t][2] = (int8_t)((t & 3) - 1); q.tap_w[t] = (int16_t)t;
+    q.tap_off[t][2] = (int8_t)((t & 3) - 1); q.tap_w[t] = t;
   }
   return p;
 }
@@ -167,6 +167,60 @@ static RdPlan plan_rows(int D, int H, int W, int SC, int cstride, int N, int dcs
   phase_defaults(q, D, H, W);
   q.ntaps = 1;
   return p;
+}
+
+// Row tables + per-tap scalars (see RdRow in rdgan_plan.h).  Appends this plan's rows to `out` and records
+// each phase's first entry in ph.tab (relative to the plan's own table start).  Returns false if a tap
+// offset falls outside the [-1, 2] range the 12-bit validity mask encodes.
+static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
+  const int S[3] = {p.SD, p.SH, p.SW};
+  const int Dd[3] = {p.DD, p.DH, p.DW};
+  p.src_sample = (long)p.SD * p.SH * p.SW * p.s_cstride;
+  p.dst_sample = (long)p.DD * p.DH * p.DW * p.d_cstride;
+  int first = 0;
+  for (int pi = 0; pi < p.nphases; ++pi) {
+    RdPhase& q = p.ph[pi];
+    q.tab = first;
+    for (int t = 0; t < q.ntaps; ++t) {
+      int mask = 0;
+      for (int a = 0; a < 3; ++a) {
+        int off = q.tap_off[t][a];
+        if (off < -1 || off > 2 || (p.s_shift && off > 1)) return false;
+        mask |= 1 << (a * 4 + off + 1);
+      }
+      q.tap_mask[t] = mask;
+      q.tap_code[t] = ((q.tap_off[t][0] + 1) * 2) | ((6 + (q.tap_off[t][1] + 1) * 2) << 8) | ((12 + (q.tap_off[t][2] + 1) * 2) << 16);
+      q.tap_delta[t] = ((q.tap_off[t][0] * p.SH + q.tap_off[t][1]) * p.SW + q.tap_off[t][2]) * p.s_cstride;
+    }
+    const int LL[3] = {q.LD, q.LH, q.LW};
+    for (int ld = 0; ld < q.LD; ++ld)
+      for (int lh = 0; lh < q.LH; ++lh)
+        for (int lw = 0; lw < q.LW; ++lw) {
+          const int l[3] = {ld, lh, lw};
+          RdRow e = {0, 0, 0, 0};
+          long so = 0, dof = 0;
+          for (int a = 0; a < 3; ++a) {
+            int pre = l[a] * q.s_mul[a];
+            so = so * S[a] + (pre >> p.s_shift);
+            dof = dof * Dd[a] + (l[a] * q.o_mul[a] + q.o_off[a]);
+            for (int off = -1; off <= 2; ++off) {
+              int v = pre + off;
+              if (v >= 0 && v < (S[a] << p.s_shift)) e.y |= 1 << (a * 4 + off + 1);
+            }
+            if (p.s_shift)
+              for (int off = -1; off <= 1; ++off) {
+                int code = (((pre + off) >> 1) - (pre >> 1)) + 1;      // arithmetic shift: (-1)>>1 = -1
+                e.w |= (code & 3) << (a * 6 + (off + 1) * 2);
+              }
+          }
+          e.x = (int)(so * p.s_cstride);
+          e.z = (int)(dof * p.d_cstride);
+          out.push_back(e);
+        }
+    (void)LL;
+    first += q.L;
+  }
+  return true;
 }
 
 // ------------------------------------------------------------------------------------
@@ -195,6 +249,7 @@ struct rdgan_handle {
   // plans
   std::vector<RdPlan> plans;
   RdPlan* d_plans = nullptr;
+  RdRow* d_tab = nullptr;
   // workspace
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -268,6 +323,11 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   }
   long tm = plan_tiles(hp, B, BM);
   if (tm <= 0) return 0;
+  {  // a tile's buffer descriptor is based at its first sample: its span must stay below 2 GiB
+    long minL = hp.ph[0].L;
+    for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
+    if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
+  }
   dim3 grid((unsigned)tm, (unsigned)(hp.N / BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, W, ldw, dst, epi);
   RD_CHECK(h, hipGetLastError());
@@ -345,6 +405,8 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
   size_t need = (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
   if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
+  if ((T.rows_per_split / hp.ph[0].L + 2) * std::max(hp.src_sample, hp.dst_sample) * 4 >= 0x7FFFFFF0L)
+    return bad_arg(h, "wgrad: split span exceeds 2 GiB");
   const int np = hp.nphases;
   if (BR == 128 && BN == 128) RD_TRY((launch_wgrad_cfg<128, 128>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
   else if (BR == 128) RD_TRY((launch_wgrad_cfg<128, 64>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
@@ -478,9 +540,21 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->plans[PL_D2B + l - 2] = plan_conv_dgrad_s2(id[0], id[1], id[2], dch[l - 1], od[0], od[1], od[2], dch[l], pd);
   }
   h->plans[PL_D1B] = plan_rows(h->ddim[1][0], h->ddim[1][1], h->ddim[1][2], 64, 64, 64, 64);
-  hipError_t e = hipMalloc((void**)&h->d_plans, sizeof(RdPlan) * PL_COUNT);
+  hipError_t e = hipSuccess;
+  {
+    std::vector<RdRow> tab;
+    std::vector<size_t> first(PL_COUNT);
+    for (int i = 0; i < PL_COUNT; ++i) {
+      first[i] = tab.size();
+      if (!plan_build_tables(h->plans[i], tab)) { delete h; return -2; }
+    }
+    e = hipMalloc((void**)&h->d_tab, sizeof(RdRow) * tab.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_tab, tab.data(), sizeof(RdRow) * tab.size(), hipMemcpyHostToDevice);
+    for (int i = 0; i < PL_COUNT; ++i) h->plans[i].tab = h->d_tab + first[i];
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_plans, sizeof(RdPlan) * PL_COUNT);
   if (e == hipSuccess) e = hipMemcpy(h->d_plans, h->plans.data(), sizeof(RdPlan) * PL_COUNT, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { delete h; return (int)e; }
+  if (e != hipSuccess) { if (h->d_tab) (void)hipFree(h->d_tab); if (h->d_plans) (void)hipFree(h->d_plans); delete h; return (int)e; }
 
   // workspace carve (two passes: size, then assign)
   const long MB = h->MB, NB = h->NB;
@@ -553,6 +627,7 @@ extern "C" void rdgan_destroy(rdgan_handle* h) {
   }
   if (h->ws) (void)hipFree(h->ws);
   if (h->d_plans) (void)hipFree(h->d_plans);
+  if (h->d_tab) (void)hipFree(h->d_tab);
   delete h;
 }
 
@@ -907,13 +982,20 @@ extern "C" int rdgan_adam(float* params, const float* grad, float* v, long n, in
 // op-level entry points for the parity tests
 // ------------------------------------------------------------------------------------
 struct TmpPlan {
-  RdPlan host; RdPlan* dev = nullptr;
+  RdPlan host; RdPlan* dev = nullptr; RdRow* tab = nullptr;
   int upload() {
-    hipError_t e = hipMalloc((void**)&dev, sizeof(RdPlan));
+    std::vector<RdRow> t;
+    if (!plan_build_tables(host, t)) return -2;
+    hipError_t e = hipMalloc((void**)&tab, sizeof(RdRow) * t.size());
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpy(tab, t.data(), sizeof(RdRow) * t.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int)e;
+    host.tab = tab;
+    e = hipMalloc((void**)&dev, sizeof(RdPlan));
     if (e != hipSuccess) return (int)e;
     return (int)hipMemcpy(dev, &host, sizeof(RdPlan), hipMemcpyHostToDevice);
   }
-  ~TmpPlan() { if (dev) (void)hipFree(dev); }
+  ~TmpPlan() { if (dev) (void)hipFree(dev); if (tab) (void)hipFree(tab); }
 };
 
 extern "C" int rdgan_op_conv3d(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W,

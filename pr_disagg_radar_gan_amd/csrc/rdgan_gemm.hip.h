@@ -5,8 +5,12 @@
 // v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD): lane l supplies A[i=l&31][k=l>>5]
 // and B[k=l>>5][j=l&31]; D register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), col l&31.
 // 256-thread workgroups = 4 waves (one per SIMD); operands staged global -> registers -> LDS
-// (double buffered, one barrier per K chunk); A is gathered on the fly from NDHWC
-// activations through an RdPlan (im2col never materialised, nearest-upsample folded in).
+// (double buffered, one barrier per K chunk).  A is gathered on the fly from NDHWC
+// activations (im2col never materialised).  The gather costs 4 VALU instructions per row and
+// K chunk: the per-row source offset and a 12-bit validity mask come from a host-built row
+// table (RdRow), the per-tap offset and mask are wave-uniform scalars from the plan, and
+// out-of-image taps are turned into an out-of-range buffer offset so the hardware bounds
+// check of buffer_load returns the zero padding.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rdgan_plan.h"
@@ -16,25 +20,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RD_LRELU_ALPHA 0.2f
+#define RD_OOB 0x80000000u            // >= num_records of every descriptor below -> load returns 0
+#define RD_RSRC_BYTES 0x7FFFFFF0u
 
 __device__ __forceinline__ float rd_lrelu(float x) { return x > 0.f ? x : RD_LRELU_ALPHA * x; }
 // slope of LeakyReLU recovered from its (possibly dropout-scaled) output: TF's LeakyReluGrad
 // uses features > 0 ? 1 : alpha, and sign(output) == sign(features) for kept elements.
 __device__ __forceinline__ float rd_lrelu_slope_from_out(float h) { return h > 0.f ? 1.f : RD_LRELU_ALPHA; }
 
-struct RdRowDecode {
-  int b, ld, lh, lw;
-};
-__device__ __forceinline__ RdRowDecode rd_decode_row(int m, const RdPhase& P) {
-  RdRowDecode r;
-  r.b = m / P.L;
-  int rem = m - r.b * P.L;
-  int hw = P.LH * P.LW;
-  r.ld = rem / hw;
-  rem -= r.ld * hw;
-  r.lh = rem / P.LW;
-  r.lw = rem - r.lh * P.LW;
-  return r;
+__device__ __forceinline__ f32x4 rd_buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rd_make_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RD_RSRC_BYTES, 0x00020000);
+}
+// s_shift == 1 (direct form of the folded upsample): per-row element delta of a tap from the 2-bit codes
+__device__ __forceinline__ int rd_shift_delta(int w, int sd, int sh_, int sw, int SH, int SW, int cstride) {
+  int dd = ((w >> sd) & 3) - 1, dh = ((w >> sh_) & 3) - 1, dw = ((w >> sw) & 3) - 1;
+  return ((dd * SH + dh) * SW + dw) * cstride;
 }
 
 // ------------------------------------------------------------------------------------
@@ -43,7 +46,7 @@ __device__ __forceinline__ RdRowDecode rd_decode_row(int m, const RdPhase& P) {
 template <int BM, int BN, int WM, int WN, int BK>
 __global__ void __launch_bounds__(256)
 k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
-            const float* __restrict__ W, int ldw, float* __restrict__ dst, RdEpi epi) {
+            const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -59,7 +62,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhalf = lane >> 5;
 
-  // ---- which phase / tile
+  // ---- which phase / tile (all wave-uniform)
   int mt = blockIdx.x, pidx = 0;
   for (int p = 0; p < plan->nphases; ++p) {
     int nt = (B * plan->ph[p].L + BM - 1) / BM;
@@ -67,31 +70,40 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
     mt -= nt;
   }
   const RdPhase& P = plan->ph[pidx];
-  const int rows = B * P.L;
+  const int L = P.L;
+  const int rows = B * L;
   const int m0 = mt * BM;
   const int n0 = blockIdx.y * BN;
-  const int SD = plan->SD, SH = plan->SH, SW = plan->SW, sh = plan->s_shift;
-  const int limD = SD << sh, limH = SH << sh, limW = SW << sh;
+  const int b0 = m0 / L, l0 = m0 - b0 * L;
+  const int sh = plan->s_shift, SH = plan->SH, SW = plan->SW;
   const int cstride = plan->s_cstride, SC = plan->SC, wrpt = plan->w_rows_per_tap;
   const bool partial_c = (SC & 3) != 0;
-  const float* Wp = W + P.w_off;
+  const int ssample = (int)plan->src_sample;
+  const RdRow* __restrict__ tab = plan->tab + P.tab;
+  const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)b0 * plan->src_sample);
+  const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(W + P.w_off);
 
-  // ---- per-thread A rows
-  int rb[A_P], rc[A_P];
+  // ---- per-thread A rows: byte offset relative to sample b0 (incl. this thread's channel group), validity bits
+  int roff[A_P], rbits[A_P], rcode[A_P];
   const int a_c4 = (tid % A_F4) * 4;
 #pragma unroll
   for (int i = 0; i < A_P; ++i) {
     int r = tid / A_F4 + i * A_RPP;
-    int m = m0 + r;
-    if (r < BM && m < rows) {
-      RdRowDecode d = rd_decode_row(m, P);
-      rb[i] = d.b;
-      rc[i] = (d.ld * P.s_mul[0]) | ((d.lh * P.s_mul[1]) << 8) | ((d.lw * P.s_mul[2]) << 16);
-    } else {
-      rb[i] = -1; rc[i] = 0;
+    roff[i] = 0; rbits[i] = 0; rcode[i] = 0;
+    if (r < BM && m0 + r < rows) {
+      int l = l0 + r, bb = 0;
+      if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
+      else { bb = l / L; l -= bb * L; }
+      RdRow e = tab[l];
+      roff[i] = (bb * ssample + e.x + a_c4) * 4;
+      rbits[i] = e.y; rcode[i] = e.w;
     }
   }
+  // ---- per-thread B (weight) rows
+  int boff[B_P];
   const int b_kk = tid / B_F4, b_n4 = (tid % B_F4) * 4;
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) boff[i] = ((b_kk + i * B_RPP) * ldw + n0 + b_n4) * 4;
 
   const int CPT = (SC + BK - 1) / BK;
   const int nchunks = P.ntaps * CPT;
@@ -99,32 +111,36 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   f32x4 ra[A_P], rw[B_P];
   auto load_chunk = [&](int q) {
     const int tap = q / CPT, cc = q - tap * CPT;
-    const int od = P.tap_off[tap][0], oh = P.tap_off[tap][1], ow = P.tap_off[tap][2];
+    const int tmask = P.tap_mask[tap];
     const int c = cc * BK + a_c4;
+    const bool c_ok = c < SC;
+    int sdelta = cc * BK * 4, sd = 0, sh_ = 0, sw = 0;
+    if (sh) {
+      const int code = P.tap_code[tap];
+      sd = code & 255; sh_ = (code >> 8) & 255; sw = code >> 16;
+    } else {
+      sdelta += P.tap_delta[tap] * 4;
+    }
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      int pd = (rc[i] & 255) + od, ph = ((rc[i] >> 8) & 255) + oh, pw = ((rc[i] >> 16) & 255) + ow;
-      bool ok = rb[i] >= 0 && (unsigned)pd < (unsigned)limD && (unsigned)ph < (unsigned)limH &&
-                (unsigned)pw < (unsigned)limW && c < SC;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        long pix = (((long)rb[i] * SD + (pd >> sh)) * SH + (ph >> sh)) * SW + (pw >> sh);
-        v = *(const f32x4*)(src + pix * cstride + c);
-        if (partial_c) {
-          if (c + 1 >= SC) v.y = 0.f;
-          if (c + 2 >= SC) v.z = 0.f;
-          if (c + 3 >= SC) v.w = 0.f;
-        }
+      unsigned voff = (unsigned)(roff[i] + sdelta);
+      if (sh) voff += (unsigned)(rd_shift_delta(rcode[i], sd, sh_, sw, SH, SW, cstride) * 4);
+      bool ok = c_ok && ((rbits[i] & tmask) == tmask);
+      f32x4 v = rd_buf_load4(rsA, ok ? voff : RD_OOB);
+      if (partial_c) {
+        if (c + 1 >= SC) v.y = 0.f;
+        if (c + 2 >= SC) v.z = 0.f;
+        if (c + 3 >= SC) v.w = 0.f;
       }
       ra[i] = v;
     }
-    const long krow0 = (long)P.tap_w[tap] * wrpt + cc * BK;
+    const int krow0 = P.tap_w[tap] * wrpt + cc * BK;
+    const int sB = krow0 * ldw * 4;
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int kk = b_kk + i * B_RPP;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kk < BK && cc * BK + kk < SC) v = *(const f32x4*)(Wp + (krow0 + kk) * ldw + n0 + b_n4);
-      rw[i] = v;
+      bool ok = kk < BK && cc * BK + kk < SC;
+      rw[i] = rd_buf_load4(rsB, ok ? (unsigned)(boff[i] + sB) : RD_OOB);
     }
   };
   auto store_chunk = [&](int buf) {
@@ -133,12 +149,12 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       int r = tid / A_F4 + i * A_RPP;
-      if (r < BM) *(f32x4*)&As[r * AST + a_c4] = ra[i];
+      if (BM % A_RPP == 0 || r < BM) *(f32x4*)&As[r * AST + a_c4] = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int kk = b_kk + i * B_RPP;
-      if (kk < BK) *(f32x4*)&Bs[kk * BST + b_n4] = rw[i];
+      if (BK % B_RPP == 0 || kk < BK) *(f32x4*)&Bs[kk * BST + b_n4] = rw[i];
     }
   };
 
@@ -156,47 +172,55 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   for (int q = 0; q < nchunks; ++q) {
     const int buf = q & 1;
     if (q + 1 < nchunks) load_chunk(q + 1);
-    const float* As = smem + buf * STAGE;
-    const float* Bs = As + BM * AST;
+    const float* As = smem + buf * STAGE + (wm * WTM + l31) * AST + lhalf * 4;
+    const float* Bs = smem + buf * STAGE + BM * AST + lhalf * 4 * BST + wn * WTN + l31;
+    // LDS fragments double-buffered in registers: the reads of k-group j8+1 are issued before the MFMAs of j8
+    constexpr int NJ = BK / 8;
+    f32x4 fa[2][TM];
+    float fb[2][4][TN];
+    auto load_frag = [&](int slot, int j8) {
 #pragma unroll
-    for (int j8 = 0; j8 < BK / 8; ++j8) {
-      f32x4 a[TM];
+      for (int i = 0; i < TM; ++i) fa[slot][i] = *(const f32x4*)&As[i * 32 * AST + j8 * 8];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = *(const f32x4*)&As[(wm * WTM + i * 32 + l31) * AST + j8 * 8 + lhalf * 4];
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float bv[TN];
+        for (int j = 0; j < TN; ++j) fb[slot][s][j] = Bs[(j8 * 8 + s) * BST + j * 32];
+    };
+    load_frag(0, 0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = Bs[(j8 * 8 + lhalf * 4 + s) * BST + wn * WTN + j * 32 + l31];
+    for (int j8 = 0; j8 < NJ; ++j8) {
+      const int cur = j8 & 1;
+      if (j8 + 1 < NJ) load_frag(cur ^ 1, j8 + 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], bv[j], acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][s][j], acc[i][j], 0, 0, 0);
     }
     if (q + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue
-  const int DD = plan->DD, DH = plan->DH, DW = plan->DW, dcs = plan->d_cstride;
+  const int dcs = plan->d_cstride;
+  const long dsample = plan->dst_sample;
   const int mode = epi.mode;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-      const int m = m0 + row;
-      if (m < rows) {
-        RdRowDecode d = rd_decode_row(m, P);
-        long pix = (((long)d.b * DD + d.ld * P.o_mul[0] + P.o_off[0]) * DH + d.lh * P.o_mul[1] + P.o_off[1]) * DW +
-                   d.lw * P.o_mul[2] + P.o_off[2];
+      if (m0 + row < rows) {
+        int l = l0 + row, bb = b0;
+        if (L >= BM) { if (l >= L) { l -= L; bb += 1; } }
+        else { int qd = l / L; l -= qd * L; bb += qd; }
+        const long rowbase = (long)bb * dsample + tab[l].z;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int col = n0 + wn * WTN + j * 32 + l31;
-          const long idx = pix * dcs + col;
+          const long idx = rowbase + col;
           float v = acc[i][j][r];
           if (mode == RD_EPI_BIAS) {
             v += epi.bias[col];
@@ -215,6 +239,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
       }
     }
   }
+  (void)dcs;
 }
 
 // ------------------------------------------------------------------------------------
@@ -257,58 +282,82 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhalf = lane >> 5;
   const RdPhase& P = plan->ph[blockIdx.z];
-  const int rows = B * P.L;
+  const int L = P.L;
+  const int rows = B * L;
   const int rt = blockIdx.x / T.NT, ntile = blockIdx.x - rt * T.NT;
   const int n0 = ntile * BN;
   const int mbeg = blockIdx.y * T.rows_per_split;
   const int mend = min(rows, mbeg + T.rows_per_split);
-  const int SD = plan->SD, SH = plan->SH, SW = plan->SW, sh = plan->s_shift;
-  const int limD = SD << sh, limH = SH << sh, limW = SW << sh;
+  const int sh = plan->s_shift, SH = plan->SH, SW = plan->SW;
   const int cstride = plan->s_cstride, SC = plan->SC;
-  const int DD = plan->DD, DH = plan->DH, DW = plan->DW, dcs = plan->d_cstride;
   const bool partial_c = (SC & 3) != 0;
+  const int ssample = (int)plan->src_sample, dsample = (int)plan->dst_sample;
+  const RdRow* __restrict__ tab = plan->tab + P.tab;
+  // descriptors are based at the first sample this block touches (wave-uniform)
+  const int bb0 = mbeg / L;
+  const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)bb0 * plan->src_sample);
+  const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(dy + (long)bb0 * plan->dst_sample);
 
   // this thread's A column group (tap, c) is fixed over the whole loop
   int a_tap, a_c;
   const int a_r = (tid % A_F4) * 4;
   rd_wgrad_tile_row(T, BR, rt, a_r, a_tap, a_c);
   const bool a_ok = a_tap < P.ntaps && a_c < SC;
-  int od = 0, oh = 0, ow = 0;
-  if (a_ok) { od = P.tap_off[a_tap][0]; oh = P.tap_off[a_tap][1]; ow = P.tap_off[a_tap][2]; }
-  const int b_n4 = (tid % B_F4) * 4;
+  int tmask = 0x7FFF, tdelta = 0, sd = 0, sh_ = 0, sw = 0;   // tmask never matches when !a_ok
+  if (a_ok) {
+    tmask = P.tap_mask[a_tap];
+    if (sh) { const int code = P.tap_code[a_tap]; sd = code & 255; sh_ = (code >> 8) & 255; sw = code >> 16; }
+    else tdelta = P.tap_delta[a_tap];
+  }
+  const int a_const = (tdelta + a_c) * 4;
+  const int b_const = (n0 + (tid % B_F4) * 4) * 4;
+
+  // row cursors (sample index relative to bb0, row inside the sample) of this thread's A and B positions
+  int ab[A_P], al[A_P], gb[B_P], gl[B_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) { int m = mbeg + tid / A_F4 + i * A_PPP; ab[i] = m / L; al[i] = m - ab[i] * L; ab[i] -= bb0; }
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) { int m = mbeg + tid / B_F4 + i * B_PPP; gb[i] = m / L; gl[i] = m - gb[i] * L; gb[i] -= bb0; }
 
   f32x4 ra[A_P], rg[B_P];
   auto load_chunk = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       int m = mb + tid / A_F4 + i * A_PPP;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_ok && m < mend) {
-        RdRowDecode d = rd_decode_row(m, P);
-        int pd = d.ld * P.s_mul[0] + od, ph = d.lh * P.s_mul[1] + oh, pw = d.lw * P.s_mul[2] + ow;
-        if ((unsigned)pd < (unsigned)limD && (unsigned)ph < (unsigned)limH && (unsigned)pw < (unsigned)limW) {
-          long pix = (((long)d.b * SD + (pd >> sh)) * SH + (ph >> sh)) * SW + (pw >> sh);
-          v = *(const f32x4*)(src + pix * cstride + a_c);
-          if (partial_c) {
-            if (a_c + 1 >= SC) v.y = 0.f;
-            if (a_c + 2 >= SC) v.z = 0.f;
-            if (a_c + 3 >= SC) v.w = 0.f;
-          }
-        }
+      unsigned voff = RD_OOB;
+      if (m < mend) {
+        RdRow e = tab[al[i]];
+        int off = (ab[i] * ssample + e.x) * 4 + a_const;
+        if (sh) off += rd_shift_delta(e.w, sd, sh_, sw, SH, SW, cstride) * 4;
+        if ((e.y & tmask) == tmask) voff = (unsigned)off;
+      }
+      f32x4 v = rd_buf_load4(rsA, voff);
+      if (partial_c) {
+        if (a_c + 1 >= SC) v.y = 0.f;
+        if (a_c + 2 >= SC) v.z = 0.f;
+        if (a_c + 3 >= SC) v.w = 0.f;
       }
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int m = mb + tid / B_F4 + i * B_PPP;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < mend) {
-        RdRowDecode d = rd_decode_row(m, P);
-        long pix = (((long)d.b * DD + d.ld * P.o_mul[0] + P.o_off[0]) * DH + d.lh * P.o_mul[1] + P.o_off[1]) * DW +
-                   d.lw * P.o_mul[2] + P.o_off[2];
-        v = *(const f32x4*)(dy + pix * dcs + n0 + b_n4);
-      }
-      rg[i] = v;
+      unsigned voff = RD_OOB;
+      if (m < mend) voff = (unsigned)((gb[i] * dsample + tab[gl[i]].z) * 4 + b_const);
+      rg[i] = rd_buf_load4(rsB, voff);
+    }
+    // advance the cursors by one chunk (BKP rows)
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      al[i] += BKP;
+      if (L >= BKP) { if (al[i] >= L) { al[i] -= L; ab[i] += 1; } }
+      else { int qd = al[i] / L; al[i] -= qd * L; ab[i] += qd; }
+    }
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      gl[i] += BKP;
+      if (L >= BKP) { if (gl[i] >= L) { gl[i] -= L; gb[i] += 1; } }
+      else { int qd = gl[i] / L; gl[i] -= qd * L; gb[i] += qd; }
     }
   };
   auto store_chunk = [&](int buf) {
@@ -317,7 +366,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
 #pragma unroll
     for (int i = 0; i < A_P; ++i) *(f32x4*)&As[(tid / A_F4 + i * A_PPP) * AST + a_r] = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_P; ++i) *(f32x4*)&Bs[(tid / B_F4 + i * B_PPP) * BST + b_n4] = rg[i];
+    for (int i = 0; i < B_P; ++i) *(f32x4*)&Bs[(tid / B_F4 + i * B_PPP) * BST + (tid % B_F4) * 4] = rg[i];
   };
 
   f32x16 acc[TM][TN];
@@ -337,20 +386,32 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   for (int q = 0; q < nchunks; ++q) {
     const int buf = q & 1;
     if (q + 1 < nchunks) load_chunk(mbeg + (q + 1) * BKP);
-    const float* As = smem + buf * STAGE;
-    const float* Bs = As + BKP * AST;
+    const float* As = smem + buf * STAGE + lhalf * AST + wm * WTM + l31;
+    const float* Bs = smem + buf * STAGE + BKP * AST + lhalf * BST + wn * WTN + l31;
+    // operands of 4 k-steps (8 rows) per group, double-buffered in registers
+    constexpr int NG = BKP / 8;
+    float fa[2][4][TM], fb[2][4][TN];
+    auto load_frag = [&](int slot, int g) {
 #pragma unroll
-    for (int s = 0; s < BKP / 2; ++s) {
-      float av[TM], bv[TN];
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[(2 * s + lhalf) * AST + wm * WTM + i * 32 + l31];
+        for (int i = 0; i < TM; ++i) fa[slot][s][i] = As[(g * 8 + 2 * s) * AST + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bs[(2 * s + lhalf) * BST + wn * WTN + j * 32 + l31];
+        for (int j = 0; j < TN; ++j) fb[slot][s][j] = Bs[(g * 8 + 2 * s) * BST + j * 32];
+      }
+    };
+    load_frag(0, 0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int g = 0; g < NG; ++g) {
+      const int cur = g & 1;
+      if (g + 1 < NG) load_frag(cur ^ 1, g + 1);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s][i], fb[cur][s][j], acc[i][j], 0, 0, 0);
     }
     if (q + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();

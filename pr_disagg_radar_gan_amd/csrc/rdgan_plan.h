@@ -16,9 +16,20 @@ struct RdPhase {
   int o_mul[3], o_off[3];
   int ntaps;
   int w_off;                   // element offset added to W for this phase
-  int8_t tap_off[RD_MAX_TAPS][4];
-  int16_t tap_w[RD_MAX_TAPS];  // weight row block = tap_w * w_rows_per_tap
+  int tab;                     // first entry of this phase's row table in RdPlan::tab
+  int8_t tap_off[RD_MAX_TAPS][4];   // per-axis source offset of the tap, each in [-1, 2]
+  int tap_w[RD_MAX_TAPS];      // weight row block = tap_w * w_rows_per_tap (int32: scalar-loadable)
+  int tap_delta[RD_MAX_TAPS];  // s_shift == 0: element offset of the tap relative to the row base
+  int tap_mask[RD_MAX_TAPS];   // validity bits the tap needs: bit (axis*4 + off + 1) per axis
+  int tap_code[RD_MAX_TAPS];   // s_shift == 1: the three 2-bit-code shift amounts, packed sd | sh<<8 | sw<<16
 };
+
+// Row table entry (one per row l of a sample, per phase), built on the host at plan time:
+//   x = element offset of the row's source base pixel inside its sample (coords l*s_mul, >> s_shift)
+//   y = validity bits: bit (axis*4 + off + 1) set iff 0 <= l*s_mul + off < S << s_shift, off in [-1,2]
+//   z = element offset of the row's destination pixel inside its sample
+//   w = s_shift == 1 only: 2-bit codes ((l+off)>>1) - (l>>1) + 1 at bit axis*6 + (off+1)*2, off in [-1,1]
+struct RdRow { int x, y, z, w; };
 
 struct RdPlan {
   int nphases;
@@ -31,6 +42,8 @@ struct RdPlan {
   int d_cstride;               // floats per destination pixel
   int N;                       // GEMM N
   int pad_;
+  long src_sample, dst_sample; // floats per sample of the source / destination tensor
+  const RdRow* tab;            // device pointer to the row tables of all phases
   RdPhase ph[RD_MAX_PHASES];
 };
 
