@@ -38,7 +38,7 @@ static RdPlan plan_conv_fwd(int D, int H, int W, int Cin, int Cout, int Do, int 
   q.ntaps = 27;
   for (int t = 0; t < 27; ++t) {
     q.tap_off[t][0] = (int8_t)(t / 9 - pd); q.tap_off[t][1] = (int8_t)((t / 3) % 3 - ph_);
-    q.tap_off[t][2] = (int8_t)(t % 3 - pw); q.tap_w[t] = t;
+    q.tap_off[t][2] = (int8_t)(t % 3 - pw); q.tap[t].w = t;
   }
   return p;
 }
@@ -55,7 +55,7 @@ static RdPlan plan_d1_fwd(int nd, int Do, int Ho, int Wo) {
   q.ntaps = 9;
   for (int t = 0; t < 9; ++t) {
     q.tap_off[t][0] = (int8_t)(t / 3); q.tap_off[t][1] = (int8_t)(t % 3); q.tap_off[t][2] = 0;
-    q.tap_w[t] = t;
+    q.tap[t].w = t;
   }
   return p;
 }
@@ -70,7 +70,7 @@ static RdPlan plan_conv_dgrad_s1(int D, int H, int W, int Cin, int Cout) {
   q.ntaps = 27;
   for (int t = 0; t < 27; ++t) {
     q.tap_off[t][0] = (int8_t)(1 - t / 9); q.tap_off[t][1] = (int8_t)(1 - (t / 3) % 3);
-    q.tap_off[t][2] = (int8_t)(1 - t % 3); q.tap_w[t] = t;
+    q.tap_off[t][2] = (int8_t)(1 - t % 3); q.tap[t].w = t;
   }
   return p;
 }
@@ -105,7 +105,7 @@ static RdPlan plan_conv_dgrad_s2(int D, int H, int W, int Cin, int Do, int Ho, i
           int k = q.ntaps++;
           q.tap_off[k][0] = (int8_t)(base[0] - jd); q.tap_off[k][1] = (int8_t)(base[1] - jh);
           q.tap_off[k][2] = (int8_t)(base[2] - jw);
-          q.tap_w[k] = ((pi[0] + 2 * jd) * 3 + (pi[1] + 2 * jh)) * 3 + (pi[2] + 2 * jw);
+          q.tap[k].w = ((pi[0] + 2 * jd) * 3 + (pi[1] + 2 * jh)) * 3 + (pi[2] + 2 * jw);
         }
   }
   p.nphases = np;
@@ -127,7 +127,7 @@ static RdPlan plan_upconv_fwd_collapsed(int D, int H, int W, int Cin, int Cout) 
     for (int t = 0; t < 8; ++t) {
       q.tap_off[t][0] = (int8_t)(par[0] - 1 + (t >> 2)); q.tap_off[t][1] = (int8_t)(par[1] - 1 + ((t >> 1) & 1));
       q.tap_off[t][2] = (int8_t)(par[2] - 1 + (t & 1));
-      q.tap_w[t] = ph * 8 + t;
+      q.tap[t].w = ph * 8 + t;
     }
   }
   return p;
@@ -153,7 +153,7 @@ static RdPlan plan_upconv_dgrad_collapsed(int D, int H, int W, int Cin, int Cout
   q.ntaps = 64;
   for (int t = 0; t < 64; ++t) {
     q.tap_off[t][0] = (int8_t)((t >> 4) - 1); q.tap_off[t][1] = (int8_t)(((t >> 2) & 3) - 1);
-    q.tap_off[t][2] = (int8_t)((t & 3) - 1); q.tap_w[t] = t;
+    q.tap_off[t][2] = (int8_t)((t & 3) - 1); q.tap[t].w = t;
   }
   return p;
 }
@@ -188,9 +188,9 @@ static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
         if (off < -1 || off > 2 || (p.s_shift && off > 1)) return false;
         mask |= 1 << (a * 4 + off + 1);
       }
-      q.tap_mask[t] = mask;
-      q.tap_code[t] = ((q.tap_off[t][0] + 1) * 2) | ((6 + (q.tap_off[t][1] + 1) * 2) << 8) | ((12 + (q.tap_off[t][2] + 1) * 2) << 16);
-      q.tap_delta[t] = ((q.tap_off[t][0] * p.SH + q.tap_off[t][1]) * p.SW + q.tap_off[t][2]) * p.s_cstride;
+      q.tap[t].mask = mask;
+      q.tap[t].code = ((q.tap_off[t][0] + 1) * 2) | ((6 + (q.tap_off[t][1] + 1) * 2) << 8) | ((12 + (q.tap_off[t][2] + 1) * 2) << 16);
+      q.tap[t].delta = ((q.tap_off[t][0] * p.SH + q.tap_off[t][1]) * p.SW + q.tap_off[t][2]) * p.s_cstride * 4;
     }
     const int LL[3] = {q.LD, q.LH, q.LW};
     for (int ld = 0; ld < q.LD; ++ld)
@@ -310,13 +310,13 @@ static long plan_tiles(const RdPlan& p, int B, int BM) {
   return t;
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, bool PARTIAL, bool SHIFT>
 static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                            const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
   constexpr int AST = BK + 4, BST = BN + 4;
   constexpr size_t lds = 2 * (size_t)(BM * AST + BK * BST) * sizeof(float);
   static bool attr_done = false;
-  auto kern = k_conv_gemm<BM, BN, WM, WN, BK>;
+  auto kern = k_conv_gemm<BM, BN, WM, WN, BK, PARTIAL, SHIFT>;
   if (!attr_done) {
     RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -328,7 +328,7 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
     for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
     if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
   }
-  dim3 grid((unsigned)tm, (unsigned)(hp.N / BN));
+  dim3 grid((unsigned)(tm * (hp.N / BN)));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, W, ldw, dst, epi);
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -337,18 +337,27 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
 static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* W,
                        int ldw, float* dst, const RdEpi& epi, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
+  const bool partial = (hp.SC & 3) != 0, shift = hp.s_shift != 0;
+  if (partial && shift) return bad_arg(h, "conv: SC % 4 != 0 with a folded upsample is not supported");
   if (hp.SC < 32 && hp.SC != 27) {   // small-K taps (D1): BK = 8
-    if (hp.N % 64) return bad_arg(h, "conv: N % 64 != 0 for BK=8 path");
-    return launch_conv_cfg<128, 64, 2, 2, 8>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    if (hp.N % 64 || shift) return bad_arg(h, "conv: unsupported BK=8 case");
+    if (partial) return launch_conv_cfg<128, 64, 2, 2, 8, true, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    return launch_conv_cfg<128, 64, 2, 2, 8, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
   }
-  if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200)
-    return launch_conv_cfg<128, 128, 2, 2, 32>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+#define RD_CONV(BM_, BN_, WM_, WN_)                                                                                  \
+  do {                                                                                                               \
+    if (partial) return launch_conv_cfg<BM_, BN_, WM_, WN_, 32, true, false>(h, hp, dp, B, src, W, ldw, dst, epi, st); \
+    if (shift) return launch_conv_cfg<BM_, BN_, WM_, WN_, 32, false, true>(h, hp, dp, B, src, W, ldw, dst, epi, st);   \
+    return launch_conv_cfg<BM_, BN_, WM_, WN_, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);             \
+  } while (0)
+  if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200) RD_CONV(128, 128, 2, 2);
   if (hp.N % 64 == 0) {
-    if (plan_tiles(hp, B, 128) * (hp.N / 64) >= 200)
-      return launch_conv_cfg<128, 64, 2, 2, 32>(h, hp, dp, B, src, W, ldw, dst, epi, st);
-    return launch_conv_cfg<64, 64, 2, 2, 32>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    if (plan_tiles(hp, B, 128) * (hp.N / 64) >= 200) RD_CONV(128, 64, 2, 2);
+    RD_CONV(64, 64, 2, 2);
   }
-  if (hp.N == 32) return launch_conv_cfg<128, 32, 4, 1, 32>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  if (hp.N == 32 && !partial && !shift)
+    return launch_conv_cfg<128, 32, 4, 1, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+#undef RD_CONV
   return bad_arg(h, "conv: unsupported N");
 }
 
@@ -375,20 +384,21 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   rps = (rps + 31) / 32 * 32;
   T.rows_per_split = (int)rps;
   nsplit = (int)((rows + rps - 1) / rps);
+  T.nsplit = nsplit; T.nphases = p.nphases;
   return T;
 }
 
-template <int BR, int BN>
+template <int BR, int BN, bool PARTIAL, bool SHIFT>
 static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int B, const float* src, const float* dy,
                             float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(32 * (BR + 4) + 32 * (BN + 4)) * sizeof(float);
   static bool attr_done = false;
-  auto kern = k_wgrad_gemm<BR, BN>;
+  auto kern = k_wgrad_gemm<BR, BN, PARTIAL, SHIFT>;
   if (!attr_done) {
     RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  dim3 grid((unsigned)(T.RT * T.NT), (unsigned)nsplit, (unsigned)nphases);
+  dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, dy, partial, T);
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -396,7 +406,7 @@ static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int 
 
 // dW (rows tap_w*wrpt + c, leading dimension ldw = N) from src (gathered through the plan) and dy
 static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* dy,
-                        float* dW, float* partial, size_t partial_cap, hipStream_t st, int tag) {
+                        float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
   if (hp.N % 64) return bad_arg(h, "wgrad: N % 64 != 0");
   for (int i = 1; i < hp.nphases; ++i)
@@ -408,13 +418,23 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   if ((T.rows_per_split / hp.ph[0].L + 2) * std::max(hp.src_sample, hp.dst_sample) * 4 >= 0x7FFFFFF0L)
     return bad_arg(h, "wgrad: split span exceeds 2 GiB");
   const int np = hp.nphases;
-  if (BR == 128 && BN == 128) RD_TRY((launch_wgrad_cfg<128, 128>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
-  else if (BR == 128) RD_TRY((launch_wgrad_cfg<128, 64>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
-  else if (BN == 128) RD_TRY((launch_wgrad_cfg<64, 128>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
-  else RD_TRY((launch_wgrad_cfg<64, 64>(h, dp, np, B, src, dy, partial, T, nsplit, st)));
+  const bool partial = (hp.SC & 3) != 0, shift = hp.s_shift != 0;
+  if (partial && (shift || BR != 64 || BN != 64)) return bad_arg(h, "wgrad: SC % 4 != 0 only with the 64x64 tile");
+#define RD_WG(BR_, BN_)                                                                                           \
+  do {                                                                                                            \
+    if (shift) RD_TRY((launch_wgrad_cfg<BR_, BN_, false, true>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st))); \
+    else RD_TRY((launch_wgrad_cfg<BR_, BN_, false, false>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));      \
+  } while (0)
+  float* partial_buf = partial_ws;
+  if (partial) RD_TRY((launch_wgrad_cfg<64, 64, true, false>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  else if (BR == 128 && BN == 128) RD_WG(128, 128);
+  else if (BR == 128) RD_WG(128, 64);
+  else if (BN == 128) RD_WG(64, 128);
+  else RD_WG(64, 64);
+#undef RD_WG
   long total = (long)T.RT * BR * (hp.N / 4);
   int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks, np), dim3(256), 0, st, dp, partial, nsplit, T, BR, dW, hp.N);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks, np), dim3(256), 0, st, dp, partial_ws, nsplit, T, BR, dW, hp.N);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include "rdgan_plan.h"
 #include "rdgan_rng.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,13 +41,26 @@ __device__ __forceinline__ int rd_shift_delta(int w, int sd, int sh_, int sw, in
   return ((dd * SH + dh) * SW + dw) * cstride;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2).  This bijective remap
+// gives every XCD a contiguous range of the logical tile order, so tiles that share operand rows (halo
+// rows of neighbouring M tiles, the tap tiles of one wgrad split) hit the same L2.  Placement only
+// affects speed, never correctness.
+__device__ __forceinline__ int rd_xcd_swizzle(int lin, int total) {
+  const int xcd = lin & 7, idx = lin >> 3;
+  const int q = total >> 3, r = total & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
 // ------------------------------------------------------------------------------------
 // C[m][n] = sum_{tap,c} A_gather[m][tap][c] * W[tap_w*wrpt + c][n]  (+ fused epilogue)
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, bool PARTIAL, bool SHIFT>
 __global__ void __launch_bounds__(256)
 k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
             const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {
+  // PARTIAL: SC % 4 != 0 (the last float4 of a tap is masked element-wise); SHIFT: s_shift == 1 (direct
+  // form of the folded nearest upsample).  Both are compile-time so the hot loop has no uniform branches.
   static_assert(WM * WN == 4, "4 waves");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -62,8 +76,11 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhalf = lane >> 5;
 
-  // ---- which phase / tile (all wave-uniform)
-  int mt = blockIdx.x, pidx = 0;
+  // ---- which phase / tile (all wave-uniform); 1-D grid, N tile fastest so both N tiles of an M tile run together
+  const int NTn = plan->N / BN;
+  const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ntile = swz % NTn;
+  int mt = swz / NTn, pidx = 0;
   for (int p = 0; p < plan->nphases; ++p) {
     int nt = (B * plan->ph[p].L + BM - 1) / BM;
     if (mt < nt) { pidx = p; break; }
@@ -73,12 +90,12 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   const int L = P.L;
   const int rows = B * L;
   const int m0 = mt * BM;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = ntile * BN;
   const int b0 = m0 / L, l0 = m0 - b0 * L;
-  const int sh = plan->s_shift, SH = plan->SH, SW = plan->SW;
+  const int SH = plan->SH, SW = plan->SW;
   const int cstride = plan->s_cstride, SC = plan->SC, wrpt = plan->w_rows_per_tap;
-  const bool partial_c = (SC & 3) != 0;
   const int ssample = (int)plan->src_sample;
+  const int ntaps = P.ntaps;
   const RdRow* __restrict__ tab = plan->tab + P.tab;
   const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)b0 * plan->src_sample);
   const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(W + P.w_off);
@@ -106,55 +123,63 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   for (int i = 0; i < B_P; ++i) boff[i] = ((b_kk + i * B_RPP) * ldw + n0 + b_n4) * 4;
 
   const int CPT = (SC + BK - 1) / BK;
-  const int nchunks = P.ntaps * CPT;
+  const int nchunks = ntaps * CPT;
 
-  f32x4 ra[A_P], rw[B_P];
-  auto load_chunk = [&](int q) {
-    const int tap = q / CPT, cc = q - tap * CPT;
-    const int tmask = P.tap_mask[tap];
-    const int c = cc * BK + a_c4;
+  // K order: channel chunk outer, tap inner (the taps of one chunk re-read the same 128-byte pixel segments of
+  // neighbouring rows).  (ld_tap, ld_cc) is the chunk the NEXT load_chunk call fetches; its tap descriptor `ti`
+  // was scalar-loaded one call earlier, so no load_chunk waits on a scalar load it has just issued.
+  int ld_tap = 0, ld_cc = 0;
+  RdTap ti = P.tap[0];
+
+  // two register sets: the gather of chunk q+2 is in flight while chunk q is multiplied and chunk q+1 sits in LDS
+  f32x4 ra[2][A_P], rw[2][B_P];
+  auto load_chunk = [&](auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
+    const int tmask = ti.mask;
+    const int c = ld_cc * BK + a_c4;
     const bool c_ok = c < SC;
-    int sdelta = cc * BK * 4, sd = 0, sh_ = 0, sw = 0;
-    if (sh) {
-      const int code = P.tap_code[tap];
-      sd = code & 255; sh_ = (code >> 8) & 255; sw = code >> 16;
-    } else {
-      sdelta += P.tap_delta[tap] * 4;
-    }
+    const int sdelta = ld_cc * BK * 4 + (SHIFT ? 0 : ti.delta);
+    const int sd = ti.code & 255, sh_ = (ti.code >> 8) & 255, sw = ti.code >> 16;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       unsigned voff = (unsigned)(roff[i] + sdelta);
-      if (sh) voff += (unsigned)(rd_shift_delta(rcode[i], sd, sh_, sw, SH, SW, cstride) * 4);
+      if (SHIFT) voff += (unsigned)(rd_shift_delta(rcode[i], sd, sh_, sw, SH, SW, cstride) * 4);
       bool ok = c_ok && ((rbits[i] & tmask) == tmask);
+#ifdef RD_ABL_L1
+      voff = (unsigned)(roff[i] & 0x3FFF);     // diagnostic build: every gather hits a 16 KiB window
+#endif
       f32x4 v = rd_buf_load4(rsA, ok ? voff : RD_OOB);
-      if (partial_c) {
+      if (PARTIAL) {
         if (c + 1 >= SC) v.y = 0.f;
         if (c + 2 >= SC) v.z = 0.f;
         if (c + 3 >= SC) v.w = 0.f;
       }
-      ra[i] = v;
+      ra[slot][i] = v;
     }
-    const int krow0 = P.tap_w[tap] * wrpt + cc * BK;
-    const int sB = krow0 * ldw * 4;
+    const int sB = (ti.w * wrpt + ld_cc * BK) * ldw * 4;
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int kk = b_kk + i * B_RPP;
-      bool ok = kk < BK && cc * BK + kk < SC;
-      rw[i] = rd_buf_load4(rsB, ok ? (unsigned)(boff[i] + sB) : RD_OOB);
+      bool ok = (BK % B_RPP == 0 || kk < BK) && ld_cc * BK + kk < SC;
+      rw[slot][i] = rd_buf_load4(rsB, ok ? (unsigned)(boff[i] + sB) : RD_OOB);
     }
+    // advance to the next chunk and fetch its tap descriptor (consumed by the next call)
+    if (++ld_tap == ntaps) { ld_tap = 0; ++ld_cc; }
+    ti = P.tap[ld_tap];
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
     float* As = smem + buf * STAGE;
     float* Bs = As + BM * AST;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       int r = tid / A_F4 + i * A_RPP;
-      if (BM % A_RPP == 0 || r < BM) *(f32x4*)&As[r * AST + a_c4] = ra[i];
+      if (BM % A_RPP == 0 || r < BM) *(f32x4*)&As[r * AST + a_c4] = ra[slot][i];
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int kk = b_kk + i * B_RPP;
-      if (BK % B_RPP == 0 || kk < BK) *(f32x4*)&Bs[kk * BST + b_n4] = rw[i];
+      if (BK % B_RPP == 0 || kk < BK) *(f32x4*)&Bs[kk * BST + b_n4] = rw[slot][i];
     }
   };
 
@@ -166,12 +191,16 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_chunk(0);
-  store_chunk(0);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  load_chunk(S0{});
+  if (nchunks > 1) load_chunk(S1{});
+  store_chunk(0, S0{});
   __syncthreads();
-  for (int q = 0; q < nchunks; ++q) {
+  auto step = [&](int q, auto cur_c, auto nxt_c) {
+    // chunk q: LDS buffer q&1; registers `cur` are free (chunk q was stored last step), `nxt` hold chunk q+1
     const int buf = q & 1;
-    if (q + 1 < nchunks) load_chunk(q + 1);
+    if (q + 2 < nchunks) load_chunk(cur_c);
     const float* As = smem + buf * STAGE + (wm * WTM + l31) * AST + lhalf * 4;
     const float* Bs = smem + buf * STAGE + BM * AST + lhalf * 4 * BST + wn * WTN + l31;
     // LDS fragments double-buffered in registers: the reads of k-group j8+1 are issued before the MFMAs of j8
@@ -199,12 +228,15 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][s][j], acc[i][j], 0, 0, 0);
     }
-    if (q + 1 < nchunks) store_chunk(buf ^ 1);
+    if (q + 1 < nchunks) store_chunk(buf ^ 1, nxt_c);
     __syncthreads();
+  };
+  for (int q = 0; q < nchunks; q += 2) {
+    step(q, S0{}, S1{});
+    if (q + 1 < nchunks) step(q + 1, S1{}, S0{});
   }
 
   // ---- epilogue
-  const int dcs = plan->d_cstride;
   const long dsample = plan->dst_sample;
   const int mode = epi.mode;
 #pragma unroll
@@ -239,7 +271,6 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
       }
     }
   }
-  (void)dcs;
 }
 
 // ------------------------------------------------------------------------------------
@@ -253,6 +284,7 @@ struct RdWgradTiling {
   int cw;                // c extent per tap inside a tile (BR, or padded SC < BR)
   int taps_per_tile;     // 1 or BR/cw
   int rows_per_split;    // multiple of 32
+  int nsplit, nphases;   // grid = RT*NT * nsplit * nphases workgroups (1-D)
 };
 
 __device__ __forceinline__ void rd_wgrad_tile_row(const RdWgradTiling& T, int BR, int rt, int r, int& tap, int& c) {
@@ -266,7 +298,7 @@ __device__ __forceinline__ void rd_wgrad_tile_row(const RdWgradTiling& T, int BR
   }
 }
 
-template <int BR, int BN>
+template <int BR, int BN, bool PARTIAL, bool SHIFT>
 __global__ void __launch_bounds__(256)
 k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
              const float* __restrict__ dy, float* __restrict__ partial, RdWgradTiling T) {
@@ -281,16 +313,19 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhalf = lane >> 5;
-  const RdPhase& P = plan->ph[blockIdx.z];
+  // 1-D grid, (tap,c) tile fastest: the tiles of one row split read the same source rows and run on one XCD
+  const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tiles = T.RT * T.NT;
+  const int bx = swz % tiles, by = (swz / tiles) % T.nsplit, bz = swz / (tiles * T.nsplit);
+  const RdPhase& P = plan->ph[bz];
   const int L = P.L;
   const int rows = B * L;
-  const int rt = blockIdx.x / T.NT, ntile = blockIdx.x - rt * T.NT;
+  const int rt = bx / T.NT, ntile = bx - rt * T.NT;
   const int n0 = ntile * BN;
-  const int mbeg = blockIdx.y * T.rows_per_split;
+  const int mbeg = by * T.rows_per_split;
   const int mend = min(rows, mbeg + T.rows_per_split);
-  const int sh = plan->s_shift, SH = plan->SH, SW = plan->SW;
+  const int SH = plan->SH, SW = plan->SW;
   const int cstride = plan->s_cstride, SC = plan->SC;
-  const bool partial_c = (SC & 3) != 0;
   const int ssample = (int)plan->src_sample, dsample = (int)plan->dst_sample;
   const RdRow* __restrict__ tab = plan->tab + P.tab;
   // descriptors are based at the first sample this block touches (wave-uniform)
@@ -305,11 +340,12 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   const bool a_ok = a_tap < P.ntaps && a_c < SC;
   int tmask = 0x7FFF, tdelta = 0, sd = 0, sh_ = 0, sw = 0;   // tmask never matches when !a_ok
   if (a_ok) {
-    tmask = P.tap_mask[a_tap];
-    if (sh) { const int code = P.tap_code[a_tap]; sd = code & 255; sh_ = (code >> 8) & 255; sw = code >> 16; }
-    else tdelta = P.tap_delta[a_tap];
+    const RdTap t = P.tap[a_tap];
+    tmask = t.mask;
+    if (SHIFT) { sd = t.code & 255; sh_ = (t.code >> 8) & 255; sw = t.code >> 16; }
+    else tdelta = t.delta;
   }
-  const int a_const = (tdelta + a_c) * 4;
+  const int a_const = tdelta + a_c * 4;
   const int b_const = (n0 + (tid % B_F4) * 4) * 4;
 
   // row cursors (sample index relative to bb0, row inside the sample) of this thread's A and B positions
@@ -319,32 +355,44 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
 #pragma unroll
   for (int i = 0; i < B_P; ++i) { int m = mbeg + tid / B_F4 + i * B_PPP; gb[i] = m / L; gl[i] = m - gb[i] * L; gb[i] -= bb0; }
 
-  f32x4 ra[A_P], rg[B_P];
-  auto load_chunk = [&](int mb) {
+  // row-table entries of the NEXT chunk's rows, fetched one load_chunk call ahead so the gather never waits
+  // on a table load it has just issued
+  RdRow ea[A_P];
+  int ez[B_P];
+  auto fetch_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) ea[i] = tab[al[i]];
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) ez[i] = tab[gl[i]].z;
+  };
+  fetch_rows();
+
+  f32x4 ra[2][A_P], rg[2][B_P];
+  auto load_chunk = [&](int mb, auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       int m = mb + tid / A_F4 + i * A_PPP;
       unsigned voff = RD_OOB;
-      if (m < mend) {
-        RdRow e = tab[al[i]];
+      {
+        const RdRow e = ea[i];
         int off = (ab[i] * ssample + e.x) * 4 + a_const;
-        if (sh) off += rd_shift_delta(e.w, sd, sh_, sw, SH, SW, cstride) * 4;
-        if ((e.y & tmask) == tmask) voff = (unsigned)off;
+        if (SHIFT) off += rd_shift_delta(e.w, sd, sh_, sw, SH, SW, cstride) * 4;
+        if (m < mend && (e.y & tmask) == tmask) voff = (unsigned)off;
       }
       f32x4 v = rd_buf_load4(rsA, voff);
-      if (partial_c) {
+      if (PARTIAL) {
         if (a_c + 1 >= SC) v.y = 0.f;
         if (a_c + 2 >= SC) v.z = 0.f;
         if (a_c + 3 >= SC) v.w = 0.f;
       }
-      ra[i] = v;
+      ra[slot][i] = v;
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int m = mb + tid / B_F4 + i * B_PPP;
-      unsigned voff = RD_OOB;
-      if (m < mend) voff = (unsigned)((gb[i] * dsample + tab[gl[i]].z) * 4 + b_const);
-      rg[i] = rd_buf_load4(rsB, voff);
+      unsigned voff = m < mend ? (unsigned)((gb[i] * dsample + ez[i]) * 4 + b_const) : RD_OOB;
+      rg[slot][i] = rd_buf_load4(rsB, voff);
     }
     // advance the cursors by one chunk (BKP rows)
 #pragma unroll
@@ -359,14 +407,16 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
       if (L >= BKP) { if (gl[i] >= L) { gl[i] -= L; gb[i] += 1; } }
       else { int qd = gl[i] / L; gl[i] -= qd * L; gb[i] += qd; }
     }
+    fetch_rows();        // al/gl < L always, so the table reads stay in range even past the last chunk
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
     float* As = smem + buf * STAGE;
     float* Bs = As + BKP * AST;
 #pragma unroll
-    for (int i = 0; i < A_P; ++i) *(f32x4*)&As[(tid / A_F4 + i * A_PPP) * AST + a_r] = ra[i];
+    for (int i = 0; i < A_P; ++i) *(f32x4*)&As[(tid / A_F4 + i * A_PPP) * AST + a_r] = ra[slot][i];
 #pragma unroll
-    for (int i = 0; i < B_P; ++i) *(f32x4*)&Bs[(tid / B_F4 + i * B_PPP) * BST + (tid % B_F4) * 4] = rg[i];
+    for (int i = 0; i < B_P; ++i) *(f32x4*)&Bs[(tid / B_F4 + i * B_PPP) * BST + (tid % B_F4) * 4] = rg[slot][i];
   };
 
   f32x16 acc[TM][TN];
@@ -378,14 +428,17 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = (mend - mbeg + BKP - 1) / BKP;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   if (nchunks > 0) {
-    load_chunk(mbeg);
-    store_chunk(0);
+    load_chunk(mbeg, S0{});                 // the row cursors advance one chunk per call: calls must stay in order
+    if (nchunks > 1) load_chunk(mbeg + BKP, S1{});
+    store_chunk(0, S0{});
   }
   __syncthreads();
-  for (int q = 0; q < nchunks; ++q) {
+  auto step = [&](int q, auto cur_c, auto nxt_c) {
     const int buf = q & 1;
-    if (q + 1 < nchunks) load_chunk(mbeg + (q + 1) * BKP);
+    if (q + 2 < nchunks) load_chunk(mbeg + (q + 2) * BKP, cur_c);
     const float* As = smem + buf * STAGE + lhalf * AST + wm * WTM + l31;
     const float* Bs = smem + buf * STAGE + BKP * AST + lhalf * BST + wn * WTN + l31;
     // operands of 4 k-steps (8 rows) per group, double-buffered in registers
@@ -413,12 +466,16 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s][i], fb[cur][s][j], acc[i][j], 0, 0, 0);
     }
-    if (q + 1 < nchunks) store_chunk(buf ^ 1);
+    if (q + 1 < nchunks) store_chunk(buf ^ 1, nxt_c);
     __syncthreads();
+  };
+  for (int q = 0; q < nchunks; q += 2) {
+    step(q, S0{}, S1{});
+    if (q + 1 < nchunks) step(q + 1, S1{}, S0{});
   }
 
   const int N = plan->N;
-  float* out = partial + (((long)blockIdx.z * gridDim.y + blockIdx.y) * T.RT + rt) * BR * N;
+  float* out = partial + (((long)bz * T.nsplit + by) * T.RT + rt) * BR * N;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -446,6 +503,6 @@ __global__ void k_wgrad_reduce(const RdPlan* __restrict__ plan, const float* __r
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const float* p = pbase + (long)R * N + n;
     for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(p + k * stride);
-    *(f32x4*)(dW + P.w_off + ((long)P.tap_w[tap] * plan->w_rows_per_tap + c) * ldw + n) = s;
+    *(f32x4*)(dW + P.w_off + ((long)P.tap[tap].w * plan->w_rows_per_tap + c) * ldw + n) = s;
   }
 }

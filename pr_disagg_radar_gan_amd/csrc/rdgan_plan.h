@@ -10,6 +10,8 @@
 #define RD_MAX_TAPS 64
 #define RD_MAX_PHASES 8
 
+struct RdTap { int mask, delta, w, code; };
+
 struct RdPhase {
   int L, LD, LH, LW;           // rows per sample and loop extents
   int s_mul[3];
@@ -17,11 +19,13 @@ struct RdPhase {
   int ntaps;
   int w_off;                   // element offset added to W for this phase
   int tab;                     // first entry of this phase's row table in RdPlan::tab
-  int8_t tap_off[RD_MAX_TAPS][4];   // per-axis source offset of the tap, each in [-1, 2]
-  int tap_w[RD_MAX_TAPS];      // weight row block = tap_w * w_rows_per_tap (int32: scalar-loadable)
-  int tap_delta[RD_MAX_TAPS];  // s_shift == 0: element offset of the tap relative to the row base
-  int tap_mask[RD_MAX_TAPS];   // validity bits the tap needs: bit (axis*4 + off + 1) per axis
-  int tap_code[RD_MAX_TAPS];   // s_shift == 1: the three 2-bit-code shift amounts, packed sd | sh<<8 | sw<<16
+  int8_t tap_off[RD_MAX_TAPS][4];   // per-axis source offset of the tap, each in [-1, 2] (host side only)
+  // per-tap scalars, one 16-byte scalar load per K chunk:
+  //   x = validity bits the tap needs: bit (axis*4 + off + 1) per axis
+  //   y = s_shift == 0: BYTE offset of the tap relative to the row base
+  //   z = weight row block: W rows start at z * w_rows_per_tap
+  //   w = s_shift == 1: the three 2-bit-code shift amounts, packed sd | sh<<8 | sw<<16
+  RdTap tap[RD_MAX_TAPS];
 };
 
 // Row table entry (one per row l of a sample, per phase), built on the host at plan time:
