@@ -450,13 +450,17 @@ static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>(
 // out[c] = sum over rows of src[rows][C]
 static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, float* out, hipStream_t st) {
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-  long nblk = std::min<long>(1024, std::max<long>(1, rows / 64));
+  long nblk = std::min<long>(1024, std::max<long>(1, rows / 32));
   if ((size_t)nblk * C > h->cpartial_cap) nblk = std::max<long>(1, (long)(h->cpartial_cap / C));
   long rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
-  int threads = std::max(64, std::min(256, (C + 63) / 64 * 64));
-  hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)nblk), dim3(threads), 0, st, src, rows, C, h->cpartial, rpb);
-  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 255) / 256), dim3(256), 0, st, h->cpartial, (int)nblk, C, out);
+  dim3 grid((unsigned)nblk);
+  if (C == 64) hipLaunchKernelGGL(k_colsum_partial<16>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
+  else if (C == 128) hipLaunchKernelGGL(k_colsum_partial<32>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
+  else if (C == 256) hipLaunchKernelGGL(k_colsum_partial<64>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
+  else hipLaunchKernelGGL(k_colsum_partial_any, grid, dim3(std::max(64, std::min(256, (C + 63) / 64 * 64))), 0, st, src, rows, C,
+                          h->cpartial, rpb);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 63) / 64), dim3(256), 0, st, h->cpartial, (int)nblk, C, out);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -880,7 +884,7 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
   }
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_critic_dense_wgrad, dim3((h->F + 255) / 256), dim3(256), 0, st, h->dh[4], grad + h->doff[8], NBt,
+    hipLaunchKernelGGL(k_critic_dense_wgrad, dim3((h->F + 63) / 64), dim3(256), 0, st, h->dh[4], grad + h->doff[8], NBt,
                        h->F, B);
     RD_CHECK(h, hipMemsetAsync(grad + h->doff[9], 0, sizeof(float), st));   // sum of dv over real|fake = 0
     RD_CHECK(h, hipMemsetAsync(grad + h->n_critic, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));

@@ -294,18 +294,49 @@ __global__ void k_critic_top_bwd(const float* __restrict__ h4, const float* __re
   }
 }
 
-// dW6[i] = sum_b buf[b][i] * dv(b) over the 3B batch whose last third holds r4
-__global__ void k_critic_dense_wgrad(const float* __restrict__ buf, float* __restrict__ dw, int NB, int F, int B) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= F) return;
+// dW6[i] = sum_b buf[b][i] * dv(b) over the 3B batch whose last third holds r4;
+// block = 64 columns x 4 sample groups
+__global__ void __launch_bounds__(256)
+k_critic_dense_wgrad(const float* __restrict__ buf, float* __restrict__ dw, int NB, int F, int B) {
+  __shared__ float red[256];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   float s = 0.f;
-  for (int b = 0; b < NB; ++b) s += buf[(long)b * F + i] * rd_dv(b, B, 0);
-  dw[i] = s;
+  if (i < F)
+    for (int b = g; b < NB; b += 4) s += buf[(long)b * F + i] * rd_dv(b, B, 0);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && i < F) dw[i] = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
 }
 
-// column sums of rows [0,rows) of a [rows][C] matrix: stage 1 writes partial[blk][C]
-__global__ void k_colsum_partial(const float* __restrict__ src, long rows, int C, float* __restrict__ partial,
-                                 long rows_per_blk) {
+// column sums of rows [0,rows) of a [rows][C] matrix, two deterministic stages.
+// stage 1: CG = C/4 float4 column groups x RG = 256/CG row groups per block; each thread streams float4s
+// down its rows, the row groups are folded through LDS, and partial[blk][C] is written.
+template <int CG>
+__global__ void __launch_bounds__(256)
+k_colsum_partial(const float* __restrict__ src, long rows, float* __restrict__ partial, long rows_per_blk) {
+  constexpr int RG = 256 / CG, C = CG * 4;
+  __shared__ f32x4 red[256];
+  const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
+  const long r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  long r = r0 + rg;
+  for (; r + RG < r1; r += 2 * RG) {            // two independent chains to keep loads in flight
+    s0 += *(const f32x4*)(src + r * C + cg * 4);
+    s1 += *(const f32x4*)(src + (r + RG) * C + cg * 4);
+  }
+  if (r < r1) s0 += *(const f32x4*)(src + r * C + cg * 4);
+  red[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (rg == 0) {
+    f32x4 t = red[cg];
+#pragma unroll 4
+    for (int k = 1; k < RG; ++k) t += red[k * CG + cg];
+    *(f32x4*)(partial + (long)blockIdx.x * C + cg * 4) = t;
+  }
+}
+// generic (any C): one thread per column, used for the few wide-and-short cases (Dense bias: 256 x 3072)
+__global__ void k_colsum_partial_any(const float* __restrict__ src, long rows, int C, float* __restrict__ partial,
+                                     long rows_per_blk) {
   const long r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
@@ -313,12 +344,20 @@ __global__ void k_colsum_partial(const float* __restrict__ src, long rows, int C
     partial[(long)blockIdx.x * C + c] = s;
   }
 }
-__global__ void k_reduce_partials(const float* __restrict__ partial, int nsplit, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + i];
-  out[i] = s;
+// stage 2: out[c] = sum_k partial[k][c]; block = 64 columns x 4 partial groups
+__global__ void __launch_bounds__(256)
+k_reduce_partials(const float* __restrict__ partial, int nsplit, int n, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < n) {
+    int k = g;
+    for (; k + 4 < nsplit; k += 8) { s0 += partial[(long)k * n + c]; s1 += partial[(long)(k + 4) * n + c]; }
+    if (k < nsplit) s0 += partial[(long)k * n + c];
+  }
+  red[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && c < n) out[c] = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
 }
 
 // col2im of the D1 input gradient restricted to the sample channel (channel 0):

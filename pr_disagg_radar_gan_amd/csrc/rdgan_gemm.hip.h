@@ -216,6 +216,9 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
         for (int j = 0; j < TN; ++j) fb[slot][s][j] = Bs[(j8 * 8 + s) * BST + j * 32];
     };
     load_frag(0, 0);
+#ifdef RD_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int j8 = 0; j8 < NJ; ++j8) {
       const int cur = j8 & 1;
@@ -228,6 +231,9 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][s][j], acc[i][j], 0, 0, 0);
     }
+#ifdef RD_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (q + 1 < nchunks) store_chunk(buf ^ 1, nxt_c);
     __syncthreads();
   };
