@@ -313,7 +313,7 @@ static long plan_tiles(const RdPlan& p, int B, int BM) {
 template <int BM, int BN, int WM, int WN, int BK, bool PARTIAL, bool SHIFT>
 static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                            const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
-  constexpr int AST = BK + 4, BST = BN + 4;
+  constexpr int AST = BK == 32 ? BK : BK + 4, BST = BN;
   constexpr size_t lds = 2 * (size_t)(BM * AST + BK * BST) * sizeof(float);
   static bool attr_done = false;
   auto kern = k_conv_gemm<BM, BN, WM, WN, BK, PARTIAL, SHIFT>;
@@ -352,6 +352,8 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
   } while (0)
   if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200) RD_CONV(128, 128, 2, 2);
   if (hp.N % 64 == 0) {
+    // N = 64 layers with plenty of rows: 256-row tile so every wave owns a 64x64 tile (64 MFMAs per barrier)
+    if (hp.N == 64 && plan_tiles(hp, B, 256) >= 1024) RD_CONV(256, 64, 4, 1);
     if (plan_tiles(hp, B, 128) * (hp.N / 64) >= 200) RD_CONV(128, 64, 2, 2);
     RD_CONV(64, 64, 2, 2);
   }
@@ -368,6 +370,7 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   const RdPhase& q = p.ph[0];
   BR = p.SC >= 128 ? 128 : 64;
   BN = (p.N % 128 == 0) ? 128 : 64;
+  if (BN == 64 && p.SC == 128 && q.ntaps % 2 == 0 && (long)B * q.L >= 65536) BR = 256;   // two taps per tile, 4 accumulators per wave
   if (p.SC >= BR) {
     T.tiles_per_tap = (p.SC + BR - 1) / BR; T.cw = BR; T.taps_per_tile = 1; T.RT = q.ntaps * T.tiles_per_tap;
   } else {
@@ -391,7 +394,7 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
 template <int BR, int BN, bool PARTIAL, bool SHIFT>
 static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int B, const float* src, const float* dy,
                             float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
-  constexpr size_t lds = 2 * (size_t)(32 * (BR + 4) + 32 * (BN + 4)) * sizeof(float);
+  constexpr size_t lds = 2 * (size_t)(32 * BR + 32 * BN) * sizeof(float);
   static bool attr_done = false;
   auto kern = k_wgrad_gemm<BR, BN, PARTIAL, SHIFT>;
   if (!attr_done) {
@@ -427,6 +430,7 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   } while (0)
   float* partial_buf = partial_ws;
   if (partial) RD_TRY((launch_wgrad_cfg<64, 64, true, false>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  else if (BR == 256) RD_WG(256, 64);
   else if (BR == 128 && BN == 128) RD_WG(128, 128);
   else if (BR == 128) RD_WG(128, 64);
   else if (BN == 128) RD_WG(64, 128);

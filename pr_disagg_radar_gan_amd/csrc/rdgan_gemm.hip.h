@@ -64,8 +64,11 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   static_assert(WM * WN == 4, "4 waves");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
-  constexpr int AST = BK + 4;                 // b128 fragment reads conflict-free (stride 36 / 12 dwords)
-  constexpr int BST = BN + 4;
+  // A image in LDS: BK = 32 -> unpadded 128-byte rows whose 16-byte chunk c sits at c ^ ((row >> 1) & 7), which
+  // makes the b128 fragment reads of every 16-lane group conflict-free; BK = 8 -> rows padded to 12 dwords.
+  constexpr bool SWZ = BK == 32;
+  constexpr int AST = SWZ ? BK : BK + 4;
+  constexpr int BST = BN;                     // B rows are read 32 consecutive floats at a time: no padding needed
   constexpr int A_F4 = BK / 4, A_RPP = 256 / A_F4, A_P = (BM + A_RPP - 1) / A_RPP;
   constexpr int B_F4 = BN / 4, B_RPP = 256 / B_F4, B_P = (BK + B_RPP - 1) / B_RPP;
   constexpr int STAGE = BM * AST + BK * BST;
@@ -131,10 +134,10 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   int ld_tap = 0, ld_cc = 0;
   RdTap ti = P.tap[0];
 
-  // two register sets: the gather of chunk q+2 is in flight while chunk q is multiplied and chunk q+1 sits in LDS
-  f32x4 ra[2][A_P], rw[2][B_P];
-  auto load_chunk = [&](auto slot_c) {
-    constexpr int slot = decltype(slot_c)::value;
+  // one register set: the gather of chunk q+1 is in flight while chunk q is multiplied (a second set, i.e. a
+  // distance-2 prefetch, measured no gain: the per-chunk cost is issue/barrier structure, not load latency)
+  f32x4 ra[A_P], rw[B_P];
+  auto load_chunk = [&]() {
     const int tmask = ti.mask;
     const int c = ld_cc * BK + a_c4;
     const bool c_ok = c < SC;
@@ -154,32 +157,33 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
         if (c + 2 >= SC) v.z = 0.f;
         if (c + 3 >= SC) v.w = 0.f;
       }
-      ra[slot][i] = v;
+      ra[i] = v;
     }
     const int sB = (ti.w * wrpt + ld_cc * BK) * ldw * 4;
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int kk = b_kk + i * B_RPP;
       bool ok = (BK % B_RPP == 0 || kk < BK) && ld_cc * BK + kk < SC;
-      rw[slot][i] = rd_buf_load4(rsB, ok ? (unsigned)(boff[i] + sB) : RD_OOB);
+      rw[i] = rd_buf_load4(rsB, ok ? (unsigned)(boff[i] + sB) : RD_OOB);
     }
     // advance to the next chunk and fetch its tap descriptor (consumed by the next call)
     if (++ld_tap == ntaps) { ld_tap = 0; ++ld_cc; }
     ti = P.tap[ld_tap];
   };
-  auto store_chunk = [&](int buf, auto slot_c) {
-    constexpr int slot = decltype(slot_c)::value;
+  // LDS write offset of this thread's A chunk; A_RPP is a multiple of 16, so the swizzle term is the same for all i
+  const int a_wr = SWZ ? (((tid % A_F4) ^ (((tid / A_F4) >> 1) & 7)) * 4) : a_c4;
+  auto store_chunk = [&](int buf) {
     float* As = smem + buf * STAGE;
     float* Bs = As + BM * AST;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       int r = tid / A_F4 + i * A_RPP;
-      if (BM % A_RPP == 0 || r < BM) *(f32x4*)&As[r * AST + a_c4] = ra[slot][i];
+      if (BM % A_RPP == 0 || r < BM) *(f32x4*)&As[r * AST + a_wr] = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int kk = b_kk + i * B_RPP;
-      if (BK % B_RPP == 0 || kk < BK) *(f32x4*)&Bs[kk * BST + b_n4] = rw[slot][i];
+      if (BK % B_RPP == 0 || kk < BK) *(f32x4*)&Bs[kk * BST + b_n4] = rw[i];
     }
   };
 
@@ -191,34 +195,30 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  load_chunk(S0{});
-  if (nchunks > 1) load_chunk(S1{});
-  store_chunk(0, S0{});
+  // swizzled fragment read offsets (floats) of this lane for the logical chunks 2*j8 + lhalf
+  const int a_sw = (l31 >> 1) & 7;
+  load_chunk();
+  store_chunk(0);
   __syncthreads();
-  auto step = [&](int q, auto cur_c, auto nxt_c) {
-    // chunk q: LDS buffer q&1; registers `cur` are free (chunk q was stored last step), `nxt` hold chunk q+1
+  for (int q = 0; q < nchunks; ++q) {
     const int buf = q & 1;
-    if (q + 2 < nchunks) load_chunk(cur_c);
-    const float* As = smem + buf * STAGE + (wm * WTM + l31) * AST + lhalf * 4;
+    if (q + 1 < nchunks) load_chunk();
+    const float* As = smem + buf * STAGE + (wm * WTM + l31) * AST;
     const float* Bs = smem + buf * STAGE + BM * AST + lhalf * 4 * BST + wn * WTN + l31;
     // LDS fragments double-buffered in registers: the reads of k-group j8+1 are issued before the MFMAs of j8
     constexpr int NJ = BK / 8;
     f32x4 fa[2][TM];
     float fb[2][4][TN];
     auto load_frag = [&](int slot, int j8) {
+      const int acol = SWZ ? (((j8 * 2 + lhalf) ^ a_sw) * 4) : (j8 * 8 + lhalf * 4);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[slot][i] = *(const f32x4*)&As[i * 32 * AST + j8 * 8];
+      for (int i = 0; i < TM; ++i) fa[slot][i] = *(const f32x4*)&As[i * 32 * AST + acol];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[slot][s][j] = Bs[(j8 * 8 + s) * BST + j * 32];
     };
     load_frag(0, 0);
-#ifdef RD_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int j8 = 0; j8 < NJ; ++j8) {
       const int cur = j8 & 1;
@@ -231,15 +231,8 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][s][j], acc[i][j], 0, 0, 0);
     }
-#ifdef RD_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    if (q + 1 < nchunks) store_chunk(buf ^ 1, nxt_c);
+    if (q + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();
-  };
-  for (int q = 0; q < nchunks; q += 2) {
-    step(q, S0{}, S1{});
-    if (q + 1 < nchunks) step(q + 1, S1{}, S0{});
   }
 
   // ---- epilogue
@@ -310,7 +303,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
              const float* __restrict__ dy, float* __restrict__ partial, RdWgradTiling T) {
   constexpr int BKP = 32;
   constexpr int WTM = BR / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
-  constexpr int AST = BR + 4, BST = BN + 4;
+  constexpr int AST = BR, BST = BN;          // operands are read 32 consecutive floats at a time: no padding needed
   constexpr int A_F4 = BR / 4, A_PPP = 256 / A_F4, A_P = BKP / A_PPP;   // positions per pass
   constexpr int B_F4 = BN / 4, B_PPP = 256 / B_F4, B_P = BKP / B_PPP;
   constexpr int STAGE = BKP * AST + BKP * BST;
@@ -373,9 +366,8 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   };
   fetch_rows();
 
-  f32x4 ra[2][A_P], rg[2][B_P];
-  auto load_chunk = [&](int mb, auto slot_c) {
-    constexpr int slot = decltype(slot_c)::value;
+  f32x4 ra[A_P], rg[B_P];
+  auto load_chunk = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       int m = mb + tid / A_F4 + i * A_PPP;
@@ -392,13 +384,13 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
         if (a_c + 2 >= SC) v.z = 0.f;
         if (a_c + 3 >= SC) v.w = 0.f;
       }
-      ra[slot][i] = v;
+      ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int m = mb + tid / B_F4 + i * B_PPP;
       unsigned voff = m < mend ? (unsigned)((gb[i] * dsample + ez[i]) * 4 + b_const) : RD_OOB;
-      rg[slot][i] = rd_buf_load4(rsB, voff);
+      rg[i] = rd_buf_load4(rsB, voff);
     }
     // advance the cursors by one chunk (BKP rows)
 #pragma unroll
@@ -415,14 +407,13 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
     }
     fetch_rows();        // al/gl < L always, so the table reads stay in range even past the last chunk
   };
-  auto store_chunk = [&](int buf, auto slot_c) {
-    constexpr int slot = decltype(slot_c)::value;
+  auto store_chunk = [&](int buf) {
     float* As = smem + buf * STAGE;
     float* Bs = As + BKP * AST;
 #pragma unroll
-    for (int i = 0; i < A_P; ++i) *(f32x4*)&As[(tid / A_F4 + i * A_PPP) * AST + a_r] = ra[slot][i];
+    for (int i = 0; i < A_P; ++i) *(f32x4*)&As[(tid / A_F4 + i * A_PPP) * AST + a_r] = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_P; ++i) *(f32x4*)&Bs[(tid / B_F4 + i * B_PPP) * BST + (tid % B_F4) * 4] = rg[slot][i];
+    for (int i = 0; i < B_P; ++i) *(f32x4*)&Bs[(tid / B_F4 + i * B_PPP) * BST + (tid % B_F4) * 4] = rg[i];
   };
 
   f32x16 acc[TM][TN];
@@ -434,17 +425,14 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = (mend - mbeg + BKP - 1) / BKP;
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
   if (nchunks > 0) {
-    load_chunk(mbeg, S0{});                 // the row cursors advance one chunk per call: calls must stay in order
-    if (nchunks > 1) load_chunk(mbeg + BKP, S1{});
-    store_chunk(0, S0{});
+    load_chunk(mbeg);                       // the row cursors advance one chunk per call: calls must stay in order
+    store_chunk(0);
   }
   __syncthreads();
-  auto step = [&](int q, auto cur_c, auto nxt_c) {
+  for (int q = 0; q < nchunks; ++q) {
     const int buf = q & 1;
-    if (q + 2 < nchunks) load_chunk(mbeg + (q + 2) * BKP, cur_c);
+    if (q + 1 < nchunks) load_chunk(mbeg + (q + 1) * BKP);
     const float* As = smem + buf * STAGE + lhalf * AST + wm * WTM + l31;
     const float* Bs = smem + buf * STAGE + BKP * AST + lhalf * BST + wn * WTN + l31;
     // operands of 4 k-steps (8 rows) per group, double-buffered in registers
@@ -472,12 +460,8 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s][i], fb[cur][s][j], acc[i][j], 0, 0, 0);
     }
-    if (q + 1 < nchunks) store_chunk(buf ^ 1, nxt_c);
+    if (q + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();
-  };
-  for (int q = 0; q < nchunks; q += 2) {
-    step(q, S0{}, S1{});
-    if (q + 1 < nchunks) step(q + 1, S1{}, S0{});
   }
 
   const int N = plan->N;
