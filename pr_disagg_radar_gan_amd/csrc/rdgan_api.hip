@@ -175,6 +175,9 @@ static RdPlan plan_rows(int D, int H, int W, int SC, int cstride, int N, int dcs
 static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
   const int S[3] = {p.SD, p.SH, p.SW};
   const int Dd[3] = {p.DD, p.DH, p.DW};
+  p.interleave = p.nphases > 1;
+  for (int pi = 1; pi < p.nphases; ++pi)
+    if (p.ph[pi].L != p.ph[0].L) p.interleave = 0;
   p.src_sample = (long)p.SD * p.SH * p.SW * p.s_cstride;
   p.dst_sample = (long)p.DD * p.DH * p.DW * p.d_cstride;
   int first = 0;

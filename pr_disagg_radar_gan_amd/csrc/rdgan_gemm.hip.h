@@ -84,10 +84,15 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
   const int ntile = swz % NTn;
   int mt = swz / NTn, pidx = 0;
-  for (int p = 0; p < plan->nphases; ++p) {
-    int nt = (B * plan->ph[p].L + BM - 1) / BM;
-    if (mt < nt) { pidx = p; break; }
-    mt -= nt;
+  if (plan->interleave) {
+    pidx = mt % plan->nphases;
+    mt /= plan->nphases;
+  } else {
+    for (int p = 0; p < plan->nphases; ++p) {
+      int nt = (B * plan->ph[p].L + BM - 1) / BM;
+      if (mt < nt) { pidx = p; break; }
+      mt -= nt;
+    }
   }
   const RdPhase& P = plan->ph[pidx];
   const int L = P.L;
@@ -432,7 +437,9 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   __syncthreads();
   for (int q = 0; q < nchunks; ++q) {
     const int buf = q & 1;
+#ifndef RD_ABL_W
     if (q + 1 < nchunks) load_chunk(mbeg + (q + 1) * BKP);
+#endif
     const float* As = smem + buf * STAGE + lhalf * AST + wm * WTM + l31;
     const float* Bs = smem + buf * STAGE + BKP * AST + lhalf * BST + wn * WTN + l31;
     // operands of 4 k-steps (8 rows) per group, double-buffered in registers

@@ -45,7 +45,8 @@ struct RdPlan {
   int DD, DH, DW;              // destination spatial dims
   int d_cstride;               // floats per destination pixel
   int N;                       // GEMM N
-  int pad_;
+  int interleave;              // all phases congruent: tile order is (row tile, phase) with the phase fastest, so
+                               // the phases that re-read the same source rows run together
   long src_sample, dst_sample; // floats per sample of the source / destination tensor
   const RdRow* tab;            // device pointer to the row tables of all phases
   RdPhase ph[RD_MAX_PHASES];

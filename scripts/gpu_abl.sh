@@ -1,5 +1,4 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for l in pr_disagg_radar_gan_amd/librdgan_hip.so scratch/librdgan_abl1.so; do
-  timeout -k 10 120 python scratch/abl.py $PWD/$l 2>&1 | tail -1
-done
+timeout -k 10 120 python scratch/abl.py $PWD/pr_disagg_radar_gan_amd/librdgan_hip.so 2>&1 | tail -1
+timeout -k 10 120 python scratch/abl_w.py $PWD/pr_disagg_radar_gan_amd/librdgan_hip.so 2>&1 | tail -1
