@@ -248,7 +248,7 @@ def _get_trainer(per_rank_batch):
 def train(n_epochs, _batch_size, start_epoch=0, make_plots=False, max_batches_per_epoch=None, save_models=True):
     """reference :431-521: train with a fixed batch size for ``n_epochs``; per iteration n_disc critic
     steps then one generator step; prints the losses, raises ValueError on NaN, appends to ``hist`` and
-    after each epoch writes hist.csv and saves gen_/disc_{params}_{epoch:04d}.h5 (.npz without h5py)."""
+    after each epoch writes hist.csv and saves gen_/disc_{params}_{epoch:04d}.h5 (Keras weight layout)."""
     global batch_size
     import torch
     from .trainer import shard_slice
@@ -301,11 +301,7 @@ def _end_of_epoch(epoch, make_plots, save_models):
     if make_plots:
         _plot_epoch(epoch)
     if save_models:
-        try:
-            import h5py  # noqa: F401
-            ext = 'h5'
-        except ImportError:
-            ext = 'npz'
+        ext = 'h5'
         generator.save(f'{outdir}/gen_{params}_{epoch:04d}.{ext}')                   # reference :520-521
         critic.save(f'{outdir}/disc_{params}_{epoch:04d}.{ext}')
 

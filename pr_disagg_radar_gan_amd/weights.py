@@ -98,7 +98,7 @@ def infer_ndomain_from_gen(arrays):
 
 
 def save_weights(path, arrays, shapes, kind):
-    """.npz container (always available) or Keras-layout .h5 (needs h5py; see h5io)."""
+    """.npz container or Keras-layout .h5 (h5io: h5py when present, else the built-in h5lite)."""
     if path.endswith(".npz"):
         np.savez(path, __kind__=np.array(kind), **{f"{i:02d}:{n}": a for i, ((n, _), a) in enumerate(zip(shapes, arrays))})
         return

@@ -1,0 +1,110 @@
+"""-m gpu: the reference-API mirrors end to end on the HIP engine (BASELINE configs[0] plumbing case and a
+miniature training run), checked against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rdgan_np as onp
+from oracle import rdgan_torch as ot
+from pr_disagg_radar_gan_amd import gan_train_cwgangp_pixelnorm as T
+from pr_disagg_radar_gan_amd import models, weights as W
+from pr_disagg_radar_gan_amd import raindisagg_gan_pretrained as P
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generate_scenarios_example_case(tmp_path, monkeypatch):
+    """example.py: 10 scenarios for cond = 10 mm/day everywhere, through a Keras-layout .h5 on disk."""
+    rng = np.random.default_rng(3)
+    g = W.init_generator(rng, 16)
+    path = str(tmp_path / "gen_test_0020.h5")
+    models.Generator(g, 16).save(path)
+    monkeypatch.setattr(P, "generator_file", path)
+    monkeypatch.setattr(P, "gen", P._LazyGenerator())
+    cond1 = 10 * np.ones((16, 16, 1))
+    np.random.seed(0)
+    sc = P.generate_scenarios(cond1, 10)
+    assert sc.shape == (10, 24, 16, 16) and sc.dtype == np.float64
+    np.testing.assert_allclose(sc.sum(axis=1), 10.0, rtol=1e-5)          # every scenario sums to the daily total
+    np.random.seed(0)
+    ref = onp.generate_scenarios([a.astype(np.float64) for a in g], cond1, 10)
+    np.testing.assert_allclose(sc, ref, rtol=1e-4, atol=1e-7)            # north_star tolerance
+    assert P.latent_dim == 100 and P.gen.inputs[0].shape[1] == 100
+
+
+def test_predict_batches_and_critic_predict():
+    rng = np.random.default_rng(4)
+    gen = models.Generator(W.init_generator(rng, 16), 16)
+    crit = models.Critic(W.init_critic(rng, 16), 16)
+    x, cond, z = ot.synthetic_batch(7, 16, 11)
+    full = gen.predict([z, cond])
+    parts = gen.predict([z, cond], batch_size=3)                          # ragged chunks 3+3+1
+    np.testing.assert_allclose(full, parts, rtol=1e-6, atol=1e-9)
+    v = crit.predict([full, cond])
+    ref = ot.critic_forward([torch.from_numpy(a).double() for a in crit.get_weights()], torch.from_numpy(full).double(),
+                            torch.from_numpy(cond).double(), None).numpy()
+    np.testing.assert_allclose(v, ref, rtol=1e-4, atol=1e-6)
+
+
+def test_train_mirror_runs_and_matches_oracle(tmp_path, monkeypatch):
+    """Two iterations of T.train (n_disc critic steps + 1 generator step each) on synthetic tiles; the weights
+    after training equal an oracle replay that is fed the same batches and step seeds."""
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(0)
+    data = (rng.gamma(0.3, 2.0, (4, 24, 32, 32)).astype(np.float32) + 1e-3)
+    idx = [(t, y, x) for t in range(4) for y in (0, 16) for x in (0, 16)]
+    T.configure(ndomain=16, n_disc=2)
+    T.use_arrays(data, idx)
+    T.build_networks(seed=5)
+    g0, d0 = T.generator.get_weights(), T.critic.get_weights()
+    T.hist["d_loss"].clear(); T.hist["g_loss"].clear()
+
+    # record what train() feeds the engine
+    from pr_disagg_radar_gan_amd import trainer as TR
+    calls = []
+    orig_c, orig_g = TR.WGANGPTrainer.critic_step, TR.WGANGPTrainer.gen_step
+
+    def rec_c(self, x, c, z, seed=None):
+        seed = self._next_seed() if seed is None else seed
+        calls.append(("c", x.cpu().numpy(), c.cpu().numpy(), z.cpu().numpy(), seed))
+        return orig_c(self, x, c, z, seed)
+
+    def rec_g(self, z, c, seed=None):
+        seed = self._next_seed() if seed is None else seed
+        calls.append(("g", z.cpu().numpy(), c.cpu().numpy(), seed))
+        return orig_g(self, z, c, seed)
+
+    monkeypatch.setattr(TR.WGANGPTrainer, "critic_step", rec_c)
+    monkeypatch.setattr(TR.WGANGPTrainer, "gen_step", rec_g)
+    np.random.seed(1)
+    hist = T.train(1, 4, max_batches_per_epoch=2)
+    assert len(hist["d_loss"]) == 2 and np.all(np.isfinite(hist["d_loss"])) and np.all(np.isfinite(hist["g_loss"]))
+    assert [c[0] for c in calls] == ["c", "c", "g", "c", "c", "g"]        # T:468-482
+    assert os.path.exists("hist.csv")
+    saved = [f for f in os.listdir(T.outdir) if f.startswith("gen_") and f.endswith("_0001.h5")]
+    assert saved, os.listdir(T.outdir)
+    g1 = T.generator.get_weights()
+    assert all(np.array_equal(a, b) for a, b in zip(g1, W.load_weights(os.path.join(T.outdir, saved[0]))))
+
+    # oracle replay (fp32 torch, same Adam, shared iteration counter)
+    tr = ot.Trainer(16, seed=0)
+    tr.gp = [torch.from_numpy(a.copy()) for a in g0]; tr.dp = [torch.from_numpy(a.copy()) for a in d0]
+    tr.gv = [torch.zeros_like(p) for p in tr.gp]; tr.dv = [torch.zeros_like(p) for p in tr.dp]
+    for c in calls:
+        if c[0] == "c":
+            tr.critic_step(torch.from_numpy(c[1]), torch.from_numpy(c[2]), torch.from_numpy(c[3]), c[4])
+        else:
+            tr.gen_step(torch.from_numpy(c[1]), torch.from_numpy(c[2]), c[3])
+    assert tr.t == 6
+    # Adam's first steps move every weight by ~lr regardless of gradient size, so compare the UPDATE directions
+    for name, new, old, ref in (("gen", g1, g0, tr.gp), ("critic", T.critic.get_weights(), d0, tr.dp)):
+        for a, o, r in zip(new, old, ref):
+            da, dr = a - o, r.numpy() - o
+            if np.abs(dr).max() == 0:
+                continue
+            big = np.abs(dr) > 0.5 * np.abs(dr).max()
+            assert np.mean(np.sign(da[big]) == np.sign(dr[big])) > 0.99, name
+            assert abs(np.abs(da).max() - np.abs(dr).max()) <= 0.05 * np.abs(dr).max() + 1e-7, name
+    T.configure(n_disc=5)

@@ -63,14 +63,8 @@ def test_weight_layouts_and_containers(tmp_path):
         W.load_weights(str(tmp_path / "missing.h5"))
     with pytest.raises(ValueError):
         models.Generator(g[:-1], 16)
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            W.save_weights(str(tmp_path / "gen.h5"), g, W.gen_param_shapes(16), "generator")
-    else:
-        W.save_weights(str(tmp_path / "gen.h5"), g, W.gen_param_shapes(16), "generator")
-        assert all(np.array_equal(a, b) for a, b in zip(g, W.load_weights(str(tmp_path / "gen.h5"))))
+    W.save_weights(str(tmp_path / "gen.h5"), g, W.gen_param_shapes(16), "generator")    # dependency-free h5lite writer
+    assert all(np.array_equal(a, b) for a, b in zip(g, W.load_weights(str(tmp_path / "gen.h5"))))
 
 
 class _FakeGen:
