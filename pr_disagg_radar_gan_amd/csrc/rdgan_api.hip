@@ -258,8 +258,8 @@ struct rdgan_handle {
   size_t ws_bytes = 0;
   float *xcat, *h0, *h1, *r1, *h2, *r2, *h3, *r3, *P9, *fake, *dl, *gh3, *gup3, *dy2, *gup2, *dy1, *gup1, *ga0;
   float *cin, *dh[5], *du[5], *v, *P1, *g0, *gpv;
-  float *wpartial, *cpartial;
-  size_t wpartial_cap = 0, cpartial_cap = 0;
+  float *wpartial, *cpartial, *kpartial;
+  size_t wpartial_cap = 0, cpartial_cap = 0, kpartial_cap = 0;
   float *DWT[5], *W1T, *GWT[4], *W9T;
   float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
   int collapse = 1;               // 1: 8-tap collapsed generator blocks (default); 0: direct 27-tap form
@@ -331,8 +331,22 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
     for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
     if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
   }
-  dim3 grid((unsigned)(tm * (hp.N / BN)));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, W, ldw, dst, epi);
+  const long blocks = tm * (hp.N / BN);
+  // split-K for small-M / large-K layers (critic tail, Dense, first generator block): few workgroups, long K loops
+  RdEpi e2 = epi;
+  e2.ksplit = 1; e2.kpart = nullptr; e2.kstride = 0;
+  const long nch = (long)hp.ph[0].ntaps * ((hp.SC + BK - 1) / BK);
+  const long total = (long)B * hp.dst_sample;
+  if (h && blocks < 256 && nch >= 16 && hp.d_cstride == hp.N && hp.N % 4 == 0) {
+    long ks = std::min<long>(std::min<long>(8, 640 / blocks), nch / 4);
+    for (int i = 1; i < hp.nphases; ++i) ks = std::min<long>(ks, (long)hp.ph[i].ntaps * ((hp.SC + BK - 1) / BK) / 2);
+    if (ks >= 2 && (size_t)(ks * total) <= h->kpartial_cap) { e2.ksplit = (int)ks; e2.kpart = h->kpartial; e2.kstride = total; }
+  }
+  dim3 grid((unsigned)blocks, (unsigned)e2.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, W, ldw, dst, e2);
+  if (e2.ksplit > 1)
+    hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)std::min<long>((total / 4 + 255) / 256, 2048)), dim3(256), 0, st, dst,
+                       total, hp.N, e2);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -598,6 +612,12 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
   }
   h->wpartial_cap = wneed;
   h->cpartial_cap = (size_t)1024 * std::max(h->n_nodes, 256);
+  {  // split-K partials: up to 8 copies of the largest small-M destination (critic layers 3/4, Dense, generator block 1)
+    size_t m = std::max<size_t>((size_t)NB * h->dL[3] * 256, (size_t)MB * h->n_nodes);
+    m = std::max<size_t>(m, (size_t)NB * h->dL[2] * 128);
+    m = std::max<size_t>(m, (size_t)MB * h->gpix[1] * 256);
+    h->kpartial_cap = 8 * m;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     size_t off = 0;
     auto carve = [&](float*& p, size_t nfloats) {
@@ -629,6 +649,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     carve(h->gpv, MB);
     carve(h->wpartial, h->wpartial_cap);
     carve(h->cpartial, h->cpartial_cap);
+    carve(h->kpartial, h->kpartial_cap);
     h->DWT[0] = h->DWT[1] = nullptr;
     for (int l = 2; l <= 4; ++l) carve(h->DWT[l], 27L * dch[l - 1] * dch[l]);
     carve(h->W1T, 64 * 64);
@@ -718,6 +739,7 @@ extern "C" int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, lo
 static RdEpi epi_make(int mode, const float* bias = nullptr, const float* aux = nullptr, int use_drop = 0,
                       uint32_t key = 0, uint32_t idx_base = 0) {
   RdEpi e; e.mode = mode; e.use_drop = use_drop; e.key = key; e.idx_base = idx_base; e.bias = bias; e.aux = aux;
+  e.ksplit = 1; e.kpart = nullptr; e.kstride = 0;
   return e;
 }
 

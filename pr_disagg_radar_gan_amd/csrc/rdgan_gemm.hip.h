@@ -131,13 +131,18 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   for (int i = 0; i < B_P; ++i) boff[i] = ((b_kk + i * B_RPP) * ldw + n0 + b_n4) * 4;
 
   const int CPT = (SC + BK - 1) / BK;
-  const int nchunks = ntaps * CPT;
+  // split-K: this workgroup multiplies chunks [q0, q0 + nchunks) of the ntaps*CPT chunks of the K loop
+  const int nch_all = ntaps * CPT;
+  const int ksplit = epi.ksplit > 1 ? epi.ksplit : 1;
+  const int per_split = (nch_all + ksplit - 1) / ksplit;
+  const int q0 = (int)blockIdx.y * per_split;
+  const int nchunks = max(0, min(nch_all, q0 + per_split) - q0);
 
   // K order: channel chunk outer, tap inner (the taps of one chunk re-read the same 128-byte pixel segments of
   // neighbouring rows).  (ld_tap, ld_cc) is the chunk the NEXT load_chunk call fetches; its tap descriptor `ti`
   // was scalar-loaded one call earlier, so no load_chunk waits on a scalar load it has just issued.
-  int ld_tap = 0, ld_cc = 0;
-  RdTap ti = P.tap[0];
+  int ld_cc = q0 / ntaps, ld_tap = q0 - ld_cc * ntaps;
+  RdTap ti = P.tap[ld_tap];
 
   // one register set: the gather of chunk q+1 is in flight while chunk q is multiplied (a second set, i.e. a
   // distance-2 prefetch, measured no gain: the per-chunk cost is issue/barrier structure, not load latency)
@@ -202,8 +207,10 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 
   // swizzled fragment read offsets (floats) of this lane for the logical chunks 2*j8 + lhalf
   const int a_sw = (l31 >> 1) & 7;
-  load_chunk();
-  store_chunk(0);
+  if (nchunks > 0) {
+    load_chunk();
+    store_chunk(0);
+  }
   __syncthreads();
   for (int q = 0; q < nchunks; ++q) {
     const int buf = q & 1;
@@ -258,6 +265,10 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
           const int col = n0 + wn * WTN + j * 32 + l31;
           const long idx = rowbase + col;
           float v = acc[i][j][r];
+          if (ksplit > 1) {
+            epi.kpart[(long)blockIdx.y * epi.kstride + idx] = v;
+            continue;
+          }
           if (mode == RD_EPI_BIAS) {
             v += epi.bias[col];
           } else if (mode == RD_EPI_BIAS_LRELU) {
@@ -274,6 +285,36 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
         }
       }
     }
+  }
+}
+
+// split-K finish: dst[idx] = epilogue(sum_s kpart[s][idx]); the destination is dense with N floats per pixel
+__global__ void k_splitk_finish(float* dst, long total, int N, RdEpi epi) {
+  const int mode = epi.mode;
+  for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total / 4; i4 += (long)gridDim.x * blockDim.x) {
+    const long idx0 = i4 * 4;
+    f32x4 v = *(const f32x4*)(epi.kpart + idx0);
+    for (int s = 1; s < epi.ksplit; ++s) v += *(const f32x4*)(epi.kpart + s * epi.kstride + idx0);
+    const int col0 = (int)(idx0 % N);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long idx = idx0 + e;
+      float x = v[e];
+      if (mode == RD_EPI_BIAS) {
+        x += epi.bias[col0 + e];
+      } else if (mode == RD_EPI_BIAS_LRELU) {
+        x = rd_lrelu(x + epi.bias[col0 + e]);
+      } else if (mode == RD_EPI_BIAS_LRELU_DROP) {
+        x = rd_lrelu(x + epi.bias[col0 + e]);
+        if (epi.use_drop) x *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
+      } else if (mode == RD_EPI_GATE_AUX) {
+        float g = rd_lrelu_slope_from_out(epi.aux[idx]);
+        if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
+        x *= g;
+      }
+      v[e] = x;
+    }
+    *(f32x4*)(dst + idx0) = v;
   }
 }
 

@@ -62,4 +62,9 @@ struct RdEpi {
   uint32_t idx_base;           // added to the flat destination index for the mask counter
   const float* bias;
   const float* aux;            // RD_EPI_GATE_AUX: activation whose sign/mask gates the result
+  // split-K (small-M, large-K layers): gridDim.y = ksplit workgroups share one output tile, each writes its raw
+  // partial sums to kpart[split * kstride + idx]; k_splitk_finish adds them up and applies the epilogue
+  int ksplit;
+  float* kpart;
+  long kstride;
 };
