@@ -317,7 +317,14 @@ template <int BM, int BN, int WM, int WN, int BK, bool PARTIAL, bool SHIFT>
 static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                            const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
   constexpr int AST = BK == 32 ? BK : BK + 4, BST = BN;
-  constexpr size_t lds = 2 * (size_t)(BM * AST + BK * BST) * sizeof(float);
+#ifdef RD_ONE_BLOCK_PER_CU
+  constexpr size_t lds = 150 * 1024;      // diagnostic build: one workgroup per CU (no partner wave on a SIMD)
+#else
+  // the BK = 32 kernels reuse the staging LDS for the output tile + BM row bases in the epilogue
+  constexpr size_t lds_loop = 2 * (size_t)(BM * AST + BK * BST) * sizeof(float);
+  constexpr size_t lds_epi = BK == 32 ? ((size_t)BM * BN * sizeof(float) + (size_t)BM * 8) : 0;
+  constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+#endif
   static bool attr_done = false;
   auto kern = k_conv_gemm<BM, BN, WM, WN, BK, PARTIAL, SHIFT>;
   if (!attr_done) {
@@ -370,7 +377,10 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
   if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200) RD_CONV(128, 128, 2, 2);
   if (hp.N % 64 == 0) {
     // N = 64 layers with plenty of rows: 256-row tile so every wave owns a 64x64 tile (64 MFMAs per barrier)
-    if (hp.N == 64 && plan_tiles(hp, B, 256) >= 1024) RD_CONV(256, 64, 4, 1);
+    if (hp.N == 64 && !shift && plan_tiles(hp, B, 256) >= 1024) {   // (the SHIFT variant of this tile would spill)
+      if (partial) return launch_conv_cfg<256, 64, 4, 1, 32, true, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+      return launch_conv_cfg<256, 64, 4, 1, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    }
     if (plan_tiles(hp, B, 128) * (hp.N / 64) >= 200) RD_CONV(128, 64, 2, 2);
     RD_CONV(64, 64, 2, 2);
   }
@@ -1128,3 +1138,13 @@ extern "C" int rdgan_op_rng(uint64_t seed, uint32_t stream_id, float* mask_out, 
                      mask_out, uniform_out, n);
   return (int)hipStreamSynchronize((hipStream_t)stream);
 }
+
+#ifdef RD_STAMP
+extern "C" int rdgan_debug_stamps(unsigned long long* out, int reset) {
+  unsigned long long z[8] = {0};
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess && out) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(rd_stamp_acc), sizeof(z));
+  if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(rd_stamp_acc), z, sizeof(z));
+  return (int)e;
+}
+#endif

@@ -21,6 +21,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RD_LRELU_ALPHA 0.2f
+#ifndef RD_PRIO_LOAD
+#define RD_PRIO_LOAD 2
+#endif
 #define RD_OOB 0x80000000u            // >= num_records of every descriptor below -> load returns 0
 #define RD_RSRC_BYTES 0x7FFFFFF0u
 
@@ -31,6 +34,14 @@ __device__ __forceinline__ float rd_lrelu_slope_from_out(float h) { return h > 0
 
 __device__ __forceinline__ f32x4 rd_buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+}
+// Gather load with the out-of-image case folded into the offset.  The empty asm pins the selected offset in a
+// VGPR: without it hipcc (ROCm 7.2) turns load(ok ? off : OOB) into two exec-masked loads into the same
+// registers with an s_waitcnt vmcnt(0) between them -- a full memory round trip per gathered row.
+__device__ __forceinline__ f32x4 rd_buf_load4_if(__amdgpu_buffer_rsrc_t rsrc, bool ok, unsigned voff) {
+  unsigned off = ok ? voff : RD_OOB;
+  asm volatile("" : "+v"(off));
+  return rd_buf_load4(rsrc, off);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rd_make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RD_RSRC_BYTES, 0x00020000);
@@ -52,6 +63,18 @@ __device__ __forceinline__ int rd_xcd_swizzle(int lin, int total) {
   return base + idx;
 }
 
+#ifdef RD_STAMP
+// diagnostic build only: per-segment cycle totals of the K loop (never compiled into the shipped library)
+__device__ unsigned long long rd_stamp_acc[8];
+__device__ __forceinline__ unsigned long long rd_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#endif
+
 // ------------------------------------------------------------------------------------
 // C[m][n] = sum_{tap,c} A_gather[m][tap][c] * W[tap_w*wrpt + c][n]  (+ fused epilogue)
 // ------------------------------------------------------------------------------------
@@ -72,12 +95,16 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   constexpr int A_F4 = BK / 4, A_RPP = 256 / A_F4, A_P = (BM + A_RPP - 1) / A_RPP;
   constexpr int B_F4 = BN / 4, B_RPP = 256 / B_F4, B_P = (BK + B_RPP - 1) / B_RPP;
   constexpr int STAGE = BM * AST + BK * BST;
+  constexpr int TG = 8;                       // taps per group whose gather offsets live in registers
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhalf = lane >> 5;
+#ifdef RD_STAMP
+  const unsigned long long st_kernel0 = rd_stamp();
+#endif
 
   // ---- which phase / tile (all wave-uniform); 1-D grid, N tile fastest so both N tiles of an M tile run together
   const int NTn = plan->N / BN;
@@ -131,6 +158,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   for (int i = 0; i < B_P; ++i) boff[i] = ((b_kk + i * B_RPP) * ldw + n0 + b_n4) * 4;
 
   const int CPT = (SC + BK - 1) / BK;
+  const bool k_tail = (SC % BK) != 0;         // the last channel chunk of a tap is partial (Dense 356, column GEMM 27)
   // split-K: this workgroup multiplies chunks [q0, q0 + nchunks) of the ntaps*CPT chunks of the K loop
   const int nch_all = ntaps * CPT;
   const int ksplit = epi.ksplit > 1 ? epi.ksplit : 1;
@@ -138,30 +166,52 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   const int q0 = (int)blockIdx.y * per_split;
   const int nchunks = max(0, min(nch_all, q0 + per_split) - q0);
 
-  // K order: channel chunk outer, tap inner (the taps of one chunk re-read the same 128-byte pixel segments of
-  // neighbouring rows).  (ld_tap, ld_cc) is the chunk the NEXT load_chunk call fetches; its tap descriptor `ti`
-  // was scalar-loaded one call earlier, so no load_chunk waits on a scalar load it has just issued.
-  int ld_cc = q0 / ntaps, ld_tap = q0 - ld_cc * ntaps;
-  RdTap ti = P.tap[ld_tap];
+  // K order: tap group (8 taps) outer, channel chunk, tap inner -- the taps of one chunk re-read the same 128-byte
+  // pixel segments of neighbouring rows.  For the taps of the current group the byte offset of every gathered row
+  // sits in registers with the image-border test already folded in (out-of-image -> an out-of-range offset that the
+  // buffer bounds check turns into zeros), and the channel-chunk offset rides in the load's scalar offset: the hot
+  // loop issues ONE instruction per gathered row.  (In-kernel stamps: with a partner wave streaming 64-cycle MFMAs
+  // on the SIMD every dependent short instruction of the load phase waits for an MFMA slot -- ~100 instructions
+  // cost ~4000 cycles per chunk against 700 alone -- so instruction count is what matters here.)
+  unsigned voffs[A_P][TG];
+  int tapw[TG];
+  auto build_group = [&](int g) {
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      const int tap = min(g * TG + t, ntaps - 1);
+      const RdTap ti = P.tap[tap];
+      tapw[t] = ti.w * wrpt * ldw * 4;
+      const int sd = ti.code & 255, sh_ = (ti.code >> 8) & 255, sw = ti.code >> 16;
+#pragma unroll
+      for (int i = 0; i < A_P; ++i) {
+        int off = roff[i] + (SHIFT ? rd_shift_delta(rcode[i], sd, sh_, sw, SH, SW, cstride) * 4 : ti.delta);
+        voffs[i][t] = ((rbits[i] & ti.mask) == ti.mask) ? (unsigned)off : RD_OOB;
+      }
+    }
+  };
+  // position of the NEXT chunk to load: group, channel chunk, tap inside the group
+  int ld_g, ld_cc, ld_t, ld_gt;
+  {
+    const int full = TG * CPT;
+    ld_g = q0 / full;
+    const int rem = q0 - ld_g * full;
+    ld_gt = min(TG, ntaps - ld_g * TG);
+    ld_cc = ld_gt > 0 ? rem / ld_gt : 0;
+    ld_t = ld_gt > 0 ? rem - ld_cc * ld_gt : 0;
+  }
+  if (nchunks > 0) build_group(ld_g);
 
-  // one register set: the gather of chunk q+1 is in flight while chunk q is multiplied (a second set, i.e. a
-  // distance-2 prefetch, measured no gain: the per-chunk cost is issue/barrier structure, not load latency)
   f32x4 ra[A_P], rw[B_P];
-  auto load_chunk = [&]() {
-    const int tmask = ti.mask;
+  auto issue_loads = [&](auto t_c) {
+    constexpr int t = decltype(t_c)::value;
+    const int sA = ld_cc * BK * 4;
+    const bool tail = k_tail && ld_cc == CPT - 1;
     const int c = ld_cc * BK + a_c4;
-    const bool c_ok = c < SC;
-    const int sdelta = ld_cc * BK * 4 + (SHIFT ? 0 : ti.delta);
-    const int sd = ti.code & 255, sh_ = (ti.code >> 8) & 255, sw = ti.code >> 16;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      unsigned voff = (unsigned)(roff[i] + sdelta);
-      if (SHIFT) voff += (unsigned)(rd_shift_delta(rcode[i], sd, sh_, sw, SH, SW, cstride) * 4);
-      bool ok = c_ok && ((rbits[i] & tmask) == tmask);
-#ifdef RD_ABL_L1
-      voff = (unsigned)(roff[i] & 0x3FFF);     // diagnostic build: every gather hits a 16 KiB window
-#endif
-      f32x4 v = rd_buf_load4(rsA, ok ? voff : RD_OOB);
+      unsigned voff = voffs[i][t];
+      if (tail && c >= SC) voff = RD_OOB;                      // uniform `tail` is false in every hot launch
+      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)voff, sA, 0));
       if (PARTIAL) {
         if (c + 1 >= SC) v.y = 0.f;
         if (c + 2 >= SC) v.z = 0.f;
@@ -169,16 +219,35 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
       }
       ra[i] = v;
     }
-    const int sB = (ti.w * wrpt + ld_cc * BK) * ldw * 4;
+    const int sB = tapw[t] + ld_cc * BK * ldw * 4;
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
-      int kk = b_kk + i * B_RPP;
-      bool ok = (BK % B_RPP == 0 || kk < BK) && ld_cc * BK + kk < SC;
-      rw[i] = rd_buf_load4(rsB, ok ? (unsigned)(boff[i] + sB) : RD_OOB);
+      const int kk = b_kk + i * B_RPP;
+      unsigned voff = (unsigned)boff[i];
+      if ((BK % B_RPP != 0 && kk >= BK) || (tail && ld_cc * BK + kk >= SC)) voff = RD_OOB;
+      rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)voff, sB, 0));
     }
-    // advance to the next chunk and fetch its tap descriptor (consumed by the next call)
-    if (++ld_tap == ntaps) { ld_tap = 0; ++ld_cc; }
-    ti = P.tap[ld_tap];
+  };
+  auto load_chunk = [&]() {
+    switch (ld_t) {                                             // wave-uniform: selects the register column
+      case 0: issue_loads(std::integral_constant<int, 0>{}); break;
+      case 1: issue_loads(std::integral_constant<int, 1>{}); break;
+      case 2: issue_loads(std::integral_constant<int, 2>{}); break;
+      case 3: issue_loads(std::integral_constant<int, 3>{}); break;
+      case 4: issue_loads(std::integral_constant<int, 4>{}); break;
+      case 5: issue_loads(std::integral_constant<int, 5>{}); break;
+      case 6: issue_loads(std::integral_constant<int, 6>{}); break;
+      default: issue_loads(std::integral_constant<int, 7>{}); break;
+    }
+    if (++ld_t == ld_gt) {
+      ld_t = 0;
+      if (++ld_cc == CPT) {
+        ld_cc = 0;
+        ++ld_g;
+        ld_gt = min(TG, ntaps - ld_g * TG);
+        if (ld_gt > 0) build_group(ld_g);                       // once per 8*CPT chunks; never for <= 8 taps
+      }
+    }
   };
   // LDS write offset of this thread's A chunk; A_RPP is a multiple of 16, so the swizzle term is the same for all i
   const int a_wr = SWZ ? (((tid % A_F4) ^ (((tid / A_F4) >> 1) & 7)) * 4) : a_c4;
@@ -212,9 +281,16 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
     store_chunk(0);
   }
   __syncthreads();
+#ifdef RD_STAMP
+  unsigned long long st_load = 0, st_mfma = 0, st_store = 0, st_bar = 0, st_t0 = rd_stamp();
+  const unsigned long long st_begin = st_t0;
+#endif
   for (int q = 0; q < nchunks; ++q) {
     const int buf = q & 1;
     if (q + 1 < nchunks) load_chunk();
+#ifdef RD_STAMP
+    { unsigned long long t = rd_stamp(); st_load += t - st_t0; st_t0 = t; }
+#endif
     const float* As = smem + buf * STAGE + (wm * WTM + l31) * AST;
     const float* Bs = smem + buf * STAGE + BM * AST + lhalf * 4 * BST + wn * WTN + l31;
     // LDS fragments double-buffered in registers: the reads of k-group j8+1 are issued before the MFMAs of j8
@@ -241,15 +317,110 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
+#ifdef RD_MFMA16_TIMING
+          {   // timing-only diagnostic: two 16x16x4 MFMAs (32 cycles each) instead of one 32x32x2 (64 cycles); results are WRONG
+            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+            f32x4_ c0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            f32x4_ c1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i][s], fb[cur][s][j], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i][s], fb[cur][s][j], c1, 0, 0, 0);
+            acc[i][j][0] = c0[0]; acc[i][j][1] = c0[1]; acc[i][j][2] = c0[2]; acc[i][j][3] = c0[3];
+            acc[i][j][4] = c1[0]; acc[i][j][5] = c1[1]; acc[i][j][6] = c1[2]; acc[i][j][7] = c1[3];
+          }
+#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][s][j], acc[i][j], 0, 0, 0);
+#endif
     }
+#ifdef RD_STAMP
+    { unsigned long long t = rd_stamp(); st_mfma += t - st_t0; st_t0 = t; }
+#endif
     if (q + 1 < nchunks) store_chunk(buf ^ 1);
+#ifdef RD_STAMP
+    { unsigned long long t = rd_stamp(); st_store += t - st_t0; st_t0 = t; }
+#endif
     __syncthreads();
+#ifdef RD_STAMP
+    { unsigned long long t = rd_stamp(); st_bar += t - st_t0; st_t0 = t; }
+#endif
   }
+#ifdef RD_STAMP
+  const unsigned long long st_loop_end = st_t0;
+  if (lane == 0 && BM == 256) {
+    atomicAdd(&rd_stamp_acc[6], st_begin - st_kernel0);
+    atomicAdd(&rd_stamp_acc[0], st_load); atomicAdd(&rd_stamp_acc[1], st_mfma); atomicAdd(&rd_stamp_acc[2], st_store);
+    atomicAdd(&rd_stamp_acc[3], st_bar); atomicAdd(&rd_stamp_acc[4], st_t0 - st_begin); atomicAdd(&rd_stamp_acc[5], 1ull);
+  }
+#endif
 
   // ---- epilogue
   const long dsample = plan->dst_sample;
   const int mode = epi.mode;
+  // LDS_EPI: the accumulator tile goes through the (now idle) staging LDS so that every thread stores whole float4s of
+  // one output row: BM*BN/1024 coalesced dwordx4 stores + 1 row-table load per thread instead of 16*TM*TN scalar
+  // stores + 16*TM dependent table loads (VMEM instructions issue slowly beside a partner wave's MFMA stream; stamps
+  // put the scalar epilogue at 21 % of a workgroup's lifetime).
+  constexpr bool LDS_EPI = BK == 32;
+  if constexpr (LDS_EPI) {
+    float* Cs = smem;                                   // [BM][BN]
+    int* Rb = (int*)(smem + BM * BN);                   // [BM][2]: destination row base (floats, 64-bit) or -1
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Cs[row * BN + wn * WTN + j * 32 + l31] = acc[i][j][r];
+      }
+    if (tid < BM) {
+      long rb = -1;
+      if (m0 + tid < rows) {
+        int l = l0 + tid, bb = b0;
+        if (L >= BM) { if (l >= L) { l -= L; bb += 1; } }
+        else { int qd = l / L; l -= qd * L; bb += qd; }
+        rb = (long)bb * dsample + tab[l].z;
+      }
+      Rb[2 * tid] = (int)(rb & 0xFFFFFFFFll); Rb[2 * tid + 1] = (int)(rb >> 32);
+    }
+    __syncthreads();
+    constexpr int F4R = BN / 4;                         // float4s per row; 256 % F4R == 0, so a thread's columns are fixed
+    constexpr int RPP = 256 / F4R;                      // rows per pass
+    const int c4 = (tid % F4R) * 4;
+    const int col = n0 + c4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (ksplit == 1 && (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP))
+      bias4 = *(const f32x4*)(epi.bias + col);
+#pragma unroll 4
+    for (int row = tid / F4R; row < BM; row += RPP) {
+      const long rb = ((long)Rb[2 * row + 1] << 32) | (unsigned)Rb[2 * row];
+      if (rb < 0) continue;
+      const long idx0 = rb + col;
+      f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
+      if (ksplit > 1) {
+        *(f32x4*)(epi.kpart + (long)blockIdx.y * epi.kstride + idx0) = v;
+        continue;
+      }
+      if (mode == RD_EPI_BIAS) {
+        v += bias4;
+      } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
+        v += bias4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = rd_lrelu(v[e]);
+          if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
+          v[e] = x;
+        }
+      } else if (mode == RD_EPI_GATE_AUX) {
+        const f32x4 a4 = *(const f32x4*)(epi.aux + idx0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float g = rd_lrelu_slope_from_out(a4[e]);
+          if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
+          v[e] *= g;
+        }
+      }
+      *(f32x4*)(dst + idx0) = v;
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -286,6 +457,10 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
       }
     }
   }
+  }
+#ifdef RD_STAMP
+  { unsigned long long t = rd_stamp(); if (lane == 0 && BM == 256) atomicAdd(&rd_stamp_acc[7], t - st_loop_end); }
+#endif
 }
 
 // split-K finish: dst[idx] = epilogue(sum_s kpart[s][idx]); the destination is dense with N floats per pixel
@@ -417,14 +592,10 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       int m = mb + tid / A_F4 + i * A_PPP;
-      unsigned voff = RD_OOB;
-      {
-        const RdRow e = ea[i];
-        int off = (ab[i] * ssample + e.x) * 4 + a_const;
-        if (SHIFT) off += rd_shift_delta(e.w, sd, sh_, sw, SH, SW, cstride) * 4;
-        if (m < mend && (e.y & tmask) == tmask) voff = (unsigned)off;
-      }
-      f32x4 v = rd_buf_load4(rsA, voff);
+      const RdRow e = ea[i];
+      int off = (ab[i] * ssample + e.x) * 4 + a_const;
+      if (SHIFT) off += rd_shift_delta(e.w, sd, sh_, sw, SH, SW, cstride) * 4;
+      f32x4 v = rd_buf_load4_if(rsA, m < mend && (e.y & tmask) == tmask, (unsigned)off);
       if (PARTIAL) {
         if (a_c + 1 >= SC) v.y = 0.f;
         if (a_c + 2 >= SC) v.z = 0.f;
@@ -435,8 +606,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int m = mb + tid / B_F4 + i * B_PPP;
-      unsigned voff = m < mend ? (unsigned)((gb[i] * dsample + ez[i]) * 4 + b_const) : RD_OOB;
-      rg[i] = rd_buf_load4(rsB, voff);
+      rg[i] = rd_buf_load4_if(rsB, m < mend, (unsigned)((gb[i] * dsample + ez[i]) * 4 + b_const));
     }
     // advance the cursors by one chunk (BKP rows)
 #pragma unroll
@@ -478,9 +648,9 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   __syncthreads();
   for (int q = 0; q < nchunks; ++q) {
     const int buf = q & 1;
-#ifndef RD_ABL_W
+    __builtin_amdgcn_s_setprio(RD_PRIO_LOAD);          // see k_conv_gemm
     if (q + 1 < nchunks) load_chunk(mbeg + (q + 1) * BKP);
-#endif
+    __builtin_amdgcn_s_setprio(0);
     const float* As = smem + buf * STAGE + lhalf * AST + wm * WTM + l31;
     const float* Bs = smem + buf * STAGE + BKP * AST + lhalf * BST + wn * WTN + l31;
     // operands of 4 k-steps (8 rows) per group, double-buffered in registers
@@ -508,6 +678,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s][i], fb[cur][s][j], acc[i][j], 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(RD_PRIO_LOAD);
     if (q + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();
   }
