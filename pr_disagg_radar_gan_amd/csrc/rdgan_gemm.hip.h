@@ -52,6 +52,18 @@ __device__ __forceinline__ int rd_shift_delta(int w, int sd, int sh_, int sw, in
   return ((dd * SH + dh) * SW + dw) * cstride;
 }
 
+// The row tables are written by the host before any launch and never by a kernel: reading them through the
+// constant address space lets hipcc use scalar loads (s_load) wherever the index is wave-uniform.
+typedef const RdRow __attribute__((address_space(4)))* RdRowTab;
+__device__ __forceinline__ RdRowTab rd_row_tab(const RdPlan* plan, int first) {
+  return (RdRowTab)(unsigned long long)(plan->tab + first);
+}
+__device__ __forceinline__ RdRow rd_row(RdRowTab t, int l) {
+  RdRow e;
+  e.x = t[l].x; e.y = t[l].y; e.z = t[l].z; e.w = t[l].w;
+  return e;
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2).  This bijective remap
 // gives every XCD a contiguous range of the logical tile order, so tiles that share operand rows (halo
 // rows of neighbouring M tiles, the tap tiles of one wgrad split) hit the same L2.  Placement only
@@ -131,7 +143,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   const int cstride = plan->s_cstride, SC = plan->SC, wrpt = plan->w_rows_per_tap;
   const int ssample = (int)plan->src_sample;
   const int ntaps = P.ntaps;
-  const RdRow* __restrict__ tab = plan->tab + P.tab;
+  const RdRowTab tab = rd_row_tab(plan, P.tab);
   const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)b0 * plan->src_sample);
   const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(W + P.w_off);
 
@@ -146,7 +158,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
       int l = l0 + r, bb = 0;
       if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
       else { bb = l / L; l -= bb * L; }
-      RdRow e = tab[l];
+      RdRow e = rd_row(tab, l);
       roff[i] = (bb * ssample + e.x + a_c4) * 4;
       rbits[i] = e.y; rcode[i] = e.w;
     }
@@ -547,7 +559,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   const int SH = plan->SH, SW = plan->SW;
   const int cstride = plan->s_cstride, SC = plan->SC;
   const int ssample = (int)plan->src_sample, dsample = (int)plan->dst_sample;
-  const RdRow* __restrict__ tab = plan->tab + P.tab;
+  const RdRowTab tab = rd_row_tab(plan, P.tab);
   // descriptors are based at the first sample this block touches (wave-uniform)
   const int bb0 = mbeg / L;
   const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)bb0 * plan->src_sample);
@@ -568,10 +580,15 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   const int a_const = tdelta + a_c * 4;
   const int b_const = (n0 + (tid % B_F4) * 4) * 4;
 
-  // row cursors (sample index relative to bb0, row inside the sample) of this thread's A and B positions
+  // row cursors (sample index relative to bb0, row inside the sample) of this thread's A and B positions.
+  // With BR = 256 a whole wave gathers the same positions (A_F4 == 64), so the A cursors, the row-table lookups and the
+  // offset arithmetic are wave-uniform: readfirstlane makes that provable and they run on the scalar unit (SMEM/SALU)
+  // instead of costing vector-memory instructions next to the partner wave's MFMA stream.
+  constexpr bool UNI = A_F4 == 64;
+  const int a_pos0 = UNI ? __builtin_amdgcn_readfirstlane(tid / A_F4) : tid / A_F4;
   int ab[A_P], al[A_P], gb[B_P], gl[B_P];
 #pragma unroll
-  for (int i = 0; i < A_P; ++i) { int m = mbeg + tid / A_F4 + i * A_PPP; ab[i] = m / L; al[i] = m - ab[i] * L; ab[i] -= bb0; }
+  for (int i = 0; i < A_P; ++i) { int m = mbeg + a_pos0 + i * A_PPP; ab[i] = m / L; al[i] = m - ab[i] * L; ab[i] -= bb0; }
 #pragma unroll
   for (int i = 0; i < B_P; ++i) { int m = mbeg + tid / B_F4 + i * B_PPP; gb[i] = m / L; gl[i] = m - gb[i] * L; gb[i] -= bb0; }
 
@@ -581,7 +598,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   int ez[B_P];
   auto fetch_rows = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_P; ++i) ea[i] = tab[al[i]];
+    for (int i = 0; i < A_P; ++i) ea[i] = rd_row(tab, al[i]);
 #pragma unroll
     for (int i = 0; i < B_P; ++i) ez[i] = tab[gl[i]].z;
   };
@@ -591,7 +608,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   auto load_chunk = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      int m = mb + tid / A_F4 + i * A_PPP;
+      int m = mb + a_pos0 + i * A_PPP;
       const RdRow e = ea[i];
       int off = (ab[i] * ssample + e.x) * 4 + a_const;
       if (SHIFT) off += rd_shift_delta(e.w, sd, sh_, sw, SH, SW, cstride) * 4;
