@@ -344,7 +344,7 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   e2.ksplit = 1; e2.kpart = nullptr; e2.kstride = 0;
   const long nch = (long)hp.ph[0].ntaps * ((hp.SC + BK - 1) / BK);
   const long total = (long)B * hp.dst_sample;
-  if (h && blocks < 256 && nch >= 16 && hp.d_cstride == hp.N && hp.N % 4 == 0) {
+  if (h && blocks < 256 && nch >= 16 && hp.d_cstride == hp.N && hp.N % 4 == 0 && epi.mode != RD_EPI_BIAS_PN_LRELU) {
     long ks = std::min<long>(std::min<long>(8, 640 / blocks), nch / 4);
     for (int i = 1; i < hp.nphases; ++i) ks = std::min<long>(ks, (long)hp.ph[i].ntaps * ((hp.SC + BK - 1) / BK) / 2);
     if (ks >= 2 && (size_t)(ks * total) <= h->kpartial_cap) { e2.ksplit = (int)ks; e2.kpart = h->kpartial; e2.kstride = total; }
@@ -388,6 +388,14 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
     return launch_conv_cfg<128, 32, 4, 1, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
 #undef RD_CONV
   return bad_arg(h, "conv: unsupported N");
+}
+
+// true when launch_conv will pick a tile whose BN equals the plan's N, i.e. a workgroup owns whole output rows
+static bool conv_rows_owned(const RdPlan& hp, int B) {
+  if (hp.s_shift || (hp.SC & 3) || hp.SC < 32) return false;
+  if (hp.N == 128) return plan_tiles(hp, B, 128) >= 200;
+  if (hp.N == 64) return plan_tiles(hp, B, 256) >= 1024 || plan_tiles(hp, B, 128) >= 200;
+  return false;
 }
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -749,7 +757,7 @@ extern "C" int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, lo
 static RdEpi epi_make(int mode, const float* bias = nullptr, const float* aux = nullptr, int use_drop = 0,
                       uint32_t key = 0, uint32_t idx_base = 0) {
   RdEpi e; e.mode = mode; e.use_drop = use_drop; e.key = key; e.idx_base = idx_base; e.bias = bias; e.aux = aux;
-  e.ksplit = 1; e.kpart = nullptr; e.kstride = 0;
+  e.ksplit = 1; e.kpart = nullptr; e.kstride = 0; e.rinv = nullptr;
   return e;
 }
 
@@ -778,11 +786,15 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       Wl = h->GWC[l];
       pl = PL_G1FC + l - 1;
     }
-    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], Wl, h->gch[l], hs[l],
-                       epi_make(RD_EPI_BIAS, gp + h->goff[2 * l + 1]), st,
+    const bool fuse = conv_rows_owned(h->plans[pl], B);       // PixelNorm+LeakyReLU in the GEMM epilogue
+    RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
+    ep.rinv = rs[l];
+    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], Wl, h->gch[l], hs[l], ep, st,
                        l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
-    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st));
+    if (!fuse) {
+      ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+      RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st));
+    }
   }
   // Conv3D 64->1 (T:345) as column GEMM + gather, bias, Softmax(axis=1) (T:347), check_numerics (T:349-350)
   RD_TRY(launch_conv(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, epi_make(RD_EPI_PLAIN), st, -1));

@@ -399,7 +399,8 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
     const int c4 = (tid % F4R) * 4;
     const int col = n0 + c4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (ksplit == 1 && (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP))
+    if (ksplit == 1 && (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP ||
+                        mode == RD_EPI_BIAS_PN_LRELU))
       bias4 = *(const f32x4*)(epi.bias + col);
 #pragma unroll 4
     for (int row = tid / F4R; row < BM; row += RPP) {
@@ -421,6 +422,16 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
           if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
           v[e] = x;
         }
+      } else if (mode == RD_EPI_BIAS_PN_LRELU) {
+        // PixelNormalization (T:255-266) + LeakyReLU (T:333): the F4R lanes holding this row are an aligned lane group
+        v += bias4;
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+        for (int o = F4R / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float l2 = sqrtf(ss * (1.0f / BN) + 1.0e-8f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rd_lrelu(v[e] / l2);
+        if (c4 == 0 && epi.rinv) epi.rinv[rb / BN] = 1.0f / l2;
       } else if (mode == RD_EPI_GATE_AUX) {
         const f32x4 a4 = *(const f32x4*)(epi.aux + idx0);
 #pragma unroll

@@ -53,7 +53,9 @@ struct RdPlan {
 };
 
 // epilogue modes of the conv GEMM
-enum { RD_EPI_PLAIN = 0, RD_EPI_BIAS = 1, RD_EPI_BIAS_LRELU = 2, RD_EPI_BIAS_LRELU_DROP = 3, RD_EPI_GATE_AUX = 4 };
+// RD_EPI_BIAS_PN_LRELU: bias, PixelNormalization over the N channels of the row, LeakyReLU (needs BN == N)
+enum { RD_EPI_PLAIN = 0, RD_EPI_BIAS = 1, RD_EPI_BIAS_LRELU = 2, RD_EPI_BIAS_LRELU_DROP = 3, RD_EPI_GATE_AUX = 4,
+       RD_EPI_BIAS_PN_LRELU = 5 };
 
 struct RdEpi {
   int mode;
@@ -67,4 +69,5 @@ struct RdEpi {
   int ksplit;
   float* kpart;
   long kstride;
+  float* rinv;                 // RD_EPI_BIAS_PN_LRELU: per-pixel 1/sqrt(mean(y^2)+eps), kept for the backward pass
 };
