@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="samples per GPU per iteration")
     ap.add_argument("--n-critic", type=int, default=N_CRITIC)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ndomain", type=int, default=NDOMAIN, help="16 = BASELINE metric; 64 = large-domain variant (extra data point)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -111,17 +112,18 @@ def main():
         pg = dist.group.WORLD
 
     B = args.batch
-    eng = Engine(ndomain=NDOMAIN, max_batch=B, device=dev)
+    ND = args.ndomain
+    eng = Engine(ndomain=ND, max_batch=B, device=dev)
     rng = np.random.default_rng(0)                  # identical initial weights on every rank
-    trainer = WGANGPTrainer(eng, W.init_generator(rng, NDOMAIN), W.init_critic(rng, NDOMAIN), n_disc=args.n_critic,
+    trainer = WGANGPTrainer(eng, W.init_generator(rng, ND), W.init_critic(rng, ND), n_disc=args.n_critic,
                             process_group=pg, world_size=world, rank=rank, base_seed=1234 + 1000 * 2)
     # synthetic inputs resident in HBM; per-rank seeds 1234 + 1000*config + rank
     nbuf = 4
     data = []
     for i in range(nbuf):
-        crit = [synthetic_batch_device(B, NDOMAIN, 1234 + 2000 + rank + 97 * (i * (args.n_critic + 1) + j), dev)
+        crit = [synthetic_batch_device(B, ND, 1234 + 2000 + rank + 97 * (i * (args.n_critic + 1) + j), dev)
                 for j in range(args.n_critic)]
-        _, c, z = synthetic_batch_device(B, NDOMAIN, 1234 + 2000 + rank + 97 * (i * (args.n_critic + 1) + args.n_critic) + 13, dev)
+        _, c, z = synthetic_batch_device(B, ND, 1234 + 2000 + rank + 97 * (i * (args.n_critic + 1) + args.n_critic) + 13, dev)
         data.append((crit, (z, c)))
 
     def sync():
@@ -157,26 +159,26 @@ def main():
     if rank == 0:
         value = world * B * args.steps / dt
         avg_ms = kern_ms / max(kern_n, 1)
-        achieved = gconv3_flops(B) / (avg_ms * 1e-3) / 1e12 if kern_n else None
-        direct_equiv = gconv3_flops(B, collapsed=False) / (avg_ms * 1e-3) / 1e12 if kern_n else None
+        achieved = gconv3_flops(B, ND) / (avg_ms * 1e-3) / 1e12 if kern_n else None
+        direct_equiv = gconv3_flops(B, ND, collapsed=False) / (avg_ms * 1e-3) / 1e12 if kern_n else None
         out = {
-            "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256",
+            "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256" if ND == 16 else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles (extra data point)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ndomain=16, 24h, bs={B} fp32 per GPU, {args.n_critic} critic step + 1 gen step "
-                                   "(BASELINE configs[1])",
+            "config": {"workload": f"ndomain={ND}, 24h, bs={B} fp32 per GPU, {args.n_critic} critic step + 1 gen step"
+                                   + (" (BASELINE configs[1])" if (ND, B, args.n_critic) == (16, 256, 1) else ""),
                        "global_batch": world * B, "n_critic": args.n_critic, "parallelism": f"dp{world}",
                        "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
             "roofline": {"bound": "mfma", "kernel": "k_conv_gemm<256,64,4,1,32> generator block 3 forward (upsample+Conv3D 128->64, 8-tap collapsed form)",
                          "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
-                         "flops_per_launch": gconv3_flops(B),
+                         "flops_per_launch": gconv3_flops(B, ND),
                          "direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2)},
             "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and ND == 16:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
