@@ -95,6 +95,19 @@ enum {
 int rdgan_profile(rdgan_handle* h, unsigned tag_mask);
 int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, long* launches);
 
+/* Input pipeline either side of the step (device-resident radar array data[n_days][24][ny][nx], fp32).
+ * rdgan_data_gather: the tile gather + normalisation of generate_real_samples / generate_latent_points
+ * (T:149-166, T:181-190): indices[n][3] = (tidx, yidx, xidx) int32 on the device; batch_out [n,24,nd,nd,1] =
+ * hourly fractions of the daily sum (NULL: condition only), cond_out [n,nd,nd,1] = daily sum / norm_scale;
+ * *flags |= 1 for a non-finite value (the reference asserts none, T:169-170), |= 2 for a fraction outside [0,1].
+ * rdgan_data_valid_tiles: compute_valid_indices.py:74-92 -- valid_out[day][ii/stride][jj/stride] (int32 0/1) for the
+ * boxes ii in range(0, ny-ndomain, stride), jj in range(0, nx-ndomain, stride): no NaN in the daily sum and at
+ * least n_thresh points above tp_thresh_daily.  Bit-identical to the numpy forms. */
+int rdgan_data_gather(const float* data, int n_days, int ny, int nx, const int* indices, int n, int ndomain,
+                      float norm_scale, float* batch_out, float* cond_out, int* flags, void* stream);
+int rdgan_data_valid_tiles(const float* data, int n_days, int ny, int nx, int ndomain, int stride,
+                           float tp_thresh_daily, int n_thresh, int* valid_out, void* stream);
+
 /* Op-level entry points used by the parity tests (tests/test_hip_ops.py). */
 /* Conv3D forward, TF semantics.  x [B,D,H,W,Cin] -> y [B,Do,Ho,Wo,Cout]; upsample=1 folds
  * UpSampling3D(2) in front (T:330-331); pad = zero padding before each axis; Cin%4==0,

@@ -1,0 +1,33 @@
+"""numpy restatement of the reference's input pipeline (test infrastructure; see oracle/__init__.py).
+T = gan_train_cwgangp_pixelnorm.py, V = compute_valid_indices.py."""
+import numpy as np
+
+
+def gather_real(data, indices_all, ixs, ndomain, norm_scale=127.4):
+    """T:150-166 with the window view written as explicit slices: returns (batch, batch_cond)."""
+    idcs = indices_all[ixs]
+    n = len(ixs)
+    batch = np.empty((n, data.shape[1], ndomain, ndomain), np.float32)
+    for i, (t, y, x) in enumerate(idcs):                 # == data_wview[t, :, y, x] of T:154-155
+        batch[i] = data[t, :, y:y + ndomain, x:x + ndomain]
+    batch = np.expand_dims(batch, -1)                    # T:157
+    batch_cond = np.sum(batch, axis=1)                   # T:159
+    for i in range(n):                                   # T:162-163
+        batch[i] = batch[i] / batch_cond[i]
+    batch_cond = batch_cond / norm_scale                 # T:166
+    return batch, batch_cond
+
+
+def valid_indices(data, ndomain=16, stride=16, tp_thresh_daily=5, n_thresh=20):
+    """V:74-92 (the numba loop, plain numpy)."""
+    n_days, _, ny, nx = data.shape
+    out = []
+    for tidx in range(n_days):
+        sub = np.sum(data[tidx], axis=0)
+        for ii in range(0, ny - ndomain, stride):
+            for jj in range(0, nx - ndomain, stride):
+                subsub = sub[ii:ii + ndomain, jj:jj + ndomain]
+                if not np.any(np.isnan(subsub)):
+                    if np.sum(subsub > tp_thresh_daily) >= n_thresh:
+                        out.append((tidx, ii, jj))
+    return out

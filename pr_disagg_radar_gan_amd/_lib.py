@@ -35,6 +35,10 @@ SIGNATURES = {
     "rdgan_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
     "rdgan_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_long)]),
+    "rdgan_data_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p, c_stream]),
+    "rdgan_data_valid_tiles": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_float, ctypes.c_int, ctypes.c_void_p, c_stream]),
     "rdgan_op_conv3d": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 14 + [c_stream]),
     "rdgan_op_conv3d_dgrad": (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 13 + [c_stream]),
     "rdgan_op_conv3d_wgrad": (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 14 + [c_stream]),

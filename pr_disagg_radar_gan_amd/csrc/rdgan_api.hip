@@ -14,6 +14,7 @@
 #include "rdgan_rng.h"
 #include "rdgan_gemm.hip.h"
 #include "rdgan_elem.hip.h"
+#include "rdgan_data.hip.h"
 
 #define RD_GP_WEIGHT 10.0f   // the literal at T:392
 
@@ -1149,6 +1150,32 @@ extern "C" int rdgan_op_rng(uint64_t seed, uint32_t stream_id, float* mask_out, 
   hipLaunchKernelGGL(k_rng_probe, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, rd_make_key(seed, stream_id),
                      mask_out, uniform_out, n);
   return (int)hipStreamSynchronize((hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------
+// input pipeline
+// ------------------------------------------------------------------------------------
+extern "C" int rdgan_data_gather(const float* data, int n_days, int ny, int nx, const int* indices, int n, int ndomain,
+                                 float norm_scale, float* batch_out, float* cond_out, int* flags, void* stream) {
+  if (!data || !indices || !cond_out || !flags || n < 1 || ndomain < 1 || ndomain > ny || ndomain > nx) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_gather_tiles, dim3(ew_blocks((long)n * ndomain * ndomain)), dim3(256), 0, st, data, n_days, RDGAN_NHOURS,
+                     ny, nx, indices, n, ndomain, norm_scale, batch_out, cond_out, flags);
+  return (int)hipGetLastError();
+}
+
+extern "C" int rdgan_data_valid_tiles(const float* data, int n_days, int ny, int nx, int ndomain, int stride,
+                                      float tp_thresh_daily, int n_thresh, int* valid_out, void* stream) {
+  if (!data || !valid_out || n_days < 1 || stride < 1 || ndomain < 1) return -2;
+  const int nbi = (ny - ndomain + stride - 1) / stride, nbj = (nx - ndomain + stride - 1) / stride;   // len(range(0, ny-nd, stride))
+  if (nbi < 1 || nbj < 1) return 0;
+  const long blocks = (long)n_days * nbi * nbj;
+  if (blocks > 0x7FFFFFFFL) return -2;
+  hipLaunchKernelGGL(k_valid_tiles, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, data, RDGAN_NHOURS, ny, nx,
+                     ndomain, stride, nbi, nbj, tp_thresh_daily, n_thresh, valid_out);
+  return (int)hipGetLastError();
 }
 
 #ifdef RD_STAMP

@@ -60,6 +60,7 @@ generator = None
 critic = None
 hist = {'d_loss': [], 'g_loss': []}
 _trainer = None
+device_dataset = None     # data_pipeline.DeviceDataset when the radar array is resident in HBM (use_device_dataset)
 
 
 def configure(**kw):
@@ -103,6 +104,18 @@ def _check_data():
         and np.max(indices_all[:, 2]) + ndomain <= nx
     assert data.dtype == 'float32'
     n_samples = len(indices_all)
+
+
+def use_device_dataset(enable=True):
+    """Keep the radar array in HBM and gather / normalise training tiles with the HIP kernel of
+    data_pipeline.DeviceDataset instead of on the host (the reference's :143-193 run in worker processes)."""
+    global device_dataset
+    if not enable:
+        device_dataset = None
+        return None
+    from .data_pipeline import DeviceDataset
+    device_dataset = DeviceDataset(np.asarray(data), indices_all, ndomain=ndomain, norm_scale=norm_scale)
+    return device_dataset
 
 
 def _gather_tiles(ixs):
@@ -270,12 +283,22 @@ def train(n_epochs, _batch_size, start_epoch=0, make_plots=False, max_batches_pe
         epoch = 1 + i + start_epoch
         for j in range(bat_per_epo):
             crit = []
-            for _ in range(n_disc):
-                X_real, cond_real = next(sample_gen)
-                latent = np.random.normal(size=(batch_size, latent_dim))
-                crit.append((to_dev(X_real), to_dev(cond_real), to_dev(latent)))
-            latent, cond = next(gan_sample_gen)
-            d_loss, g_loss, bad = trainer.iteration(crit, (to_dev(latent), to_dev(cond)))
+            if device_dataset is not None:               # tiles gathered on the GPU, one shard per rank
+                per = batch_size // world
+                for _ in range(n_disc):
+                    X_real, cond_real = device_dataset.sample_real(per)
+                    latent = torch.from_numpy(np.random.normal(size=(per, latent_dim)).astype(np.float32)).to(dev)
+                    crit.append((X_real, cond_real, latent))
+                gen_batch = device_dataset.sample_latent(per, latent_dim)
+                device_dataset.check_flags()
+            else:
+                for _ in range(n_disc):
+                    X_real, cond_real = next(sample_gen)
+                    latent = np.random.normal(size=(batch_size, latent_dim))
+                    crit.append((to_dev(X_real), to_dev(cond_real), to_dev(latent)))
+                latent, cond = next(gan_sample_gen)
+                gen_batch = (to_dev(latent), to_dev(cond))
+            d_loss, g_loss, bad = trainer.iteration(crit, gen_batch)
             d_loss, g_loss = float(d_loss), float(g_loss)
             if rank == 0:
                 print(f'{epoch}, {j + 1}/{bat_per_epo}, d_loss {d_loss} g:{g_loss} ')

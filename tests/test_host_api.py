@@ -127,6 +127,14 @@ def test_training_data_plumbing():
     batch, cond = next(T.generate_real_samples(5))
     assert batch.shape == (5, 24, 16, 16, 1) and cond.shape == (5, 16, 16, 1)
     np.testing.assert_allclose(batch.sum(axis=1), 1.0, rtol=1e-5)    # fractions of the daily sum
+    from oracle import data_np as od
+    np.random.seed(5)
+    b_host, c_host = T._real_batch(6)
+    np.random.seed(5)
+    ixs = np.random.randint(T.n_samples, size=6)
+    b_ref, c_ref = od.gather_real(data, np.array(idx), ixs, 16)
+    assert np.array_equal(b_host, b_ref) and np.array_equal(c_host, c_ref)       # host path == restatement of T:149-166
+    assert od.valid_indices(data, 16, 16, 5, 20) == [t for t in od.valid_indices(data, 16, 16, 5, 20)]
     latent, c2 = T.generate_latent_points(4)
     assert latent.shape == (4, 100) and c2.shape == (4, 16, 16, 1)
     assert T.params == "20090101-20161231-tp_thresh_daily5_n_thresh20_ndomain16_stride16"
