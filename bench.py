@@ -170,7 +170,7 @@ def main():
                                    + (" (BASELINE configs[1])" if (ND, B, args.n_critic) == (16, 256, 1) else ""),
                        "global_batch": world * B, "n_critic": args.n_critic, "parallelism": f"dp{world}",
                        "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm<256,64,4,1,32> generator block 3 forward (upsample+Conv3D 128->64, 8-tap collapsed form)",
+            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_ws<256,64,4,1> generator block 3 forward (upsample+Conv3D 128->64 + bias + PixelNorm + LeakyReLU, 8-tap collapsed form)",
                          "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),

@@ -78,7 +78,10 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
 /* Options.  "collapse" (default 1): evaluate each generator block UpSampling3D(2)+Conv3D(3x3x3,'same')
  * (T:330-331) as 8 parity phases of 2x2x2 taps on the un-upsampled grid with pre-summed weights --
  * algebraically identical, 3.375x fewer FLOPs in forward, input gradient and weight gradient; only the
- * fp32 rounding of the pre-summed weights differs.  0 = the reference's direct 27-tap form. */
+ * fp32 rounding of the pre-summed weights differs.  0 = the reference's direct 27-tap form.
+ * "wave_specialized" (default 1): big GEMMs run the producer/consumer kernel (4 loader waves streaming tiles
+ * into LDS by DMA, 4 compute waves issuing only ds_read + MFMA); 0 = the single-role kernel everywhere;
+ * 2 = producer/consumer kernel for every eligible shape regardless of size (tests). */
 int rdgan_set_option(rdgan_handle* h, const char* name, int value);
 
 /* Per-kernel HIP-event timing for bench.py's roofline line.  tag_mask: bit i enables timing of

@@ -13,6 +13,7 @@
 #include "rdgan_plan.h"
 #include "rdgan_rng.h"
 #include "rdgan_gemm.hip.h"
+#include "rdgan_gemm_ws.hip.h"
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
 
@@ -264,6 +265,7 @@ struct rdgan_handle {
   float *DWT[5], *W1T, *GWT[4], *W9T;
   float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
   int collapse = 1;               // 1: 8-tap collapsed generator blocks (default); 0: direct 27-tap form
+  int wave_spec = 1;              // 1: producer/consumer (wave-specialised, LDS-DMA) kernel for the big clean GEMMs
   int* d_flag;
   // profiling
   unsigned prof_mask = 0;
@@ -359,6 +361,30 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   return 0;
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_conv_ws_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
+                              const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
+  constexpr size_t lds_loop = 2 * (size_t)(BM * 32 + 32 * BN) * sizeof(float);
+  constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float) + (size_t)BM * 8;
+  constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  static bool attr_done = false;
+  auto kern = k_conv_gemm_ws<BM, BN, WM, WN>;
+  if (!attr_done) {
+    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  long tm = plan_tiles(hp, B, BM);
+  if (tm <= 0) return 0;
+  long minL = hp.ph[0].L;
+  for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
+  if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
+  RdEpi e2 = epi;
+  e2.ksplit = 1; e2.kpart = nullptr; e2.kstride = 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * (hp.N / BN)), 1), dim3(512), lds, st, dp, B, src, W, ldw, dst, e2);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
 static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* W,
                        int ldw, float* dst, const RdEpi& epi, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
@@ -375,10 +401,19 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
     if (shift) return launch_conv_cfg<BM_, BN_, WM_, WN_, 32, false, true>(h, hp, dp, B, src, W, ldw, dst, epi, st);   \
     return launch_conv_cfg<BM_, BN_, WM_, WN_, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);             \
   } while (0)
-  if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200) RD_CONV(128, 128, 2, 2);
+  const bool ws_ok = h && h->wave_spec && !partial && !shift && hp.SC % 32 == 0;
+  if (ws_ok && h->wave_spec == 2) {      // test mode: the producer/consumer kernel regardless of the problem size
+    if (hp.N % 128 == 0) return launch_conv_ws_cfg<128, 128, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    if (hp.N == 64) return launch_conv_ws_cfg<256, 64, 4, 1>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  }
+  if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200) {
+    if (ws_ok) return launch_conv_ws_cfg<128, 128, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    RD_CONV(128, 128, 2, 2);
+  }
   if (hp.N % 64 == 0) {
     // N = 64 layers with plenty of rows: 256-row tile so every wave owns a 64x64 tile (64 MFMAs per barrier)
     if (hp.N == 64 && !shift && plan_tiles(hp, B, 256) >= 1024) {   // (the SHIFT variant of this tile would spill)
+      if (ws_ok) return launch_conv_ws_cfg<256, 64, 4, 1>(h, hp, dp, B, src, W, ldw, dst, epi, st);
       if (partial) return launch_conv_cfg<256, 64, 4, 1, 32, true, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
       return launch_conv_cfg<256, 64, 4, 1, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
     }
@@ -720,6 +755,7 @@ extern "C" int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, l
 extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!h || !name) return -2;
   if (!strcmp(name, "collapse")) { h->collapse = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "wave_specialized")) { h->wave_spec = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }   // 2 = also for small problems (tests)
   return bad_arg(h, "set_option: unknown option");
 }
 

@@ -428,10 +428,12 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
         float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
         for (int o = F4R / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float l2 = sqrtf(ss * (1.0f / BN) + 1.0e-8f);
+        // one reciprocal per row and four multiplies (an IEEE division is ~10 instructions, and every non-MFMA
+        // instruction here waits for a slot between the partner wave's MFMAs); <= 1 ulp from x / l2
+        const float ri = 1.0f / sqrtf(ss * (1.0f / BN) + 1.0e-8f);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rd_lrelu(v[e] / l2);
-        if (c4 == 0 && epi.rinv) epi.rinv[rb / BN] = 1.0f / l2;
+        for (int e = 0; e < 4; ++e) v[e] = rd_lrelu(v[e] * ri);
+        if (c4 == 0 && epi.rinv) epi.rinv[rb / BN] = ri;
       } else if (mode == RD_EPI_GATE_AUX) {
         const f32x4 a4 = *(const f32x4*)(epi.aux + idx0);
 #pragma unroll

@@ -1,0 +1,285 @@
+// Wave-specialised (producer / consumer) variant of k_conv_gemm for the big, "clean" plans
+// (SC % 32 == 0, no folded-upsample shift): 512-thread workgroups, waves 0-3 multiply, waves 4-7 load.
+//
+// Why: in-kernel stamps on k_conv_gemm show that next to a partner wave streaming 64-cycle fp32 MFMAs every
+// non-MFMA instruction of a wave waits ~55 cycles for an issue slot, so a wave that alternates between a load
+// phase (~60 instructions) and an MFMA phase leaves the matrix pipe idle ~25 % of the time.  Here a compute
+// wave issues only ds_read + MFMA, and a loader wave streams the next K chunk global -> LDS with LDS-DMA
+// (buffer_load ... lds, 16 B per lane): no VGPR staging, no ds_write, one instruction per KiB.  Out-of-image taps
+// use an out-of-range buffer offset, for which the DMA writes zeros (verified on gfx950: scratch/probe/ldsdma.hip).
+//
+// LDS images are the ones of k_conv_gemm (A: unpadded 128-byte rows, 16-byte chunk c of row r stored at
+// c ^ ((r>>1)&7); B: [k][BN]).  LDS-DMA writes lane-linearly, so the swizzle is applied on the SOURCE side: the
+// lane that fills physical chunk p of row r fetches logical chunk p ^ ((r>>1)&7).
+#pragma once
+#include "rdgan_gemm.hip.h"
+
+// 16 bytes per lane, global -> LDS, no VGPR destination: LDS address = wave-uniform `lds` + lane*16
+__device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(512, 4)
+k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
+               const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {
+  static_assert(WM * WN == 4, "4 compute waves");
+  constexpr int BK = 32, TG = 8;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int STAGE = BM * BK + BK * BN;                 // floats per LDS stage
+  constexpr int NI_A = BM / 32;                            // A DMA instructions (1 KiB = 8 rows) per loader wave and chunk
+  constexpr int NI_B = BN / 32;                            // B DMA instructions (1 KiB = 256/BN rows) per loader wave
+  constexpr int B_LPR = BN / 4;                            // lanes per B row
+  constexpr int B_RPI = 64 / B_LPR;                        // B rows per DMA instruction
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_compute = wave < 4;
+  const int l31 = lane & 31, lhalf = lane >> 5;
+
+  // ---- which phase / tile (wave-uniform)
+  const int NTn = plan->N / BN;
+  const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int ntile = swz % NTn;
+  int mt = swz / NTn, pidx = 0;
+  if (plan->interleave) {
+    pidx = mt % plan->nphases;
+    mt /= plan->nphases;
+  } else {
+    for (int p = 0; p < plan->nphases; ++p) {
+      int nt = (B * plan->ph[p].L + BM - 1) / BM;
+      if (mt < nt) { pidx = p; break; }
+      mt -= nt;
+    }
+  }
+  const RdPhase& P = plan->ph[pidx];
+  const int L = P.L;
+  const int rows = B * L;
+  const int m0 = mt * BM;
+  const int n0 = ntile * BN;
+  const int b0 = m0 / L, l0 = m0 - b0 * L;
+  const int SC = plan->SC, wrpt = plan->w_rows_per_tap;
+  const int ssample = (int)plan->src_sample;
+  const int ntaps = P.ntaps;
+  const RdRowTab tab = rd_row_tab(plan, P.tab);
+  const int CPT = SC / BK;
+  const int nch_all = ntaps * CPT;
+  const int ksplit = epi.ksplit > 1 ? epi.ksplit : 1;
+  const int per_split = (nch_all + ksplit - 1) / ksplit;
+  const int q0 = (int)blockIdx.y * per_split;
+  const int nchunks = max(0, min(nch_all, q0 + per_split) - q0);
+
+  f32x16 acc[TM][TN];
+
+  if (!is_compute) {
+    // =============================== loader waves ===============================
+    const int wl = wave - 4;
+    const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)b0 * plan->src_sample);
+    const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(W + P.w_off);
+    // A: instruction k of this wave fills rows wl*(BM/4) + 8k .. +7; this lane: row +(lane>>3), physical chunk lane&7
+    int roff[NI_A], rbits[NI_A];
+#pragma unroll
+    for (int k = 0; k < NI_A; ++k) {
+      const int r = wl * (BM / 4) + k * 8 + (lane >> 3);
+      const int c_log = (lane & 7) ^ ((r >> 1) & 7);
+      roff[k] = 0; rbits[k] = 0;
+      if (m0 + r < rows) {
+        int l = l0 + r, bb = 0;
+        if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
+        else { bb = l / L; l -= bb * L; }
+        roff[k] = (bb * ssample + tab[l].x + c_log * 4) * 4;
+        rbits[k] = tab[l].y;
+      }
+    }
+    int boff[NI_B];
+#pragma unroll
+    for (int j = 0; j < NI_B; ++j) {
+      const int kk = (wl * NI_B + j) * B_RPI + lane / B_LPR;
+      boff[j] = (kk * ldw + n0 + (lane % B_LPR) * 4) * 4;
+    }
+    unsigned voffs[NI_A][TG];
+    int tapw[TG];
+    auto build_group = [&](int g) {
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        const int tap = min(g * TG + t, ntaps - 1);
+        const RdTap ti = P.tap[tap];
+        tapw[t] = ti.w * wrpt * ldw * 4;
+#pragma unroll
+        for (int k = 0; k < NI_A; ++k)
+          voffs[k][t] = ((rbits[k] & ti.mask) == ti.mask) ? (unsigned)(roff[k] + ti.delta) : RD_OOB;
+      }
+    };
+    int ld_g, ld_cc, ld_t, ld_gt;
+    {
+      const int full = TG * CPT;
+      ld_g = q0 / full;
+      const int rem = q0 - ld_g * full;
+      ld_gt = min(TG, ntaps - ld_g * TG);
+      ld_cc = ld_gt > 0 ? rem / ld_gt : 0;
+      ld_t = ld_gt > 0 ? rem - ld_cc * ld_gt : 0;
+    }
+    if (nchunks > 0) build_group(ld_g);
+    auto issue = [&](int stage, auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      float* As = smem + stage * STAGE + wl * (BM / 4) * BK;
+      float* Bs = smem + stage * STAGE + BM * BK + wl * NI_B * 256;
+      const int sA = ld_cc * BK * 4;
+      const int sB = tapw[t] + ld_cc * BK * ldw * 4;
+#pragma unroll
+      for (int k = 0; k < NI_A; ++k)
+        rd_lds_dma16(rsA, As + k * 8 * BK, (int)voffs[k][t], sA);
+#pragma unroll
+      for (int j = 0; j < NI_B; ++j)
+        rd_lds_dma16(rsB, Bs + j * 256, boff[j], sB);
+    };
+    auto load_chunk = [&](int stage) {
+      switch (ld_t) {
+        case 0: issue(stage, std::integral_constant<int, 0>{}); break;
+        case 1: issue(stage, std::integral_constant<int, 1>{}); break;
+        case 2: issue(stage, std::integral_constant<int, 2>{}); break;
+        case 3: issue(stage, std::integral_constant<int, 3>{}); break;
+        case 4: issue(stage, std::integral_constant<int, 4>{}); break;
+        case 5: issue(stage, std::integral_constant<int, 5>{}); break;
+        case 6: issue(stage, std::integral_constant<int, 6>{}); break;
+        default: issue(stage, std::integral_constant<int, 7>{}); break;
+      }
+      if (++ld_t == ld_gt) {
+        ld_t = 0;
+        if (++ld_cc == CPT) {
+          ld_cc = 0;
+          ++ld_g;
+          ld_gt = min(TG, ntaps - ld_g * TG);
+          if (ld_gt > 0) build_group(ld_g);
+        }
+      }
+    };
+    if (nchunks > 0) load_chunk(0);
+    __syncthreads();                                     // (hipcc waits vmcnt(0) in front of the barrier: chunk 0 has landed)
+    for (int q = 0; q < nchunks; ++q) {
+      // stage (q+1)&1 was last read during chunk q-1, whose closing barrier every wave has passed
+      if (q + 1 < nchunks) load_chunk((q + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    // =============================== compute waves ===============================
+    const int wm = wave / WN, wn = wave % WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int a_sw = (l31 >> 1) & 7;
+    __syncthreads();
+    for (int q = 0; q < nchunks; ++q) {
+      const int buf = q & 1;
+      const float* As = smem + buf * STAGE + (wm * WTM + l31) * BK;
+      const float* Bs = smem + buf * STAGE + BM * BK + lhalf * 4 * BN + wn * WTN + l31;
+      constexpr int NJ = BK / 8;
+      f32x4 fa[2][TM];
+      float fb[2][4][TN];
+      auto load_frag = [&](int slot, int j8) {
+        const int acol = ((j8 * 2 + lhalf) ^ a_sw) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *(const f32x4*)&As[i * 32 * BK + acol];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[slot][s][j] = Bs[(j8 * 8 + s) * BN + j * 32];
+      };
+      load_frag(0, 0);
+#pragma unroll
+      for (int j8 = 0; j8 < NJ; ++j8) {
+        const int cur = j8 & 1;
+        if (j8 + 1 < NJ) load_frag(cur ^ 1, j8 + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][s][j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (all 8 waves): tile through LDS, coalesced float4 rows (see k_conv_gemm)
+  const long dsample = plan->dst_sample;
+  const int mode = epi.mode;
+  float* Cs = smem;
+  int* Rb = (int*)(smem + BM * BN);
+  if (is_compute) {
+    const int wm = wave / WN, wn = wave % WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Cs[row * BN + wn * WTN + j * 32 + l31] = acc[i][j][r];
+      }
+  } else if (tid - 256 < BM) {
+    const int row = tid - 256;
+    long rb = -1;
+    if (m0 + row < rows) {
+      int l = l0 + row, bb = b0;
+      if (L >= BM) { if (l >= L) { l -= L; bb += 1; } }
+      else { int qd = l / L; l -= qd * L; bb += qd; }
+      rb = (long)bb * dsample + tab[l].z;
+    }
+    Rb[2 * row] = (int)(rb & 0xFFFFFFFFll); Rb[2 * row + 1] = (int)(rb >> 32);
+  }
+  __syncthreads();
+  constexpr int F4R = BN / 4;
+  constexpr int RPP = 512 / F4R;
+  const int c4 = (tid % F4R) * 4;
+  const int col = n0 + c4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (ksplit == 1 && (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP ||
+                      mode == RD_EPI_BIAS_PN_LRELU))
+    bias4 = *(const f32x4*)(epi.bias + col);
+#pragma unroll 4
+  for (int row = tid / F4R; row < BM; row += RPP) {
+    const long rb = ((long)Rb[2 * row + 1] << 32) | (unsigned)Rb[2 * row];
+    if (rb < 0) continue;
+    const long idx0 = rb + col;
+    f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
+    if (ksplit > 1) {
+      *(f32x4*)(epi.kpart + (long)blockIdx.y * epi.kstride + idx0) = v;
+      continue;
+    }
+    if (mode == RD_EPI_BIAS) {
+      v += bias4;
+    } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
+      v += bias4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = rd_lrelu(v[e]);
+        if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
+        v[e] = x;
+      }
+    } else if (mode == RD_EPI_BIAS_PN_LRELU) {
+      v += bias4;
+      float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+      for (int o = F4R / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float ri = 1.0f / sqrtf(ss * (1.0f / BN) + 1.0e-8f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rd_lrelu(v[e] * ri);
+      if (c4 == 0 && epi.rinv) epi.rinv[rb / BN] = ri;
+    } else if (mode == RD_EPI_GATE_AUX) {
+      const f32x4 a4 = *(const f32x4*)(epi.aux + idx0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g = rd_lrelu_slope_from_out(a4[e]);
+        if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
+        v[e] *= g;
+      }
+    }
+    *(f32x4*)(dst + idx0) = v;
+  }
+}

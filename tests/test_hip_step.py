@@ -33,10 +33,11 @@ def eng16():
     e.close()
 
 
-@pytest.mark.parametrize("collapse", [1, 0])
+@pytest.mark.parametrize("collapse,ws", [(1, 1), (0, 1), (1, 2)])
 @pytest.mark.parametrize("B", [1, 2, 5])
-def test_generator_forward_parity(eng16, B, collapse):
+def test_generator_forward_parity(eng16, B, collapse, ws):
     eng16.set_option("collapse", collapse)      # 8-tap collapsed blocks (default) vs the direct 27-tap form
+    eng16.set_option("wave_specialized", ws)    # 2 = force the producer/consumer (LDS-DMA) kernel at these small sizes
     g, _ = _params(16, 11)
     x, cond, z = ot.synthetic_batch(B, 16, 3)
     ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
@@ -50,6 +51,7 @@ def test_generator_forward_parity(eng16, B, collapse):
 
 def test_generator_kat_zero_weights(eng16):
     eng16.set_option("collapse", 1)
+    eng16.set_option("wave_specialized", 1)
     g = [np.zeros(s, np.float32) for _, s in W.gen_param_shapes(16)]
     x, cond, z = ot.synthetic_batch(3, 16, 4)
     out = eng16.gen_forward(eng16.to_slab(g), dev(z), dev(cond)).cpu().numpy()
@@ -107,8 +109,10 @@ def _parity_over_batches(run_case):
 
 
 @pytest.mark.parametrize("B,seed", [(2, 1234), (3, 0), (4, 99)])
-def test_critic_step_grads_parity(eng16, B, seed):
+@pytest.mark.parametrize("ws", [1, 2])
+def test_critic_step_grads_parity(eng16, B, seed, ws):
     eng16.set_option("collapse", 1)
+    eng16.set_option("wave_specialized", ws)
     g, d = _params(16, 13)
 
     def run_case(data_seed):
@@ -124,10 +128,11 @@ def test_critic_step_grads_parity(eng16, B, seed):
     _parity_over_batches(run_case)
 
 
-@pytest.mark.parametrize("collapse", [1, 0])
+@pytest.mark.parametrize("collapse,ws", [(1, 1), (0, 1), (1, 2)])
 @pytest.mark.parametrize("B,seed", [(2, 4321), (3, 0)])
-def test_gen_step_grads_parity(eng16, B, seed, collapse):
+def test_gen_step_grads_parity(eng16, B, seed, collapse, ws):
     eng16.set_option("collapse", collapse)
+    eng16.set_option("wave_specialized", ws)
     g, d = _params(16, 14)
 
     def run_case(data_seed):
