@@ -478,6 +478,24 @@ static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int 
   return 0;
 }
 
+template <int BR, int BN>
+static int launch_wgrad_ws_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int B, const float* src, const float* dy,
+                               float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
+  constexpr size_t lds_loop = 2 * (size_t)(32 * BR + 32 * BN) * sizeof(float);
+  constexpr size_t lds_epi = (size_t)BR * BN * sizeof(float);
+  constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  static bool attr_done = false;
+  auto kern = k_wgrad_gemm_ws<BR, BN>;
+  if (!attr_done) {
+    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dp, B, src, dy, partial, T);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
 // dW (rows tap_w*wrpt + c, leading dimension ldw = N) from src (gathered through the plan) and dy
 static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* dy,
                         float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
@@ -500,7 +518,14 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
     else RD_TRY((launch_wgrad_cfg<BR_, BN_, false, false>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));      \
   } while (0)
   float* partial_buf = partial_ws;
-  if (partial) RD_TRY((launch_wgrad_cfg<64, 64, true, false>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  const long wrows = (long)B * hp.ph[0].L;
+  const bool ws = h && h->wave_spec && !partial && !shift && (h->wave_spec == 2 || wrows >= 65536);
+  if (ws && BR == 256) RD_TRY((launch_wgrad_ws_cfg<256, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  else if (ws && BR == 128 && BN == 128) RD_TRY((launch_wgrad_ws_cfg<128, 128>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  else if (ws && BR == 128) RD_TRY((launch_wgrad_ws_cfg<128, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  else if (ws && BN == 128) RD_TRY((launch_wgrad_ws_cfg<64, 128>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  else if (ws) RD_TRY((launch_wgrad_ws_cfg<64, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  else if (partial) RD_TRY((launch_wgrad_cfg<64, 64, true, false>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
   else if (BR == 256) RD_WG(256, 64);
   else if (BR == 128 && BN == 128) RD_WG(128, 128);
   else if (BR == 128) RD_WG(128, 64);

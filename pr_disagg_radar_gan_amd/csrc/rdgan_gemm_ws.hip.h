@@ -283,3 +283,181 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
     *(f32x4*)(dst + idx0) = v;
   }
 }
+
+// ------------------------------------------------------------------------------------
+// Producer / consumer weight-gradient kernel (see k_wgrad_gemm for the maths and the grid):
+// waves 0-3 multiply, waves 4-7 stream the next 32 gathered positions (A: [32][BR]) and output-gradient rows
+// (B: [32][BN]) into LDS by DMA.  Clean plans only (SC % 4 == 0, no shift).
+// ------------------------------------------------------------------------------------
+template <int BR, int BN>
+__global__ void __launch_bounds__(512, 4)
+k_wgrad_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
+                const float* __restrict__ dy, float* __restrict__ partial, RdWgradTiling T) {
+  constexpr int BKP = 32;
+  constexpr int WTM = BR / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+  constexpr int STAGE = BKP * BR + BKP * BN;
+  constexpr int A_F4 = BR / 4;                   // lanes per gathered position
+  constexpr int A_PPI = A_F4 >= 64 ? 1 : 64 / A_F4;          // positions per A DMA instruction
+  constexpr int A_IPP = A_F4 >= 64 ? A_F4 / 64 : 1;          // A DMA instructions per position (BR = 256: 1)
+  static_assert(A_IPP == 1, "BR <= 256");
+  constexpr int NI_A = BKP / A_PPI / 4;          // A DMA instructions per loader wave and chunk
+  constexpr int B_F4 = BN / 4;
+  constexpr int B_PPI = 64 / B_F4;
+  constexpr int NI_B = BKP / B_PPI / 4;
+  constexpr bool UNI = A_PPI == 1;               // a whole wave gathers one position: cursors on the scalar unit
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_compute = wave < 4;
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tiles = T.RT * T.NT;
+  const int bx = swz % tiles, by = (swz / tiles) % T.nsplit, bz = swz / (tiles * T.nsplit);
+  const RdPhase& P = plan->ph[bz];
+  const int L = P.L;
+  const int rows = B * L;
+  const int rt = bx / T.NT, ntile = bx - rt * T.NT;
+  const int n0 = ntile * BN;
+  const int mbeg = by * T.rows_per_split;
+  const int mend = min(rows, mbeg + T.rows_per_split);
+  const int nchunks = (mend - mbeg + BKP - 1) / BKP;
+  const int N = plan->N;
+
+  f32x16 acc[TM][TN];
+
+  if (!is_compute) {
+    const int wl = wave - 4;
+    const int SC = plan->SC;
+    const int ssample = (int)plan->src_sample, dsample = (int)plan->dst_sample;
+    const RdRowTab tab = rd_row_tab(plan, P.tab);
+    const int bb0 = mbeg / L;
+    const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)bb0 * plan->src_sample);
+    const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(dy + (long)bb0 * plan->dst_sample);
+    // this lane's (tap, channel) column group of the A tile
+    int a_tap, a_c;
+    rd_wgrad_tile_row(T, BR, rt, (lane % A_F4) * 4, a_tap, a_c);
+    const bool a_ok = a_tap < P.ntaps && a_c < SC;
+    int tmask = 0x7FFF, a_const = 0;
+    if (a_ok) { const RdTap t = P.tap[a_tap]; tmask = t.mask; a_const = t.delta + a_c * 4; }
+    const int b_const = (n0 + (lane % B_F4) * 4) * 4;
+    // row cursors: A instruction k gathers position (wl*NI_A + k)*A_PPI + lane/A_F4 of the chunk
+    int ab[NI_A], al[NI_A], gb[NI_B], gl[NI_B];
+#pragma unroll
+    for (int k = 0; k < NI_A; ++k) {
+      int pos = (wl * NI_A + k) * A_PPI + (UNI ? 0 : lane / A_F4);
+      int m = mbeg + pos;
+      ab[k] = m / L; al[k] = m - ab[k] * L; ab[k] -= bb0;
+    }
+#pragma unroll
+    for (int j = 0; j < NI_B; ++j) {
+      int m = mbeg + (wl * NI_B + j) * B_PPI + lane / B_F4;
+      gb[j] = m / L; gl[j] = m - gb[j] * L; gb[j] -= bb0;
+    }
+    int ex[NI_A], ey[NI_A], ez[NI_B];
+    auto fetch_rows = [&]() {
+#pragma unroll
+      for (int k = 0; k < NI_A; ++k) { ex[k] = tab[al[k]].x; ey[k] = tab[al[k]].y; }
+#pragma unroll
+      for (int j = 0; j < NI_B; ++j) ez[j] = tab[gl[j]].z;
+    };
+    fetch_rows();
+    auto load_chunk = [&](int mb, int stage) {
+      float* As = smem + stage * STAGE + wl * NI_A * 256;
+      float* Bs = smem + stage * STAGE + BKP * BR + wl * NI_B * 256;
+#pragma unroll
+      for (int k = 0; k < NI_A; ++k) {
+        const int m = mb + (wl * NI_A + k) * A_PPI + (UNI ? 0 : lane / A_F4);
+        const int off = (ab[k] * ssample + ex[k]) * 4 + a_const;
+        unsigned voff = (m < mend && (ey[k] & tmask) == tmask) ? (unsigned)off : RD_OOB;
+        asm volatile("" : "+v"(voff));
+        rd_lds_dma16(rsA, As + k * 256, (int)voff, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NI_B; ++j) {
+        const int m = mb + (wl * NI_B + j) * B_PPI + lane / B_F4;
+        unsigned voff = m < mend ? (unsigned)((gb[j] * dsample + ez[j]) * 4 + b_const) : RD_OOB;
+        asm volatile("" : "+v"(voff));
+        rd_lds_dma16(rsB, Bs + j * 256, (int)voff, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < NI_A; ++k) {
+        al[k] += BKP;
+        if (L >= BKP) { if (al[k] >= L) { al[k] -= L; ab[k] += 1; } }
+        else { int qd = al[k] / L; al[k] -= qd * L; ab[k] += qd; }
+      }
+#pragma unroll
+      for (int j = 0; j < NI_B; ++j) {
+        gl[j] += BKP;
+        if (L >= BKP) { if (gl[j] >= L) { gl[j] -= L; gb[j] += 1; } }
+        else { int qd = gl[j] / L; gl[j] -= qd * L; gb[j] += qd; }
+      }
+      fetch_rows();
+    };
+    if (nchunks > 0) load_chunk(mbeg, 0);
+    __syncthreads();
+    for (int q = 0; q < nchunks; ++q) {
+      if (q + 1 < nchunks) load_chunk(mbeg + (q + 1) * BKP, (q + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();
+    for (int q = 0; q < nchunks; ++q) {
+      const int buf = q & 1;
+      const float* As = smem + buf * STAGE + lhalf * BR + wm * WTM + l31;
+      const float* Bs = smem + buf * STAGE + BKP * BR + lhalf * BN + wn * WTN + l31;
+      constexpr int NG = BKP / 8;
+      float fa[2][4][TM], fb[2][4][TN];
+      auto load_frag = [&](int slot, int g) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[slot][s][i] = As[(g * 8 + 2 * s) * BR + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[slot][s][j] = Bs[(g * 8 + 2 * s) * BN + j * 32];
+        }
+      };
+      load_frag(0, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int cur = g & 1;
+        if (g + 1 < NG) load_frag(cur ^ 1, g + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s][i], fb[cur][s][j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- partial tile [BR][BN] through LDS, coalesced float4 stores by all 8 waves
+  float* Cs = smem;
+  if (is_compute) {
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Cs[row * BN + wn * WTN + j * 32 + l31] = acc[i][j][r];
+      }
+  }
+  __syncthreads();
+  float* out = partial + (((long)bz * T.nsplit + by) * T.RT + rt) * BR * N;
+  constexpr int F4R = BN / 4, RPP = 512 / F4R;
+  const int c4 = (tid % F4R) * 4;
+  for (int row = tid / F4R; row < BR; row += RPP)
+    *(f32x4*)(out + (long)row * N + n0 + c4) = *(const f32x4*)&Cs[row * BN + c4];
+}
