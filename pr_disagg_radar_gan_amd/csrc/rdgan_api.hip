@@ -417,7 +417,10 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
       if (partial) return launch_conv_cfg<256, 64, 4, 1, 32, true, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
       return launch_conv_cfg<256, 64, 4, 1, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
     }
-    if (plan_tiles(hp, B, 128) * (hp.N / 64) >= 200) RD_CONV(128, 64, 2, 2);
+    if (plan_tiles(hp, B, 128) * (hp.N / 64) >= 200) {
+      if (ws_ok) return launch_conv_ws_cfg<128, 64, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+      RD_CONV(128, 64, 2, 2);
+    }
     RD_CONV(64, 64, 2, 2);
   }
   if (hp.N == 32 && !partial && !shift)
@@ -519,7 +522,7 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   } while (0)
   float* partial_buf = partial_ws;
   const long wrows = (long)B * hp.ph[0].L;
-  const bool ws = h && h->wave_spec && !partial && !shift && (h->wave_spec == 2 || wrows >= 65536);
+  const bool ws = h && h->wave_spec && !partial && !shift && (h->wave_spec == 2 || wrows * hp.nphases >= 16384);
   if (ws && BR == 256) RD_TRY((launch_wgrad_ws_cfg<256, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
   else if (ws && BR == 128 && BN == 128) RD_TRY((launch_wgrad_ws_cfg<128, 128>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
   else if (ws && BR == 128) RD_TRY((launch_wgrad_ws_cfg<128, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
