@@ -370,6 +370,9 @@ k_wgrad_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict_
         const int m = mb + (wl * NI_A + k) * A_PPI + (UNI ? 0 : lane / A_F4);
         const int off = (ab[k] * ssample + ex[k]) * 4 + a_const;
         unsigned voff = (m < mend && (ey[k] & tmask) == tmask) ? (unsigned)off : RD_OOB;
+#ifdef RD_ABL_L1W
+        voff = (unsigned)(lane * 16 + (k & 3) * 1024);    // diagnostic build: every gather hits a 4 KiB window
+#endif
         asm volatile("" : "+v"(voff));
         rd_lds_dma16(rsA, As + k * 256, (int)voff, 0);
       }
@@ -377,6 +380,9 @@ k_wgrad_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict_
       for (int j = 0; j < NI_B; ++j) {
         const int m = mb + (wl * NI_B + j) * B_PPI + lane / B_F4;
         unsigned voff = m < mend ? (unsigned)((gb[j] * dsample + ez[j]) * 4 + b_const) : RD_OOB;
+#ifdef RD_ABL_L1W
+        voff = (unsigned)(lane * 16 + j * 1024);
+#endif
         asm volatile("" : "+v"(voff));
         rd_lds_dma16(rsB, Bs + j * 256, (int)voff, 0);
       }
