@@ -111,6 +111,12 @@ int rdgan_data_gather(const float* data, int n_days, int ny, int nx, const int* 
 int rdgan_data_valid_tiles(const float* data, int n_days, int ny, int nx, int ndomain, int stride,
                            float tp_thresh_daily, int n_thresh, int* valid_out, void* stream);
 
+/* Ensemble CRPS per grid point, properscoring.crps_ensemble(obs, ens, axis=0) of generate_and_evaluate_crps.py:188:
+ * ens [n][npix] (member-major), obs [npix], optional scale [npix] applied to the members first (fractions -> mm/h,
+ * :186), crps_out [npix] = mean|x_i - y| - 0.5 mean|x_i - x_j|.  n <= 8192. */
+int rdgan_crps_ensemble(const float* ens, const float* obs, const float* scale, float* crps_out, int n, long npix,
+                        void* stream);
+
 /* Op-level entry points used by the parity tests (tests/test_hip_ops.py). */
 /* Conv3D forward, TF semantics.  x [B,D,H,W,Cin] -> y [B,Do,Ho,Wo,Cout]; upsample=1 folds
  * UpSampling3D(2) in front (T:330-331); pad = zero padding before each axis; Cin%4==0,

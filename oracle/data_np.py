@@ -31,3 +31,14 @@ def valid_indices(data, ndomain=16, stride=16, tp_thresh_daily=5, n_thresh=20):
                     if np.sum(subsub > tp_thresh_daily) >= n_thresh:
                         out.append((tidx, ii, jj))
     return out
+
+
+def crps_ensemble(obs, ens):
+    """properscoring.crps_ensemble(obs, ens, axis=0) by its definition (O(n^2), fp64):
+    mean_i |x_i - y| - 0.5 mean_{i,j} |x_i - x_j|  (generate_and_evaluate_crps.py:188)."""
+    ens = np.asarray(ens, np.float64); obs = np.asarray(obs, np.float64)
+    a = np.mean(np.abs(ens - obs[None]), axis=0)
+    b = np.zeros_like(a)
+    for i in range(ens.shape[0]):
+        b += np.mean(np.abs(ens - ens[i][None]), axis=0)
+    return a - 0.5 * b / ens.shape[0]

@@ -1242,6 +1242,16 @@ extern "C" int rdgan_data_valid_tiles(const float* data, int n_days, int ny, int
   return (int)hipGetLastError();
 }
 
+extern "C" int rdgan_crps_ensemble(const float* ens, const float* obs, const float* scale, float* crps_out, int n,
+                                   long npix, void* stream) {
+  if (!ens || !obs || !crps_out || n < 1 || n > 8192 || npix < 1 || npix > 0x7FFFFFFFL) return -2;
+  int npow2 = 2;
+  while (npow2 < n) npow2 <<= 1;
+  hipLaunchKernelGGL(k_crps_ensemble, dim3((unsigned)npix), dim3(256), npow2 * sizeof(float), (hipStream_t)stream, ens, obs,
+                     scale, crps_out, n, npow2, npix);
+  return (int)hipGetLastError();
+}
+
 #ifdef RD_STAMP
 extern "C" int rdgan_debug_stamps(unsigned long long* out, int reset) {
   unsigned long long z[8] = {0};

@@ -61,3 +61,42 @@ __global__ void k_valid_tiles(const float* __restrict__ data, int nh, int ny, in
   __syncthreads();
   if (threadIdx.x == 0) valid[blockIdx.x] = (!s_nan && s_cnt >= n_thresh) ? 1 : 0;
 }
+
+// Ensemble CRPS per grid point (generate_and_evaluate_crps.py:188, properscoring.crps_ensemble(obs, ens, axis=0)):
+//   crps = mean_i |x_i - y| - 0.5 * mean_{i,j} |x_i - x_j|
+// evaluated with the sorted-ensemble identity sum_{i<j} (x_(j) - x_(i)) = sum_i (2i - n - 1) x_(i), i = 1..n.
+// One 256-thread block per grid point: the n members (stride npix floats) are sorted by a bitonic network in LDS
+// (padded to the next power of two with +inf), sums in fp64-free Kahan-free fp32 pairwise block reduction.
+// `scale` (nullable, per point) multiplies the members first -- fractions -> mm/h by cond*norm_scale (:186).
+__global__ void __launch_bounds__(256)
+k_crps_ensemble(const float* __restrict__ ens, const float* __restrict__ obs, const float* __restrict__ scale,
+                float* __restrict__ crps, int n, int npow2, long npix) {
+  extern __shared__ float xs[];
+  __shared__ float red[8];
+  const long p = blockIdx.x;
+  const float sc = scale ? scale[p] : 1.0f;
+  for (int i = threadIdx.x; i < npow2; i += 256) xs[i] = i < n ? ens[(long)i * npix + p] * sc : __builtin_inff();
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += 256) {
+        int l = i ^ j;
+        if (l > i) {
+          float a = xs[i], b = xs[l];
+          bool up = (i & k) == 0;
+          if ((a > b) == up) { xs[i] = b; xs[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  const float y = obs[p];
+  float s_abs = 0.f, s_spread = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float x = xs[i];
+    s_abs += fabsf(x - y);
+    s_spread += (float)(2 * i + 1 - n) * x;          // (2(i+1) - n - 1) x_(i+1)
+  }
+  s_abs = rd_block_sum(s_abs, red);
+  s_spread = rd_block_sum(s_spread, red + 4);
+  if (threadIdx.x == 0) crps[p] = s_abs / n - s_spread / ((float)n * (float)n);
+}
