@@ -29,7 +29,10 @@ typedef struct rdgan_handle rdgan_handle;
 
 /* Build the per-(ndomain, max_batch) plans and allocate the activation workspace.
  * Replaces model construction at T:361-362 (create_generator / create_discriminator).
- * ndomain must be a multiple of 8 (L:324); n_cond_channels must be 1 (T:129). */
+ * ndomain must be a multiple of 8 (L:324); n_cond_channels = 1 (T:129: the daily sum), 2 (+ longitude index,
+ * revision1/additional_inputs/gan_train_cwgangp_pixelnorm_lon.py:136) or 3 (+ sin/cos day of year, …_doy.py:135):
+ * every `cond` below is then [B,nd,nd,n_cond_channels], the generator's Dense has 100 + nd*nd*n_cond_channels
+ * inputs and the critic's first Conv3D 1 + n_cond_channels input channels. */
 int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels, int max_batch);
 void rdgan_destroy(rdgan_handle* h);
 const char* rdgan_last_error(const rdgan_handle* h);

@@ -18,6 +18,22 @@ def gather_real(data, indices_all, ixs, ndomain, norm_scale=127.4):
     return batch, batch_cond
 
 
+def extra_condition(batch_cond, idcs_batch, ndomain, kind, timelist_all=None, min_lonidx=0, max_lonidx=1):
+    """The extra condition channels of revision1/additional_inputs, per sample loops instead of the reference's
+    tile + transpose: 'lon' (…_lon.py:175-184) appends (xidx - min_lonidx)/max_lonidx, 'doy' (…_doy.py:173-186)
+    appends sin and cos of 2 pi doy/365 with doy = timelist_all[tidx]; each constant over the tile."""
+    n = len(idcs_batch)
+    nex = 1 if kind == "lon" else 2
+    extra = np.empty((n, ndomain, ndomain, nex), np.float64)
+    for i, (t, y, x) in enumerate(idcs_batch):
+        if kind == "lon":
+            extra[i, :, :, 0] = (x - min_lonidx) / max_lonidx
+        else:
+            extra[i, :, :, 0] = np.sin(2 * np.pi * timelist_all[t] / 365)
+            extra[i, :, :, 1] = np.cos(2 * np.pi * timelist_all[t] / 365)
+    return np.concatenate([batch_cond, extra], axis=-1)
+
+
 def valid_indices(data, ndomain=16, stride=16, tp_thresh_daily=5, n_thresh=20):
     """V:74-92 (the numba loop, plain numpy)."""
     n_days, _, ny, nx = data.shape

@@ -46,11 +46,12 @@ static RdPlan plan_conv_fwd(int D, int H, int W, int Cin, int Cout, int Do, int 
 }
 
 // D1 (T:286): 2-channel input, stride 2, 'valid'.  (kw, ci) is contiguous in NDHWC with C = 2, so the
-// 27x2 taps are gathered as 9 taps (kd,kh) x 6 contiguous floats.
-static RdPlan plan_d1_fwd(int nd, int Do, int Ho, int Wo) {
+// 27 x CP taps are gathered as 9 taps (kd,kh) x 3*CP contiguous floats (CP = floats per voxel: 2, or 4 with the
+// extra condition channels of the revision-1 variants).
+static RdPlan plan_d1_fwd(int nd, int Do, int Ho, int Wo, int CP) {
   RdPlan p; memset(&p, 0, sizeof(p));
-  p.nphases = 1; p.SD = RDGAN_NHOURS; p.SH = nd; p.SW = nd; p.s_shift = 0; p.s_cstride = 2; p.SC = 6;
-  p.w_rows_per_tap = 6; p.DD = Do; p.DH = Ho; p.DW = Wo; p.d_cstride = 64; p.N = 64;
+  p.nphases = 1; p.SD = RDGAN_NHOURS; p.SH = nd; p.SW = nd; p.s_shift = 0; p.s_cstride = CP; p.SC = 3 * CP;
+  p.w_rows_per_tap = 3 * CP; p.DD = Do; p.DH = Ho; p.DW = Wo; p.d_cstride = 64; p.N = 64;
   RdPhase& q = p.ph[0];
   phase_defaults(q, Do, Ho, Wo);
   for (int a = 0; a < 3; ++a) q.s_mul[a] = 2;
@@ -239,6 +240,7 @@ enum {
 
 struct rdgan_handle {
   int nd, s, MB, NB;
+  int nc, Cin, CP, ldp1;       // condition channels, critic input channels 1+nc, floats per input voxel, P1 columns
   std::string err;
   // layouts
   long goff[10], gsz[10], doff[10], dsz[10], n_gen, n_critic;
@@ -262,7 +264,7 @@ struct rdgan_handle {
   float *cin, *dh[5], *du[5], *v, *P1, *g0, *gpv;
   float *wpartial, *cpartial, *kpartial;
   size_t wpartial_cap = 0, cpartial_cap = 0, kpartial_cap = 0;
-  float *DWT[5], *W1T, *GWT[4], *W9T;
+  float *DWT[5], *W1T, *GWT[4], *W9T, *W1P, *dW1P;
   float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
   int collapse = 1;               // 1: 8-tap collapsed generator blocks (default); 0: direct 27-tap form
   int wave_spec = 1;              // 1: producer/consumer (wave-specialised, LDS-DMA) kernel for the big clean GEMMs
@@ -611,11 +613,13 @@ static void tf_same(int n, int& out, int& before) {
 extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels, int max_batch) {
   if (!out) return -2;
   *out = nullptr;
-  if (ndomain < 8 || ndomain % 8 || ndomain > 120 || n_cond_channels != 1 || max_batch < 1) return -2;
+  if (ndomain < 8 || ndomain % 8 || ndomain > 120 || n_cond_channels < 1 || n_cond_channels > 3 || max_batch < 1) return -2;
   rdgan_handle* h = new rdgan_handle();
   h->nd = ndomain; h->s = ndomain / 8; h->MB = max_batch; h->NB = 3 * max_batch;
+  h->nc = n_cond_channels; h->Cin = 1 + n_cond_channels; h->CP = n_cond_channels == 1 ? 2 : 4;
+  h->ldp1 = (27 * h->Cin + 63) / 64 * 64;
   const int nd = ndomain, s = h->s;
-  h->n_in = RDGAN_LATENT_DIM + nd * nd;            // T:322-323
+  h->n_in = RDGAN_LATENT_DIM + nd * nd * n_cond_channels;   // T:322-323
   h->n_nodes = 256 * s * s * 3;                    // T:318, L:325
   // generator grids (T:328-341)
   const int gch[4] = {256, 256, 128, 64};
@@ -625,7 +629,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->gch[l] = gch[l];
   }
   // critic grids (T:286-299)
-  const int dch[5] = {2, 64, 128, 256, 256};
+  const int dch[5] = {h->Cin, 64, 128, 256, 256};
   h->ddim[0][0] = RDGAN_NHOURS; h->ddim[0][1] = nd; h->ddim[0][2] = nd;
   for (int l = 1; l <= 4; ++l)
     for (int a = 0; a < 3; ++a) {
@@ -638,7 +642,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
   {
     long gs[10] = {(long)h->n_in * h->n_nodes, h->n_nodes, 27L * 256 * 256, 256, 27L * 256 * 128, 128,
                    27L * 128 * 64, 64, 27L * 64, 1};
-    long ds[10] = {27L * 2 * 64, 64, 27L * 64 * 128, 128, 27L * 128 * 256, 256, 27L * 256 * 256, 256, h->F, 1};
+    long ds[10] = {27L * h->Cin * 64, 64, 27L * 64 * 128, 128, 27L * 128 * 256, 256, 27L * 256 * 256, 256, h->F, 1};
     long o = 0;
     for (int i = 0; i < 10; ++i) { h->goff[i] = o; h->gsz[i] = gs[i]; o += gs[i]; }
     h->n_gen = o; o = 0;
@@ -660,13 +664,13 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->plans[PL_G9F] = plan_rows(g3[0], g3[1], g3[2], 64, 64, 32, 32);
     h->plans[PL_G9B] = plan_rows(g3[0], g3[1], g3[2], 27, 32, 64, 64);
   }
-  h->plans[PL_D1F] = plan_d1_fwd(nd, h->ddim[1][0], h->ddim[1][1], h->ddim[1][2]);
+  h->plans[PL_D1F] = plan_d1_fwd(nd, h->ddim[1][0], h->ddim[1][1], h->ddim[1][2], h->CP);
   for (int l = 2; l <= 4; ++l) {
     const int* id = h->ddim[l - 1]; const int* od = h->ddim[l]; const int* pd = h->dpad[l - 1];
     h->plans[PL_D2F + l - 2] = plan_conv_fwd(id[0], id[1], id[2], dch[l - 1], dch[l], od[0], od[1], od[2], 2, pd[0], pd[1], pd[2], 0);
     h->plans[PL_D2B + l - 2] = plan_conv_dgrad_s2(id[0], id[1], id[2], dch[l - 1], od[0], od[1], od[2], dch[l], pd);
   }
-  h->plans[PL_D1B] = plan_rows(h->ddim[1][0], h->ddim[1][1], h->ddim[1][2], 64, 64, 64, 64);
+  h->plans[PL_D1B] = plan_rows(h->ddim[1][0], h->ddim[1][1], h->ddim[1][2], 64, 64, h->ldp1, h->ldp1);
   hipError_t e = hipSuccess;
   {
     std::vector<RdRow> tab;
@@ -722,11 +726,11 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     carve(h->dy1, MB * h->gpix[1] * 256);
     carve(h->gup1, MB * h->gpix[1] * 256);
     carve(h->ga0, MB * h->gpix[0] * 256);
-    carve(h->cin, NB * h->dL[0] * 2);
+    carve(h->cin, NB * h->dL[0] * h->CP);
     h->dh[0] = nullptr; h->du[0] = nullptr;
     for (int l = 1; l <= 4; ++l) { carve(h->dh[l], NB * h->dL[l] * dch[l]); carve(h->du[l], NB * h->dL[l] * dch[l]); }
     carve(h->v, NB);
-    carve(h->P1, MB * h->dL[1] * 64);
+    carve(h->P1, MB * h->dL[1] * h->ldp1);
     carve(h->g0, MB * h->dL[0]);
     carve(h->gpv, MB);
     carve(h->wpartial, h->wpartial_cap);
@@ -734,7 +738,8 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     carve(h->kpartial, h->kpartial_cap);
     h->DWT[0] = h->DWT[1] = nullptr;
     for (int l = 2; l <= 4; ++l) carve(h->DWT[l], 27L * dch[l - 1] * dch[l]);
-    carve(h->W1T, 64 * 64);
+    carve(h->W1T, 64 * h->ldp1);
+    carve(h->W1P, 27L * h->CP * 64); carve(h->dW1P, 27L * h->CP * 64);
     h->GWT[0] = nullptr;
     for (int l = 1; l <= 3; ++l) carve(h->GWT[l], 27L * gch[l - 1] * gch[l]);
     carve(h->W9T, 64 * 32);
@@ -834,7 +839,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_concat, dim3(ew_blocks((long)B * h->n_in)), dim3(256), 0, st, z, cond, h->xcat, B,
-                       RDGAN_LATENT_DIM, nd * nd);
+                       RDGAN_LATENT_DIM, nd * nd * h->nc);
   }
   // Dense + LeakyReLU (T:326-327); the Reshape (T:328) is a view
   RD_TRY(launch_conv(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, gp + h->goff[0], h->n_nodes, h->h0,
@@ -886,9 +891,15 @@ extern "C" int rdgan_gen_forward(rdgan_handle* h, const float* gen_params, const
 static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st) {
   for (int l = 2; l <= 4; ++l)   // [27][Cin][Cout] -> [27][Cout][Cin]
     RD_TRY(launch_transpose(h, dp + h->doff[2 * (l - 1)], h->DWT[l], 27, h->dch[l - 1], h->dch[l], h->dch[l - 1], st));
-  // W1 [54][64] -> W1T [64][64] (columns (tap,ci), zero padded 54..63)
-  RD_TRY(launch_transpose(h, dp + h->doff[0], h->W1T, 1, 54, 64, 64, st));
+  // W1 [27*Cin][64] -> W1T [64][ldp1] (columns (tap,ci), zero padded)
+  RD_TRY(launch_transpose(h, dp + h->doff[0], h->W1T, 1, 27 * h->Cin, 64, h->ldp1, st));
+  if (h->CP != h->Cin) hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, dp + h->doff[0], h->W1P, h->Cin, h->CP);
   return 0;
+}
+
+// D1's forward weights: the caller's [27][Cin][64] kernel, or its zero-padded [27][CP][64] copy when CP > Cin
+static inline const float* d1_weights(const rdgan_handle* h, const float* dp) {
+  return h->CP != h->Cin ? h->W1P : dp + h->doff[0];
 }
 
 // forward over NBt samples already laid out in h->cin; writes h->dh[1..4], h->v
@@ -897,7 +908,8 @@ static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64
   const float* in = h->cin;
   for (int l = 1; l <= 4; ++l) {
     int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
-    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, in, dp + h->doff[2 * (l - 1)], h->dch[l], h->dh[l],
+    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
+                       h->dch[l], h->dh[l],
                        epi_make(RD_EPI_BIAS_LRELU_DROP, dp + h->doff[2 * (l - 1) + 1], nullptr, use_drop,
                                 rd_make_key(seed, RD_STREAM_D1 + l - 1), 0),
                        st, RDGAN_TAG_CRITIC_GEMM));
@@ -928,11 +940,11 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
 
 // dD/d(sample channel) for `B` samples whose u1 starts at u1: column GEMM + col2im -> h->g0
 static int critic_input_grad(rdgan_handle* h, const float* u1, int B, hipStream_t st) {
-  RD_TRY(launch_conv(h, h->plans[PL_D1B], h->d_plans + PL_D1B, B, u1, h->W1T, 64, h->P1, epi_make(RD_EPI_PLAIN), st,
+  RD_TRY(launch_conv(h, h->plans[PL_D1B], h->d_plans + PL_D1B, B, u1, h->W1T, h->ldp1, h->P1, epi_make(RD_EPI_PLAIN), st,
                      RDGAN_TAG_CRITIC_GEMM));
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
   hipLaunchKernelGGL(k_d1_col2im, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, h->P1, h->g0, B, h->ddim[0][0],
-                     h->ddim[0][1], h->ddim[0][2], h->ddim[1][0], h->ddim[1][1], h->ddim[1][2]);
+                     h->ddim[0][1], h->ddim[0][2], h->ddim[1][0], h->ddim[1][1], h->ddim[1][2], h->Cin, h->ldp1);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -942,8 +954,10 @@ extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params,
   if (!h || !critic_params || !sample || !cond || !out) return bad_arg(h, "critic_forward: null pointer");
   if (B < 1 || B > h->NB) return bad_arg(h, "critic_forward: B outside [1, 3*max_batch]");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_build_critic_input1, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, sample, cond, h->cin,
-                     B, h->ddim[0][0], h->nd * h->nd);
+  if (h->CP != h->Cin)
+    hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, critic_params + h->doff[0], h->W1P, h->Cin, h->CP);
+  hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, sample,
+                     (const float*)nullptr, cond, h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 2, 0u);
   RD_TRY(critic_forward_impl(h, critic_params, B, seed, st));
   RD_CHECK(h, hipMemcpyAsync(out, h->v, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
   return 0;
@@ -964,16 +978,16 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, x_real, h->fake, cond,
-                       h->cin, B, h->ddim[0][0], h->nd * h->nd, 0, rd_make_key(seed, RD_STREAM_ALPHA));
+                       h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 0, rd_make_key(seed, RD_STREAM_ALPHA));
   }
   RD_TRY(critic_forward_impl(h, dp, NBt, seed, st));           // T:372,373,379 as one batch
   RD_TRY(critic_dgrad_chain(h, dp, NBt, B, 0, seed, st));       // dL/dh for real|fake, dD/dh for x_hat
   // gradient penalty (T:238-241, T:382): g0 = dD/dx_hat, n = ||g0||, r0 = d(10 mean((n-1)^2))/dg0
   RD_TRY(critic_input_grad(h, h->du[1] + (long)2 * B * h->dL[1] * 64, B, st));
-  float* cin_hat = h->cin + (long)2 * B * h->dL[0] * 2;
+  float* cin_hat = h->cin + (long)2 * B * h->dL[0] * h->CP;
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_gp_norm_r0, dim3(B), dim3(256), 0, st, h->g0, cin_hat, h->gpv, (int)h->dL[0], B, RD_GP_WEIGHT);
+    hipLaunchKernelGGL(k_gp_norm_r0, dim3(B), dim3(256), 0, st, h->g0, cin_hat, h->gpv, (int)h->dL[0], B, RD_GP_WEIGHT, h->CP);
   }
   // second forward sweep of the double backward: r_l = gate_l * conv_l(r_{l-1}), in place over the x_hat third
   {
@@ -982,7 +996,8 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
       int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
       long third = (long)2 * B * h->dL[l] * h->dch[l];
       float* dst = h->dh[l] + third;
-      RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, in, dp + h->doff[2 * (l - 1)], h->dch[l], dst,
+      RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
+                         h->dch[l], dst,
                          epi_make(RD_EPI_GATE_AUX, nullptr, dst, use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 1),
                                   (uint32_t)third),
                          st, RDGAN_TAG_CRITIC_GEMM));
@@ -993,8 +1008,10 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
   for (int l = 1; l <= 4; ++l) {
     int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
     const float* in = l == 1 ? h->cin : h->dh[l - 1];
-    RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], grad + h->doff[2 * (l - 1)], h->wpartial,
-                        h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM));
+    const bool padded = l == 1 && h->CP != h->Cin;   // D1 with padding channels: gradient of the padded kernel, then drop the pad rows
+    RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], padded ? h->dW1P : grad + h->doff[2 * (l - 1)],
+                        h->wpartial, h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM));
+    if (padded) hipLaunchKernelGGL(k_unpad_w1, dim3(27), dim3(256), 0, st, h->dW1P, grad + h->doff[0], h->Cin, h->CP);
     // bias gradient: only the real|fake passes reach the loss through the bias (the penalty term does not)
     RD_TRY(launch_colsum(h, h->du[l], (long)2 * B * h->dL[l], h->dch[l], grad + h->doff[2 * (l - 1) + 1], st));
   }
@@ -1028,7 +1045,7 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, (const float*)nullptr,
-                       h->fake, cond, h->cin, B, h->ddim[0][0], nd * nd, 1, 0u);
+                       h->fake, cond, h->cin, B, h->ddim[0][0], nd * nd, h->nc, h->CP, 1, 0u);
   }
   RD_TRY(critic_forward_impl(h, dp, B, seed, st));              // critic frozen, dropout active (T:395,405)
   RD_TRY(critic_dgrad_chain(h, dp, B, B, 1, seed, st));

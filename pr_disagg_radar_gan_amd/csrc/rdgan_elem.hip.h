@@ -226,40 +226,35 @@ __global__ void k_dl_im2col(const float* __restrict__ dl, float* __restrict__ co
   }
 }
 
-// D0 + X1 (T:275-282, T:221-224): 2-channel critic input (sample | cond repeated over the 24 hours).
+// D0 + X1 (T:275-282, T:221-224): critic input with CP floats per voxel = (sample | nc condition channels repeated
+// over the 24 hours | zero padding): CP = 2 for nc = 1, CP = 4 for nc = 2 or 3 (revision1/additional_inputs variants).
 // mode 0: out[0:B] = real, out[B:2B] = fake, out[2B:3B] = alpha*real + (1-alpha)*fake, alpha = uniform(key, b)
-// mode 1: out[0:B] = fake only (generator step).
+// mode 1: out[0:B] = fake only (generator step);  mode 2: out[0:B] = real only (critic.predict).
 __global__ void k_build_critic_input(const float* __restrict__ real, const float* __restrict__ fake,
                                      const float* __restrict__ cond, float* __restrict__ out, int B, int D, int HW,
-                                     int mode, uint32_t alpha_key) {
+                                     int nc, int CP, int mode, uint32_t alpha_key) {
   const long per = (long)D * HW;
   const long total = (long)B * per;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     long b = f / per;
     long r = f - b * per;
     int hw = (int)(r % HW);
-    float c = cond[b * HW + hw];
-    float fk = fake[f];
+    float c[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < nc; ++k) c[k] = cond[(b * HW + hw) * nc + k];
+    auto put = [&](long vox, float x) {
+      float* o = out + vox * CP;
+      o[0] = x;
+      for (int k = 1; k < CP; ++k) o[k] = k - 1 < nc ? c[k - 1] : 0.f;
+    };
     if (mode == 0) {
-      float rl = real[f];
+      float rl = real[f], fk = fake[f];
       float a = rd_uniform(alpha_key, (uint32_t)b);
-      float xh = a * rl + (1.0f - a) * fk;
-      *(float2*)(out + 2 * f) = make_float2(rl, c);
-      *(float2*)(out + 2 * (total + f)) = make_float2(fk, c);
-      *(float2*)(out + 2 * (2 * total + f)) = make_float2(xh, c);
+      put(f, rl); put(total + f, fk); put(2 * total + f, a * rl + (1.0f - a) * fk);
+    } else if (mode == 1) {
+      put(f, fake[f]);
     } else {
-      *(float2*)(out + 2 * f) = make_float2(fk, c);
+      put(f, real[f]);
     }
-  }
-}
-// 2-channel critic input from an arbitrary sample (critic_forward entry point)
-__global__ void k_build_critic_input1(const float* __restrict__ x, const float* __restrict__ cond,
-                                      float* __restrict__ out, int B, int D, int HW) {
-  const long per = (long)D * HW, total = (long)B * per;
-  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
-    long b = f / per;
-    int hw = (int)((f - b * per) % HW);
-    *(float2*)(out + 2 * f) = make_float2(x[f], cond[b * HW + hw]);
   }
 }
 
@@ -364,7 +359,7 @@ k_reduce_partials(const float* __restrict__ partial, int nsplit, int n, float* _
 // g0[b][pos] = sum over taps t with (pos - t) even and o = (pos - t)/2 inside D1's output of
 // P[b][o][(t, ci=0)], where P[row][tap*2+ci] = u1[row][:] . W1[tap][ci][:]   (D1: stride 2, 'valid', T:286)
 __global__ void k_d1_col2im(const float* __restrict__ P, float* __restrict__ g0, int B, int D, int H, int W, int Do,
-                            int Ho, int Wo) {
+                            int Ho, int Wo, int Cin, int ldp) {
   const long total = (long)B * D * H * W;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     long t = f;
@@ -383,7 +378,7 @@ __global__ void k_d1_col2im(const float* __restrict__ P, float* __restrict__ g0,
           int ow = (w - tw) >> 1;
           if (w - tw < 0 || ow >= Wo) continue;
           long row = ((b * Do + od) * Ho + oh) * Wo + ow;
-          s += P[row * 64 + ((td * 3 + th) * 3 + tw) * 2];
+          s += P[row * ldp + ((td * 3 + th) * 3 + tw) * Cin];
         }
       }
     }
@@ -395,7 +390,7 @@ __global__ void k_d1_col2im(const float* __restrict__ P, float* __restrict__ g0,
 // (10/B) * 2 (n-1)/n * g0, written as the 2-channel (r0, 0) input of the second forward sweep into the
 // interpolated third of the critic-input buffer.  One block per sample.
 __global__ void k_gp_norm_r0(const float* __restrict__ g0, float* __restrict__ cin_hat, float* __restrict__ gp_out,
-                             int per, int B, float gp_weight) {
+                             int per, int B, float gp_weight, int CP) {
   __shared__ float red[4];
   __shared__ float coef_s;
   const long b = blockIdx.x;
@@ -409,8 +404,11 @@ __global__ void k_gp_norm_r0(const float* __restrict__ g0, float* __restrict__ c
   }
   __syncthreads();
   const float coef = coef_s;
-  for (int i = threadIdx.x; i < per; i += blockDim.x)
-    *(float2*)(cin_hat + 2 * (b * per + i)) = make_float2(coef * g0[b * per + i], 0.f);
+  for (int i = threadIdx.x; i < per; i += blockDim.x) {
+    float* o = cin_hat + (long)CP * (b * per + i);
+    o[0] = coef * g0[b * per + i];
+    for (int k = 1; k < CP; ++k) o[k] = 0.f;
+  }
 }
 
 // X3 (T:215-216, T:388-392): losses of the critic step as Keras reports them:
@@ -559,5 +557,21 @@ __global__ void k_lrelu_bwd(const float* __restrict__ g, const float* __restrict
     gv.x *= rd_lrelu_slope_from_out(hv.x); gv.y *= rd_lrelu_slope_from_out(hv.y);
     gv.z *= rd_lrelu_slope_from_out(hv.z); gv.w *= rd_lrelu_slope_from_out(hv.w);
     *(f32x4*)(out + 4 * i) = gv;
+  }
+}
+
+// first critic layer with CP > Cin: zero rows for the padding channels (forward copy) and their removal (gradient)
+__global__ void k_pad_w1(const float* __restrict__ w, float* __restrict__ wp, int Cin, int CP) {
+  const int total = 27 * CP * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int co = i % 64, c = (i / 64) % CP, t = i / (64 * CP);
+    wp[i] = c < Cin ? w[(t * Cin + c) * 64 + co] : 0.f;
+  }
+}
+__global__ void k_unpad_w1(const float* __restrict__ wp, float* __restrict__ w, int Cin, int CP) {
+  const int total = 27 * Cin * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int co = i % 64, c = (i / 64) % Cin, t = i / (64 * Cin);
+    w[i] = wp[(t * CP + c) * 64 + co];
   }
 }

@@ -30,8 +30,39 @@ class DeviceDataset:
         self.data = torch.from_numpy(np.ascontiguousarray(data)).to(self.device)
         self.flags = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.indices = None
+        self.extra = None
         if indices is not None:
             self.set_indices(indices)
+
+    def set_extra_condition(self, kind, timelist=None, min_lonidx=0, max_lonidx=1):
+        """Extra condition channels of the revision-1 variants, appended behind the daily sum by gather():
+        'lon' -> (xidx - min_lonidx) / max_lonidx (…_lon.py:175-184); 'doy' -> sin, cos of 2 pi doy / 365 with
+        doy = timelist[tidx] (…_doy.py:173-186); None -> the one-channel condition."""
+        if kind is None:
+            self.extra = None
+        elif kind == 'lon':
+            self.extra = ('lon', float(min_lonidx), float(max_lonidx))
+        elif kind == 'doy':
+            tl = np.asarray(timelist, dtype=np.float64)
+            if tl.shape != (self.n_days,):
+                raise ValueError("timelist must hold one day-of-year value per day of the data array")
+            self.extra = ('doy', torch.from_numpy(tl).to(self.device))
+        else:
+            raise ValueError("extra condition kind must be None, 'lon' or 'doy'")
+
+    @property
+    def n_cond_channels(self):
+        return 1 if self.extra is None else (2 if self.extra[0] == 'lon' else 3)
+
+    def _extra_channels(self, sel, cond):
+        nd = self.ndomain
+        if self.extra[0] == 'lon':
+            vals = [(sel[:, 2].double() - self.extra[1]) / self.extra[2]]
+        else:
+            ang = 2 * np.pi * self.extra[1][sel[:, 0].long()] / 365
+            vals = [torch.sin(ang), torch.cos(ang)]
+        planes = [v.float().view(-1, 1, 1, 1).expand(-1, nd, nd, 1) for v in vals]
+        return torch.cat([cond] + planes, dim=-1).contiguous()
 
     def set_indices(self, indices):
         idx = np.ascontiguousarray(np.asarray(indices), dtype=np.int32)
@@ -46,7 +77,7 @@ class DeviceDataset:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def gather(self, ixs, with_batch=True):
-        """tiles at self.indices[ixs] -> (fractions (n,24,nd,nd,1) or None, cond (n,nd,nd,1)) device tensors"""
+        """tiles at self.indices[ixs] -> (fractions (n,24,nd,nd,1) or None, cond (n,nd,nd,n_cond_channels)) device tensors"""
         ixs = torch.as_tensor(ixs, dtype=torch.long, device=self.device)
         sel = self.indices[ixs].contiguous()
         n, nd = sel.shape[0], self.ndomain
@@ -55,6 +86,8 @@ class DeviceDataset:
         rc = self.lib.rdgan_data_gather(_p(self.data), self.n_days, self.ny, self.nx, _p(sel), n, nd, self.norm_scale,
                                         _p(batch) if with_batch else ctypes.c_void_p(0), _p(cond), _p(self.flags), self._stream())
         _lib.check(rc, None, "rdgan_data_gather")
+        if self.extra is not None:
+            cond = self._extra_channels(sel, cond)
         return batch, cond
 
     def check_flags(self):

@@ -37,16 +37,18 @@ class Engine:
         self.lib = _lib.load()
         self.ndomain = int(ndomain)
         self.max_batch = int(max_batch)
+        self.n_cond_channels = int(n_cond_channels)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            rc = self.lib.rdgan_create(ctypes.byref(self._h), self.ndomain, int(n_cond_channels), self.max_batch)
+            rc = self.lib.rdgan_create(ctypes.byref(self._h), self.ndomain, self.n_cond_channels, self.max_batch)
         if rc != 0:
-            raise _lib.RdganError(f"rdgan_create(ndomain={ndomain}, max_batch={max_batch}) failed with code {rc}")
+            raise _lib.RdganError(f"rdgan_create(ndomain={ndomain}, n_cond_channels={n_cond_channels}, max_batch={max_batch}) "
+                                  f"failed with code {rc}")
         self.n_gen = int(self.lib.rdgan_gen_param_count(self._h))
         self.n_critic = int(self.lib.rdgan_critic_param_count(self._h))
-        self.gen_shapes = W.gen_param_shapes(self.ndomain)
-        self.critic_shapes = W.critic_param_shapes(self.ndomain)
+        self.gen_shapes = W.gen_param_shapes(self.ndomain, self.n_cond_channels)
+        self.critic_shapes = W.critic_param_shapes(self.ndomain, self.n_cond_channels)
         assert self.n_gen == W.param_count(self.gen_shapes) and self.n_critic == W.param_count(self.critic_shapes)
 
     def close(self):
@@ -81,7 +83,7 @@ class Engine:
         self._check_batch(B, self.max_batch)
         _chk_tensor(gen_params, (self.n_gen,), "gen_params")
         _chk_tensor(z, (B, W.LATENT_DIM), "z")
-        _chk_tensor(cond, (B, nd, nd, 1), "cond")
+        _chk_tensor(cond, (B, nd, nd, self.n_cond_channels), "cond")
         if out is None:
             out = torch.empty((B, W.NHOURS, nd, nd, 1), dtype=torch.float32, device=self.device)
         _chk_tensor(out, (B, W.NHOURS, nd, nd, 1), "out")
@@ -95,7 +97,7 @@ class Engine:
         self._check_batch(B, 3 * self.max_batch)
         _chk_tensor(critic_params, (self.n_critic,), "critic_params")
         _chk_tensor(sample, (B, W.NHOURS, nd, nd, 1), "sample")
-        _chk_tensor(cond, (B, nd, nd, 1), "cond")
+        _chk_tensor(cond, (B, nd, nd, self.n_cond_channels), "cond")
         out = torch.empty((B, 1), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.rdgan_critic_forward(self._h, _ptr(critic_params), _ptr(sample), _ptr(cond), _ptr(out), B,
                                                  ctypes.c_uint64(seed), self._stream()), self._h, "rdgan_critic_forward")
@@ -108,7 +110,7 @@ class Engine:
         _chk_tensor(critic_params, (self.n_critic,), "critic_params")
         _chk_tensor(gen_params, (self.n_gen,), "gen_params")
         _chk_tensor(x_real, (B, W.NHOURS, nd, nd, 1), "x_real")
-        _chk_tensor(cond, (B, nd, nd, 1), "cond")
+        _chk_tensor(cond, (B, nd, nd, self.n_cond_channels), "cond")
         _chk_tensor(z, (B, W.LATENT_DIM), "z")
         if grad_out is None:
             grad_out = torch.empty(self.n_critic + LOSS_SLOTS, dtype=torch.float32, device=self.device)
@@ -125,7 +127,7 @@ class Engine:
         _chk_tensor(critic_params, (self.n_critic,), "critic_params")
         _chk_tensor(gen_params, (self.n_gen,), "gen_params")
         _chk_tensor(z, (B, W.LATENT_DIM), "z")
-        _chk_tensor(cond, (B, nd, nd, 1), "cond")
+        _chk_tensor(cond, (B, nd, nd, self.n_cond_channels), "cond")
         if grad_out is None:
             grad_out = torch.empty(self.n_gen + LOSS_SLOTS, dtype=torch.float32, device=self.device)
         _chk_tensor(grad_out, (self.n_gen + LOSS_SLOTS,), "grad_out")

@@ -40,7 +40,7 @@ n_epoch_and_batch_size_list = ((50, 32),)
 plot_format = 'png'
 name = 'wgancp_pixelnorm'
 nhours = 24 // tres
-n_channel = 1
+n_channel = 1             # 2: + longitude index (revision1/additional_inputs/…_lon.py:126,136), 3: + sin/cos day of year (…_doy.py:135)
 
 plotdir = f'plots_{name}/'
 outdir = f'trained_models/{name}/'
@@ -55,6 +55,8 @@ def _params():
 params = _params()        # reference :113 -- names every artefact
 data = None               # (n_days, 24, ny, nx) float32, np.load(mmap_mode='r') (reference :117)
 indices_all = None        # (n_samples, 3) rows (tidx, yidx, xidx) (reference :120-124)
+timelist_all = None       # (n_days,) day of year, n_channel == 3 only (…_doy.py:128, reformat_data_make_timelist.py)
+min_lonidx = max_lonidx = 0   # n_channel == 2 only (…_lon.py:126-127)
 n_samples = 0
 generator = None
 critic = None
@@ -74,29 +76,37 @@ def configure(**kw):
         g[k] = v
     if ndomain % 8:
         raise ValueError("ndomain must be a multiple of 8 (reference L:324)")
+    if n_channel not in (1, 2, 3):
+        raise ValueError("n_channel must be 1 (daily sum), 2 (+ longitude) or 3 (+ sin/cos day of year)")
     params = _params()
 
 
 # ---- data (reference :111-140)
-def load_data(data_ifile=None, indices_file=None):
-    global data, indices_all, n_samples
+def load_data(data_ifile=None, indices_file=None, timelist_ifile=None):
+    global data, indices_all, n_samples, timelist_all
     data_ifile = data_ifile or f'{converted_data_path}/{startdate}-{enddate}_tres{tres}.npy'
     indices_file = indices_file or f'{indices_data_path}/valid_indices_smhi_radar_{params}.pkl'
     data = np.load(data_ifile, mmap_mode='r')
     with open(indices_file, 'rb') as f:
         indices_all = np.array(pickle.load(f))
+    if n_channel == 3:                                                        # …_doy.py:114,128
+        timelist_all = np.load(timelist_ifile or f'{converted_data_path}/{startdate}-{enddate}_tres{tres}_doy.npy')
     _check_data()
 
 
-def use_arrays(data_array, indices):
+def use_arrays(data_array, indices, timelist=None):
     """Train on in-memory arrays (tests, synthetic data) instead of the reference's files."""
-    global data, indices_all, n_samples
+    global data, indices_all, n_samples, timelist_all
     data, indices_all = data_array, np.asarray(indices)
+    timelist_all = None if timelist is None else np.asarray(timelist)
     _check_data()
 
 
 def _check_data():
-    global n_samples
+    global n_samples, min_lonidx, max_lonidx
+    if n_channel == 3 and (timelist_all is None or len(timelist_all) != data.shape[0]):
+        raise ValueError("n_channel == 3 needs the day-of-year list, one entry per day of the data array")
+    min_lonidx, max_lonidx = np.min(indices_all[:, 2]), np.max(indices_all[:, 2])      # …_lon.py:126-127
     n_days, nh, ny, nx = data.shape
     assert len(indices_all.shape) == 2 and indices_all.shape[1] == 3        # reference :131-138
     assert nh == 24 // tres
@@ -115,6 +125,10 @@ def use_device_dataset(enable=True):
         return None
     from .data_pipeline import DeviceDataset
     device_dataset = DeviceDataset(np.asarray(data), indices_all, ndomain=ndomain, norm_scale=norm_scale)
+    if n_channel == 2:
+        device_dataset.set_extra_condition('lon', min_lonidx=min_lonidx, max_lonidx=max_lonidx)
+    elif n_channel == 3:
+        device_dataset.set_extra_condition('doy', timelist=timelist_all)
     return device_dataset
 
 
@@ -128,14 +142,30 @@ def _gather_tiles(ixs):
     return out
 
 
+def _add_extra_condition(batch_cond, idcs_batch):
+    """The extra condition channels of the revision-1 variants, constant over each tile: the normalised
+    longitude index (…_lon.py:175-184) or sin/cos of the day of year (…_doy.py:173-186)."""
+    if n_channel == 1:
+        return batch_cond
+    plane = np.ones((1, ndomain, ndomain, 1))
+    if n_channel == 2:
+        lon = (idcs_batch[:, 2] - min_lonidx) / max_lonidx
+        extra = [lon[:, None, None, None] * plane]
+    else:
+        doy = timelist_all[idcs_batch[:, 0]]
+        extra = [np.sin(2 * np.pi * doy / 365)[:, None, None, None] * plane,
+                 np.cos(2 * np.pi * doy / 365)[:, None, None, None] * plane]
+    return np.concatenate([batch_cond] + extra, axis=-1)
+
+
 def _real_batch(n_batch):
     ixs = np.random.randint(n_samples, size=n_batch)
     batch = _gather_tiles(ixs)[..., None]
     batch_cond = np.sum(batch, axis=1)                     # daily sum = the condition
     batch = batch / batch_cond[:, None]                     # fractions of the daily sum (reference :162-163)
-    batch_cond = batch_cond / norm_scale
+    batch_cond = _add_extra_condition(batch_cond / norm_scale, indices_all[ixs])
     assert batch.shape == (n_batch, nhours, ndomain, ndomain, 1)
-    assert batch_cond.shape == (n_batch, ndomain, ndomain, 1)
+    assert batch_cond.shape == (n_batch, ndomain, ndomain, n_channel)
     assert not np.any(np.isnan(batch)) and not np.any(np.isnan(batch_cond))
     assert np.max(batch) <= 1 and np.min(batch) >= 0
     return batch.astype(np.float32), batch_cond.astype(np.float32)
@@ -151,8 +181,8 @@ def generate_latent_points(n_batch):
     """reference :177-193: latent ~ N(0,1) and the normalised daily sums of random real tiles."""
     latent = np.random.normal(size=(n_batch, latent_dim))
     ixs = np.random.randint(0, n_samples, size=n_batch)
-    batch_cond = np.sum(_gather_tiles(ixs)[..., None], axis=1) / norm_scale
-    assert batch_cond.shape == (n_batch, ndomain, ndomain, 1) and not np.any(np.isnan(batch_cond))
+    batch_cond = _add_extra_condition(np.sum(_gather_tiles(ixs)[..., None], axis=1) / norm_scale, indices_all[ixs])
+    assert batch_cond.shape == (n_batch, ndomain, ndomain, n_channel) and not np.any(np.isnan(batch_cond))
     return [latent, batch_cond.astype(np.float32)]
 
 
@@ -224,13 +254,13 @@ class GradientPenalty:
 def create_generator(seed=None):
     """RandomNormal(stddev=0.02) kernels, zero biases (reference :315)."""
     rng = np.random.default_rng(seed)
-    return models.Generator(W.init_generator(rng, ndomain), ndomain)
+    return models.Generator(W.init_generator(rng, ndomain, n_channel), ndomain, n_channel)
 
 
 def create_discriminator(seed=None):
     """Keras-default glorot_uniform kernels, zero biases (reference :286-304)."""
     rng = np.random.default_rng(seed)
-    return models.Critic(W.init_critic(rng, ndomain), ndomain)
+    return models.Critic(W.init_critic(rng, ndomain, n_channel), ndomain, n_channel)
 
 
 def build_networks(seed=None):
@@ -249,7 +279,7 @@ def _get_trainer(per_rank_batch):
     from .trainer import WGANGPTrainer
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    eng = models.get_engine(ndomain, per_rank_batch)
+    eng = models.get_engine(ndomain, per_rank_batch, n_channel)
     if _trainer is None or _trainer.eng is not eng:
         _trainer = WGANGPTrainer(eng, generator.get_weights(), critic.get_weights(), n_disc=n_disc,
                                  world_size=world, rank=rank, process_group=dist.group.WORLD if world > 1 else None)

@@ -10,17 +10,17 @@ from . import weights as W
 _ENGINES = {}
 
 
-def get_engine(ndomain, min_batch):
-    """One engine per (device, ndomain); regrown when a bigger batch is requested."""
+def get_engine(ndomain, min_batch, n_cond_channels=1):
+    """One engine per (device, ndomain, n_cond_channels); regrown when a bigger batch is requested."""
     import torch
     from .engine import Engine, require_gpu
     require_gpu()
-    key = (torch.cuda.current_device(), int(ndomain))
+    key = (torch.cuda.current_device(), int(ndomain), int(n_cond_channels))
     eng = _ENGINES.get(key)
     if eng is None or eng.max_batch < min_batch:
         if eng is not None:
             eng.close()
-        eng = Engine(ndomain=ndomain, max_batch=max(int(min_batch), 32))
+        eng = Engine(ndomain=ndomain, max_batch=max(int(min_batch), 32), n_cond_channels=n_cond_channels)
         _ENGINES[key] = eng
     return eng
 
@@ -28,9 +28,10 @@ def get_engine(ndomain, min_batch):
 class _Model:
     kind = None
 
-    def __init__(self, arrays, ndomain):
+    def __init__(self, arrays, ndomain, n_cond_channels=1):
         self.ndomain = int(ndomain)
-        self.shapes = W.gen_param_shapes(ndomain) if self.kind == "generator" else W.critic_param_shapes(ndomain)
+        self.n_cond_channels = nc = int(n_cond_channels)
+        self.shapes = W.gen_param_shapes(ndomain, nc) if self.kind == "generator" else W.critic_param_shapes(ndomain, nc)
         self.trainable = True
         self._slab = None
         self.set_weights(arrays)
@@ -83,7 +84,7 @@ class Generator(_Model):
             def __init__(self, shape):
                 self.shape = shape
         nd = self.ndomain
-        return [_In((None, W.LATENT_DIM)), _In((None, nd, nd, 1))]
+        return [_In((None, W.LATENT_DIM)), _In((None, nd, nd, self.n_cond_channels))]
 
     def predict(self, inputs, batch_size=None, verbose=0):
         """generator.predict([latent, cond]) -> float32 ndarray (n, 24, nd, nd, 1)."""
@@ -91,11 +92,11 @@ class Generator(_Model):
         latent, cond = inputs
         latent = np.ascontiguousarray(latent, dtype=np.float32)
         cond = np.ascontiguousarray(cond, dtype=np.float32)
-        n, nd = latent.shape[0], self.ndomain
-        if latent.shape != (n, W.LATENT_DIM) or cond.shape != (n, nd, nd, 1):
-            raise ValueError(f"predict expects latent (n,{W.LATENT_DIM}) and cond (n,{nd},{nd},1); got {latent.shape}, {cond.shape}")
+        n, nd, nc = latent.shape[0], self.ndomain, self.n_cond_channels
+        if latent.shape != (n, W.LATENT_DIM) or cond.shape != (n, nd, nd, nc):
+            raise ValueError(f"predict expects latent (n,{W.LATENT_DIM}) and cond (n,{nd},{nd},{nc}); got {latent.shape}, {cond.shape}")
         chunk = int(batch_size or min(n, 1024))
-        eng = get_engine(nd, chunk)
+        eng = get_engine(nd, chunk, nc)
         slab = self.device_slab(eng)
         out = np.empty((n, W.NHOURS, nd, nd, 1), np.float32)
         for i in range(0, n, chunk):
@@ -116,7 +117,7 @@ class Critic(_Model):
         cond = np.ascontiguousarray(cond, dtype=np.float32)
         n, nd = sample.shape[0], self.ndomain
         chunk = int(batch_size or min(n, 1024))
-        eng = get_engine(nd, max(1, (chunk + 2) // 3))
+        eng = get_engine(nd, max(1, (chunk + 2) // 3), self.n_cond_channels)
         chunk = min(chunk, 3 * eng.max_batch)
         slab = self.device_slab(eng)
         out = np.empty((n, 1), np.float32)
@@ -130,4 +131,4 @@ class Critic(_Model):
 def load_generator(path):
     """tf.keras.models.load_model(generator_file, compile=False, custom_objects=...) (reference P:43-45)."""
     arrays = W.load_weights(path)
-    return Generator(arrays, W.infer_ndomain_from_gen(arrays))
+    return Generator(arrays, *W.infer_config_from_gen(arrays))

@@ -70,16 +70,16 @@ def unflatten(flat, shapes):
     return out
 
 
-def init_generator(rng, ndomain=16):
+def init_generator(rng, ndomain=16, n_cond_channels=1):
     """RandomNormal(stddev=0.02) kernels, zero biases (reference :315)."""
     return [(rng.standard_normal(s) * 0.02).astype(np.float32) if n.endswith("kernel:0") else np.zeros(s, np.float32)
-            for n, s in gen_param_shapes(ndomain)]
+            for n, s in gen_param_shapes(ndomain, n_cond_channels)]
 
 
-def init_critic(rng, ndomain=16):
+def init_critic(rng, ndomain=16, n_cond_channels=1):
     """Keras default glorot_uniform kernels, zero biases (reference :286-304 pass none)."""
     out = []
-    for n, s in critic_param_shapes(ndomain):
+    for n, s in critic_param_shapes(ndomain, n_cond_channels):
         if n.endswith("kernel:0"):
             rec = int(np.prod(s[:-2]))
             lim = math.sqrt(6.0 / (rec * s[-2] + rec * s[-1]))
@@ -89,12 +89,19 @@ def init_critic(rng, ndomain=16):
     return out
 
 
+def infer_config_from_gen(arrays):
+    """(ndomain, n_cond_channels) of a generator from its first Dense kernel [100 + nd*nd*nc, 256*(nd/8)^2*3]
+    (T:318-326; nc = 2/3 for the revision1/additional_inputs variants)."""
+    n_in, n_nodes = arrays[0].shape
+    s = int(round(math.sqrt(n_nodes / 768.0)))
+    nd = 8 * s
+    if s < 1 or 768 * s * s != n_nodes or (n_in - LATENT_DIM) % (nd * nd) or not 1 <= (n_in - LATENT_DIM) // (nd * nd) <= 3:
+        raise ValueError(f"cannot infer ndomain from a dense kernel of shape {arrays[0].shape}")
+    return nd, (n_in - LATENT_DIM) // (nd * nd)
+
+
 def infer_ndomain_from_gen(arrays):
-    n_in = arrays[0].shape[0]
-    nd = int(round(math.sqrt(n_in - LATENT_DIM)))
-    if LATENT_DIM + nd * nd != n_in:
-        raise ValueError(f"cannot infer ndomain from dense kernel with {n_in} inputs")
-    return nd
+    return infer_config_from_gen(arrays)[0]
 
 
 def save_weights(path, arrays, shapes, kind):

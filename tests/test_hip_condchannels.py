@@ -1,0 +1,144 @@
+"""-m gpu: the extra-condition variants of revision 1: condition with 2 channels (daily sum +
+longitude index, revision1/additional_inputs/gan_train_cwgangp_pixelnorm_lon.py:136) or 3 (daily sum + sin/cos of
+the day of year, …_doy.py:135).  Only the generator's Dense width (356 -> 612 / 868) and the critic's first
+Conv3D (C_in 2 -> 3 / 4) change; forward passes and both step gradients are compared with the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rdgan_torch as ot
+from pr_disagg_radar_gan_amd import Engine
+from pr_disagg_radar_gan_amd import weights as W
+from tests.hip_util import dev, rel_err
+from tests.test_hip_step import TIGHT, _grad_errors, _parity_over_batches, _t64
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(nd, nc, seed, bias_scale=0.05):
+    rng = np.random.default_rng(seed)
+    g = W.init_generator(rng, nd, nc)
+    d = W.init_critic(rng, nd, nc)
+    g = [p if p.ndim > 1 else (bias_scale * rng.standard_normal(p.shape)).astype(np.float32) for p in g]
+    d = [p if p.ndim > 1 else (bias_scale * rng.standard_normal(p.shape)).astype(np.float32) for p in d]
+    return g, d
+
+
+def _batch(B, nd, nc, seed):
+    """synthetic tiles + the extra channels as the reference builds them: constant planes per sample"""
+    x, cond, z = ot.synthetic_batch(B, nd, seed)
+    r = np.random.default_rng(seed + 1000)
+    if nc == 2:
+        extra = [r.uniform(0, 1, B)]                                   # normalised longitude index
+    else:
+        doy = r.integers(1, 366, B)
+        extra = [np.sin(2 * np.pi * doy / 365), np.cos(2 * np.pi * doy / 365)]
+    planes = [np.broadcast_to(e.astype(np.float32)[:, None, None, None], (B, nd, nd, 1)) for e in extra]
+    return x, np.ascontiguousarray(np.concatenate([cond] + planes, axis=-1)), z
+
+
+@pytest.fixture(scope="module", params=[2, 3])
+def eng(request):
+    e = Engine(ndomain=16, max_batch=8, n_cond_channels=request.param)
+    yield e
+    e.close()
+
+
+def test_param_counts(eng):
+    nc = eng.n_cond_channels
+    assert eng.n_gen == W.param_count(W.gen_param_shapes(16, nc))
+    assert eng.n_critic == W.param_count(W.critic_param_shapes(16, nc))
+    assert eng.gen_shapes[0][1] == (100 + 256 * nc, 3072)               # Dense width 612 / 868
+    assert eng.critic_shapes[0][1] == (3, 3, 3, 1 + nc, 64)
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_generator_forward(eng, B):
+    nc = eng.n_cond_channels
+    g, _ = _params(16, nc, 21)
+    x, cond, z = _batch(B, 16, nc, 3)
+    ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
+    out = eng.gen_forward(eng.to_slab(g), dev(z), dev(cond)).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-7)          # north_star tolerance: 1e-4 relative, fp32
+    assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("seed", [0, 77])
+def test_critic_forward(eng, seed):
+    nc = eng.n_cond_channels
+    _, d = _params(16, nc, 22)
+    B = 4
+    x, cond, z = _batch(B, 16, nc, 5)
+    masks = ot.critic_masks(seed, B, 16, torch.float64)
+    ref = ot.critic_forward(_t64(d), torch.from_numpy(x).double(), torch.from_numpy(cond).double(), masks).numpy()
+    out = eng.critic_forward(eng.to_slab(d), dev(x), dev(cond), seed=seed).cpu().numpy()
+    assert rel_err(out, ref) < 2e-5
+
+
+def test_critic_step_grads(eng):
+    nc = eng.n_cond_channels
+    g, d = _params(16, nc, 23)
+    B, seed = 3, 1234
+
+    def run_case(data_seed):
+        x, cond, z = _batch(B, 16, nc, data_seed)
+        losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
+                                             torch.from_numpy(cond).double(), torch.from_numpy(z).double(), seed)
+        slab = eng.critic_grad(eng.to_slab(d), eng.to_slab(g), dev(x), dev(cond), dev(z), seed).cpu().numpy()
+        n = eng.n_critic
+        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+        assert slab[n + 4] == 0.0
+        return _grad_errors(slab[:n], grads, eng.critic_shapes)
+
+    _parity_over_batches(run_case)
+
+
+def test_gen_step_grads(eng):
+    nc = eng.n_cond_channels
+    g, d = _params(16, nc, 24)
+    B, seed = 2, 4321
+
+    def run_case(data_seed):
+        x, cond, z = _batch(B, 16, nc, data_seed)
+        loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), seed)
+        slab = eng.gen_grad(eng.to_slab(d), eng.to_slab(g), dev(z), dev(cond), seed).cpu().numpy()
+        n = eng.n_gen
+        np.testing.assert_allclose(slab[n], float(loss), rtol=2e-4, atol=1e-6)
+        return _grad_errors(slab[:n], grads, eng.gen_shapes)
+
+    _parity_over_batches(run_case)
+
+
+def test_cond_shape_checked(eng):
+    g, _ = _params(16, eng.n_cond_channels, 25)
+    x, cond, z = ot.synthetic_batch(2, 16, 1)                           # one-channel condition: wrong for this engine
+    with pytest.raises(ValueError):
+        eng.gen_forward(eng.to_slab(g), dev(z), dev(cond))
+
+
+@pytest.mark.parametrize("kind", ["lon", "doy"])
+def test_device_dataset_extra_condition(kind):
+    """DeviceDataset.gather appends the planes the reference concatenates (…_lon.py:175-184, …_doy.py:173-186)."""
+    from pr_disagg_radar_gan_amd.data_pipeline import DeviceDataset
+    r = np.random.default_rng(5)
+    n_days, ny, nx, nd = 6, 40, 48, 16
+    data = r.gamma(2.0, 1.0, (n_days, 24, ny, nx)).astype(np.float32)
+    idx = np.stack([r.integers(0, n_days, 20), r.integers(0, ny - nd, 20), r.integers(0, nx - nd, 20)], 1)
+    ds = DeviceDataset(data, idx, ndomain=nd)
+    doy = r.integers(1, 366, n_days)
+    lo, hi = idx[:, 2].min(), idx[:, 2].max()
+    if kind == "lon":
+        ds.set_extra_condition("lon", min_lonidx=lo, max_lonidx=hi)
+        want = [(idx[:, 2] - lo) / hi]
+    else:
+        ds.set_extra_condition("doy", timelist=doy)
+        want = [np.sin(2 * np.pi * doy[idx[:, 0]] / 365), np.cos(2 * np.pi * doy[idx[:, 0]] / 365)]
+    batch, cond = ds.gather(np.arange(20))
+    cond = cond.cpu().numpy()
+    assert cond.shape == (20, nd, nd, ds.n_cond_channels) and ds.n_cond_channels == 1 + len(want)
+    ds.set_extra_condition(None)
+    _, cond1 = ds.gather(np.arange(20))
+    np.testing.assert_array_equal(cond[..., :1], cond1.cpu().numpy())
+    for k, w in enumerate(want):
+        np.testing.assert_allclose(cond[..., 1 + k], np.broadcast_to(w.astype(np.float32)[:, None, None], (20, nd, nd)),
+                                   rtol=0, atol=1e-7)

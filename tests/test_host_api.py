@@ -146,3 +146,47 @@ def test_training_data_plumbing():
     np.testing.assert_allclose(pn, 3 / np.sqrt(9 + 1e-8))
     gp = T.GradientPenalty()(np.ones((2, 3, 1, 1, 1)))
     np.testing.assert_allclose(gp, np.sqrt(3) - 1)
+
+
+def test_extra_condition_variants():
+    """n_channel = 2 / 3 (revision1/additional_inputs): shapes, values of the appended planes, config inference."""
+    from oracle import data_np as od
+    rng = np.random.default_rng(1)
+    data = rng.gamma(0.3, 2.0, (6, 24, 40, 48)).astype(np.float32) + 1e-3
+    idx = np.array([(t, y, x) for t in range(6) for y in (0, 16) for x in (3, 24, 30)])
+    doy = np.array([1, 90, 180, 200, 300, 365])
+    try:
+        for nc, kind in ((2, "lon"), (3, "doy")):
+            T.configure(ndomain=16, n_channel=nc)
+            if nc == 3:
+                with pytest.raises(ValueError):
+                    T.use_arrays(data, idx)                     # day-of-year list missing
+            T.use_arrays(data, idx, timelist=doy)
+            np.random.seed(3)
+            batch, cond = T._real_batch(7)
+            np.random.seed(3)
+            ixs = np.random.randint(T.n_samples, size=7)
+            b_ref, c_ref = od.gather_real(data, idx, ixs, 16)
+            c_ref = od.extra_condition(c_ref, idx[ixs], 16, kind, doy, idx[:, 2].min(), idx[:, 2].max())
+            assert cond.shape == (7, 16, 16, nc) and cond.dtype == np.float32
+            assert np.array_equal(batch, b_ref) and np.array_equal(cond, c_ref.astype(np.float32))
+            latent, c2 = T.generate_latent_points(4)
+            assert c2.shape == (4, 16, 16, nc)
+            g = W.init_generator(rng, 16, nc)
+            assert g[0].shape == (100 + 256 * nc, 3072)          # Dense width 612 / 868 (SURVEY 8f-4)
+            assert W.init_critic(rng, 16, nc)[0].shape == (3, 3, 3, 1 + nc, 64)
+            assert W.infer_config_from_gen(g) == (16, nc)
+        assert W.infer_config_from_gen(W.init_generator(rng, 64, 1)[:1]) == (64, 1)
+        with pytest.raises(ValueError):
+            T.configure(n_channel=4)
+    finally:
+        T.configure(ndomain=16, n_channel=1)
+        T.use_arrays(data, idx)
+
+
+def test_create_rejects_bad_configuration():
+    """argument validation happens before any HIP call, so it is checkable without a GPU"""
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    for nd, nc, mb in ((16, 0, 4), (16, 4, 4), (12, 1, 4), (16, 1, 0)):
+        assert lib.rdgan_create(ctypes.byref(h), nd, nc, mb) == -2 and not h.value
