@@ -62,6 +62,7 @@ generator = None
 critic = None
 hist = {'d_loss': [], 'g_loss': []}
 _trainer = None
+resume_from = None        # path of a trainer checkpoint to continue from (set before train(); see resume())
 device_dataset = None     # data_pipeline.DeviceDataset when the radar array is resident in HBM (use_device_dataset)
 
 
@@ -273,7 +274,7 @@ def build_networks(seed=None):
 
 
 def _get_trainer(per_rank_batch):
-    global _trainer
+    global _trainer, resume_from
     import torch
     import torch.distributed as dist
     from .trainer import WGANGPTrainer
@@ -285,7 +286,20 @@ def _get_trainer(per_rank_batch):
                                  world_size=world, rank=rank, process_group=dist.group.WORLD if world > 1 else None)
         generator.adopt_slab(_trainer.gparams)
         critic.adopt_slab(_trainer.dparams)
+        if resume_from:
+            _trainer.load_checkpoint(resume_from)
+            resume_from = None
     return _trainer, world, rank
+
+
+def resume(path):
+    """Continue a run from the checkpoint _end_of_epoch writes (weights, Adam state, shared step counter, RNG
+    positions): the next train(..., start_epoch=<epochs done>) call continues bit-identically.  The reference has no
+    counterpart -- it saves weights only (:520-521) and restarts Adam from zero."""
+    global resume_from, _trainer
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    resume_from, _trainer = path, None
 
 
 def train(n_epochs, _batch_size, start_epoch=0, make_plots=False, max_batches_per_epoch=None, save_models=True):
@@ -357,6 +371,8 @@ def _end_of_epoch(epoch, make_plots, save_models):
         ext = 'h5'
         generator.save(f'{outdir}/gen_{params}_{epoch:04d}.{ext}')                   # reference :520-521
         critic.save(f'{outdir}/disc_{params}_{epoch:04d}.{ext}')
+        if _trainer is not None:
+            _trainer.save_checkpoint(f'{outdir}/checkpoint_{params}.npz', extra={'epoch': epoch})
 
 
 def _plot_epoch(epoch, n_plot=30):

@@ -80,6 +80,41 @@ class WGANGPTrainer:
                 W.unflatten(self.dparams.cpu().numpy(), self.eng.critic_shapes))
 
 
+    # ---- resume checkpoint (the reference saves weights only, T:520-521, and cannot resume)
+    def save_checkpoint(self, path, extra=None):
+        """Everything a bit-identical continuation needs: both weight slabs, both Adam second-moment slabs, the
+        shared Adam iteration counter, the step-RNG position (base_seed, calls) and numpy's global RNG state (the
+        reference draws batches and latents from it, T:150,179).  One .npz; rank 0 writes (replicas are identical)."""
+        st = np.random.get_state()
+        np.savez(path, format=np.array("rdgan-checkpoint-1"), ndomain=self.eng.ndomain,
+                 n_cond_channels=getattr(self.eng, "n_cond_channels", 1),
+                 gparams=self.gparams.cpu().numpy(), dparams=self.dparams.cpu().numpy(),
+                 gv=self.gv.cpu().numpy(), dv=self.dv.cpu().numpy(),
+                 t=self.t, calls=self.calls, base_seed=self.base_seed, n_disc=self.n_disc,
+                 hyper=np.array([self.lr, self.beta2, self.eps], np.float64),
+                 np_rng_keys=st[1], np_rng_pos=np.array([st[2], st[3]], np.int64), np_rng_gauss=np.float64(st[4]),
+                 extra=np.array(repr(extra) if extra is not None else ""))
+
+    def load_checkpoint(self, path, restore_numpy_rng=True):
+        """Inverse of save_checkpoint, in place (device slabs keep their addresses, so models that adopted them
+        keep tracking).  Raises ValueError when the file belongs to another configuration."""
+        with np.load(path, allow_pickle=False) as f:
+            if str(f["format"]) != "rdgan-checkpoint-1":
+                raise ValueError(f"{path}: not an rdgan checkpoint")
+            if int(f["ndomain"]) != self.eng.ndomain or int(f["n_cond_channels"]) != getattr(self.eng, "n_cond_channels", 1):
+                raise ValueError(f"{path}: checkpoint of ndomain {int(f['ndomain'])} / {int(f['n_cond_channels'])} condition "
+                                 f"channels does not fit this engine")
+            for name in ("gparams", "dparams", "gv", "dv"):
+                dst, src = getattr(self, name), f[name]
+                if src.shape != tuple(dst.shape) or src.dtype != np.float32:
+                    raise ValueError(f"{path}: {name} has shape {src.shape}, expected {tuple(dst.shape)}")
+                dst.copy_(torch.from_numpy(src))
+            self.t, self.calls, self.base_seed = int(f["t"]), int(f["calls"]), int(f["base_seed"])
+            if restore_numpy_rng:
+                pos = f["np_rng_pos"]
+                np.random.set_state(("MT19937", f["np_rng_keys"], int(pos[0]), int(pos[1]), float(f["np_rng_gauss"])))
+
+
 def shard_slice(global_batch, world, rank):
     """rank r takes samples [r*B/W, (r+1)*B/W) -- equal shards so the global mean is the mean of local means"""
     if global_batch % world:

@@ -60,3 +60,46 @@ def test_shard_slice():
     assert [shard_slice(8, 4, r) for r in range(4)] == [slice(0, 2), slice(2, 4), slice(4, 6), slice(6, 8)]
     with pytest.raises(ValueError):
         shard_slice(10, 4, 0)
+
+
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    """save_checkpoint / load_checkpoint: 1 iteration + save + 1 iteration == load + 1 iteration,
+    including the shared Adam counter, the step-seed position and numpy's global RNG state."""
+    sys.path.insert(0, ROOT)
+    from oracle import rdgan_torch as ot
+    from pr_disagg_radar_gan_amd import weights as W
+    from pr_disagg_radar_gan_amd.trainer import WGANGPTrainer
+    from tests.fake_engine import FakeEngine
+    torch.set_num_threads(4)
+
+    def make(seed):
+        rng = np.random.default_rng(seed)
+        return WGANGPTrainer(FakeEngine(16), W.init_generator(rng, 16), W.init_critic(rng, 16), n_disc=1)
+
+    def one_iteration(tr):
+        s = int(np.random.randint(1 << 30))                     # batches come from numpy's global RNG, as in T:150,179
+        x, c, z = (torch.from_numpy(a) for a in ot.synthetic_batch(2, 16, s))
+        return tr.iteration([(x, c, z)], (z, c))
+
+    np.random.seed(11)
+    a = make(0)
+    one_iteration(a)
+    path = str(tmp_path / "ck.npz")
+    a.save_checkpoint(path, extra={"epoch": 1})
+    want = one_iteration(a)
+
+    np.random.seed(999)                                         # a different process state
+    b = make(5)                                                 # different initial weights: everything comes from the file
+    b.load_checkpoint(path)
+    assert (b.t, b.calls) == (2, 2)
+    got = one_iteration(b)
+    for u, v in zip(want, got):
+        assert torch.equal(u, v)
+    for name in ("gparams", "dparams", "gv", "dv"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert a.t == b.t == 4 and a.calls == b.calls
+
+    other = WGANGPTrainer(FakeEngine(8), W.init_generator(np.random.default_rng(0), 8),
+                          W.init_critic(np.random.default_rng(0), 8), n_disc=1)
+    with pytest.raises(ValueError):
+        other.load_checkpoint(path)                             # ndomain 16 checkpoint into an ndomain 8 trainer

@@ -124,3 +124,40 @@ def test_train_mirror_with_device_dataset(tmp_path, monkeypatch):
     assert len(hist["g_loss"]) == 2 and np.all(np.isfinite(hist["g_loss"])) and np.all(np.isfinite(hist["d_loss"]))
     T.use_device_dataset(False)
     T.configure(n_disc=5)
+
+
+@pytest.mark.parametrize("n_channel", [1, 3])
+def test_train_mirror_resume_is_bit_identical(tmp_path, monkeypatch, n_channel):
+    """T.resume: epoch 1 + epoch 2 in one process state equals epoch 2 continued from the checkpoint
+    written after epoch 1 (weights, Adam moments, shared step counter, dropout/alpha seeds, numpy RNG).  Also runs the
+    n_channel = 3 variant (sin/cos day of year) end to end through the mirror."""
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(2)
+    data = (rng.gamma(0.3, 2.0, (4, 24, 32, 32)).astype(np.float32) + 1e-3)
+    idx = [(t, y, x) for t in range(4) for y in (0, 16) for x in (0, 16)]
+    try:
+        T.configure(ndomain=16, n_disc=1, n_channel=n_channel)
+        T.use_arrays(data, idx, timelist=[10, 100, 200, 300])
+        T.build_networks(seed=7)
+        T.hist["d_loss"].clear(); T.hist["g_loss"].clear()
+        np.random.seed(3)
+        T.train(1, 4, max_batches_per_epoch=2)
+        ck = os.path.join(T.outdir, f"checkpoint_{T.params}.npz")
+        assert os.path.exists(ck)
+        T.train(1, 4, start_epoch=1, max_batches_per_epoch=2, save_models=False)
+        want_g, want_d, want_hist = T.generator.get_weights(), T.critic.get_weights(), list(T.hist["g_loss"])
+
+        T.build_networks(seed=99)                    # fresh, different networks; everything must come from the file
+        T.hist["d_loss"].clear(); T.hist["g_loss"].clear()
+        np.random.seed(12345)
+        T.resume(ck)
+        T.train(1, 4, start_epoch=1, max_batches_per_epoch=2, save_models=False)
+        assert T.resume_from is None
+        assert all(np.array_equal(a, b) for a, b in zip(T.generator.get_weights(), want_g))
+        assert all(np.array_equal(a, b) for a, b in zip(T.critic.get_weights(), want_d))
+        assert T.hist["g_loss"] == want_hist[2:]
+        with pytest.raises(FileNotFoundError):
+            T.resume(str(tmp_path / "nope.npz"))
+    finally:
+        T.configure(n_disc=5, n_channel=1)
+        T.use_arrays(data, idx)
