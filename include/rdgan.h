@@ -84,7 +84,14 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * fp32 rounding of the pre-summed weights differs.  0 = the reference's direct 27-tap form.
  * "wave_specialized" (default 1): big GEMMs run the producer/consumer kernel (4 loader waves streaming tiles
  * into LDS by DMA, 4 compute waves issuing only ds_read + MFMA); 0 = the single-role kernel everywhere;
- * 2 = producer/consumer kernel for every eligible shape regardless of size (tests). */
+ * 2 = producer/consumer kernel for every eligible shape regardless of size (tests).
+ * "ws_ksplit" (default 1): mid-size producer/consumer launches whose workgroup count would leave part of the 256 CUs
+ * idle in the last round split their K loop over 2..8 workgroups (partials folded by a finish kernel, fixed order);
+ * 0 = never, n > 1 = force n-way splits wherever the shape allows (tests).
+ * "tapgather" (default 1): the last generator conv (64 -> 1, T:345) runs as a column GEMM over its 27 taps whose
+ * epilogue already sums the taps that fall inside the 256-row tile (ndomain 8/16: whole planes, 32/64/128: whole
+ * rows), writing 3 or 9 floats per grid point instead of 32; 0 (and every other ndomain) = full column matrix +
+ * separate gather kernel. */
 int rdgan_set_option(rdgan_handle* h, const char* name, int value);
 
 /* Per-kernel HIP-event timing for bench.py's roofline line.  tag_mask: bit i enables timing of

@@ -267,6 +267,8 @@ struct rdgan_handle {
   float *DWT[5], *W1T, *GWT[4], *W9T, *W1P, *dW1P;
   float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
   int collapse = 1;               // 1: 8-tap collapsed generator blocks (default); 0: direct 27-tap form
+  int tapgather = 1;              // 1: last generator conv sums its in-tile taps in the GEMM epilogue; 0: full column matrix + gather kernel
+  int ws_ksplit = 1;              // 1: split K of mid-size producer/consumer launches to fill whole rounds of workgroups; 0: off; >1: force (tests)
   int wave_spec = 1;              // 1: producer/consumer (wave-specialised, LDS-DMA) kernel for the big clean GEMMs
   int* d_flag;
   // profiling
@@ -382,7 +384,25 @@ static int launch_conv_ws_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* d
   if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
   RdEpi e2 = epi;
   e2.ksplit = 1; e2.kpart = nullptr; e2.kstride = 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tm * (hp.N / BN)), 1), dim3(512), lds, st, dp, B, src, W, ldw, dst, e2);
+  const long blocks = tm * (hp.N / BN);
+  // Wave quantisation: a mid-size launch of long workgroups (say 384 on 256 CUs) leaves a third of the chip idle in
+  // its last round.  Split K so that the workgroup count fills whole rounds; the partial sums cost one extra pass over
+  // the (small) output, priced at 3 % per split.
+  const long total = (long)B * hp.dst_sample;
+  if (h && h->ws_ksplit && blocks < 1024 && hp.d_cstride == hp.N && epi.mode != RD_EPI_BIAS_PN_LRELU) {
+    long nch = (long)hp.ph[0].ntaps * (hp.SC / 32);
+    for (int i = 1; i < hp.nphases; ++i) nch = std::min<long>(nch, (long)hp.ph[i].ntaps * (hp.SC / 32));
+    auto cost = [&](long ks) { double r = (double)(blocks * ks) / 256.0; return std::ceil(r) / r * (1.0 + 0.03 * (ks - 1)); };
+    long best = 1;
+    for (long ks = 2; ks <= 8; ++ks)
+      if (nch / ks >= 12 && (size_t)(ks * total) <= h->kpartial_cap && cost(ks) < cost(best) - 0.02) best = ks;
+    if (h->ws_ksplit > 1) best = std::min<long>(h->ws_ksplit, std::max<long>(1, nch / 4));   // tests: force a split
+    if (best > 1 && (size_t)(best * total) <= h->kpartial_cap) { e2.ksplit = (int)best; e2.kpart = h->kpartial; e2.kstride = total; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)e2.ksplit), dim3(512), lds, st, dp, B, src, W, ldw, dst, e2);
+  if (e2.ksplit > 1)
+    hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)std::min<long>((total / 4 + 255) / 256, 2048)), dim3(256), 0, st, dst,
+                       total, hp.N, e2);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -423,8 +443,14 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
       if (ws_ok) return launch_conv_ws_cfg<128, 64, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
       RD_CONV(128, 64, 2, 2);
     }
+    // few rows, very long K (input gradient of the first generator block): producer/consumer kernel with its K split
+    if (ws_ok && h->ws_ksplit && hp.nphases == 1 && hp.d_cstride == hp.N && (long)hp.ph[0].ntaps * (hp.SC / 32) >= 96 &&
+        plan_tiles(hp, B, 128) * (hp.N / 64) >= 32)
+      return launch_conv_ws_cfg<128, 64, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
     RD_CONV(64, 64, 2, 2);
   }
+  if (hp.N == 32 && !partial && !shift && epi.mode == RD_EPI_TAPGATHER)
+    return launch_conv_cfg<256, 32, 4, 1, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
   if (hp.N == 32 && !partial && !shift)
     return launch_conv_cfg<128, 32, 4, 1, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
 #undef RD_CONV
@@ -538,8 +564,10 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   else RD_WG(64, 64);
 #undef RD_WG
   long total = (long)T.RT * BR * (hp.N / 4);
-  int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks, np), dim3(256), 0, st, dp, partial_ws, nsplit, T, BR, dW, hp.N);
+  int outs = 256;                       // output float4s per workgroup; the other 256/outs thread slices split the fold
+  while (outs > 16 && (total + outs - 1) / outs * np < 512 && 256 / outs < nsplit) outs >>= 1;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + outs - 1) / outs), np), dim3(256), 0, st, dp, partial_ws,
+                     nsplit, T, BR, dW, hp.N, outs);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -555,7 +583,8 @@ static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>(
 // out[c] = sum over rows of src[rows][C]
 static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, float* out, hipStream_t st) {
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-  long nblk = std::min<long>(1024, std::max<long>(1, rows / 32));
+  const bool any = C != 64 && C != 128 && C != 256;
+  long nblk = std::min<long>(1024, std::max<long>(1, rows / (any ? 8 : 32)));
   if ((size_t)nblk * C > h->cpartial_cap) nblk = std::max<long>(1, (long)(h->cpartial_cap / C));
   long rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
@@ -563,9 +592,11 @@ static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, fl
   if (C == 64) hipLaunchKernelGGL(k_colsum_partial<16>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
   else if (C == 128) hipLaunchKernelGGL(k_colsum_partial<32>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
   else if (C == 256) hipLaunchKernelGGL(k_colsum_partial<64>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
-  else hipLaunchKernelGGL(k_colsum_partial_any, grid, dim3(std::max(64, std::min(256, (C + 63) / 64 * 64))), 0, st, src, rows, C,
-                          h->cpartial, rpb);
-  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 63) / 64), dim3(256), 0, st, h->cpartial, (int)nblk, C, out);
+  else {
+    const int bt = std::max(64, std::min(256, (C + 63) / 64 * 64));
+    hipLaunchKernelGGL(k_colsum_partial_any, dim3((unsigned)nblk, (C + bt - 1) / bt), dim3(bt), 0, st, src, rows, C, h->cpartial, rpb);
+  }
+  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 15) / 16), dim3(256), 0, st, h->cpartial, (int)nblk, C, out);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -789,6 +820,8 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!h || !name) return -2;
   if (!strcmp(name, "collapse")) { h->collapse = value ? 1 : 0; return 0; }
   if (!strcmp(name, "wave_specialized")) { h->wave_spec = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }   // 2 = also for small problems (tests)
+  if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "ws_ksplit")) { h->ws_ksplit = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }   // > 1 = force (tests)
   return bad_arg(h, "set_option: unknown option");
 }
 
@@ -827,7 +860,7 @@ extern "C" int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, lo
 static RdEpi epi_make(int mode, const float* bias = nullptr, const float* aux = nullptr, int use_drop = 0,
                       uint32_t key = 0, uint32_t idx_base = 0) {
   RdEpi e; e.mode = mode; e.use_drop = use_drop; e.key = key; e.idx_base = idx_base; e.bias = bias; e.aux = aux;
-  e.ksplit = 1; e.kpart = nullptr; e.kstride = 0; e.rinv = nullptr;
+  e.ksplit = 1; e.kpart = nullptr; e.kstride = 0; e.rinv = nullptr; e.gw = e.ghw = e.gq = 0;
   return e;
 }
 
@@ -866,11 +899,21 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st));
     }
   }
-  // Conv3D 64->1 (T:345) as column GEMM + gather, bias, Softmax(axis=1) (T:347), check_numerics (T:349-350)
-  RD_TRY(launch_conv(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, epi_make(RD_EPI_PLAIN), st, -1));
-  {
+  // Conv3D 64->1 (T:345) as column GEMM + gather, bias, Softmax(axis=1) (T:347), check_numerics (T:349-350).
+  // When a 256-row tile holds whole (h,w) planes (nd = 8, 16) or whole w rows (nd = 32, 64, 128) the GEMM's epilogue
+  // sums the in-tile taps itself and writes 3 (9) floats per grid point instead of 32.
+  const int gq = 256 % (nd * nd) == 0 ? 3 : (256 % nd == 0 ? 9 : 0);
+  const long ncol = (long)B * nd * nd;
+  if (gq && h->tapgather) {
+    RdEpi e = epi_make(RD_EPI_TAPGATHER);
+    e.gw = nd; e.ghw = nd * nd; e.gq = gq;
+    RD_TRY(launch_conv(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, e, st, -1));
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    long ncol = (long)B * nd * nd;
+    hipLaunchKernelGGL(k_tapsum_softmax<RDGAN_NHOURS>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->P9,
+                       gp + h->goff[9], out, B, nd, nd, gq, h->d_flag);
+  } else {
+    RD_TRY(launch_conv(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, epi_make(RD_EPI_PLAIN), st, -1));
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_colgather_softmax, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->P9, gp + h->goff[9],
                        out, B, RDGAN_NHOURS, nd, nd, h->d_flag);
   }
@@ -1017,7 +1060,7 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
   }
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_critic_dense_wgrad, dim3((h->F + 63) / 64), dim3(256), 0, st, h->dh[4], grad + h->doff[8], NBt,
+    hipLaunchKernelGGL(k_critic_dense_wgrad, dim3((h->F + 15) / 16), dim3(256), 0, st, h->dh[4], grad + h->doff[8], NBt,
                        h->F, B);
     RD_CHECK(h, hipMemsetAsync(grad + h->doff[9], 0, sizeof(float), st));   // sum of dv over real|fake = 0
     RD_CHECK(h, hipMemsetAsync(grad + h->n_critic, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));

@@ -181,6 +181,55 @@ __global__ void k_colgather_softmax(const float* __restrict__ P, const float* __
   if (bad) atomicOr(nonfinite, 1);
 }
 
+// G9+G10+G11 after the tap-gathering column GEMM (RD_EPI_TAPGATHER): Q[b][d][NQ][h][w] holds, per grid point, the sums
+// over (kh,kw) for each kd (NQ = 3) or over kw for each (kd,kh) (NQ = 9).  logits = bias + the remaining sum over
+// kd (and kh), then softmax over the 24 hours.  One thread per (sample, h, w) column, logits kept in registers.
+template <int D>
+__global__ void k_tapsum_softmax(const float* __restrict__ Q, const float* __restrict__ bias, float* __restrict__ out,
+                                 int B, int H, int W, int NQ, int* __restrict__ nonfinite) {
+  const long ncol = (long)B * H * W;
+  const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (gid >= ncol) return;
+  const int w = (int)(gid % W), h = (int)((gid / W) % H);
+  const long b = gid / ((long)W * H);
+  const float bv = bias[0];
+  const long hw = (long)H * W;
+  const float* q = Q + b * D * NQ * hw;
+  float lg[D];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    float s = bv;
+#pragma unroll
+    for (int td = 0; td < 3; ++td) {
+      const int sd = d + td - 1;
+      if (sd < 0 || sd >= D) continue;
+      if (NQ == 3) {
+        s += q[((long)sd * 3 + td) * hw + (long)h * W + w];
+      } else {
+        for (int th = 0; th < 3; ++th) {
+          const int shh = h + th - 1;
+          if ((unsigned)shh < (unsigned)H) s += q[((long)sd * 9 + td * 3 + th) * hw + (long)shh * W + w];
+        }
+      }
+    }
+    lg[d] = s;
+    mx = fmaxf(mx, s);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) { lg[d] = expf(lg[d] - mx); den += lg[d]; }
+  bool bad = false;
+  float* o = out + b * D * hw + (long)h * W + w;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const float p = lg[d] / den;
+    bad |= !(fabsf(p) <= 3.0e38f);
+    o[d * hw] = p;
+  }
+  if (bad) atomicOr(nonfinite, 1);
+}
+
 // softmax-over-hours backward: dl = p * (g - sum_d p*g), one thread per (sample,h,w) column.
 __global__ void k_softmax_bwd(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ dl,
                               int B, int D, int H, int W) {
@@ -290,17 +339,27 @@ __global__ void k_critic_top_bwd(const float* __restrict__ h4, const float* __re
 }
 
 // dW6[i] = sum_b buf[b][i] * dv(b) over the 3B batch whose last third holds r4;
-// block = 64 columns x 4 sample groups
+// block = 16 columns x 16 sample groups (F / 16 workgroups: the matrix is short and wide)
 __global__ void __launch_bounds__(256)
 k_critic_dense_wgrad(const float* __restrict__ buf, float* __restrict__ dw, int NB, int F, int B) {
   __shared__ float red[256];
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-  float s = 0.f;
-  if (i < F)
-    for (int b = g; b < NB; b += 4) s += buf[(long)b * F + i] * rd_dv(b, B, 0);
-  red[threadIdx.x] = s;
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < F) {
+    int b = g;
+    for (; b + 16 < NB; b += 32) {
+      s0 += buf[(long)b * F + i] * rd_dv(b, B, 0);
+      s1 += buf[(long)(b + 16) * F + i] * rd_dv(b + 16, B, 0);
+    }
+    if (b < NB) s0 += buf[(long)b * F + i] * rd_dv(b, B, 0);
+  }
+  red[threadIdx.x] = s0 + s1;
   __syncthreads();
-  if (g == 0 && i < F) dw[i] = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
+  if (g == 0 && i < F) {
+    float s = red[threadIdx.x];
+    for (int j = 1; j < 16; ++j) s += red[j * 16 + threadIdx.x];
+    dw[i] = s;
+  }
 }
 
 // column sums of rows [0,rows) of a [rows][C] matrix, two deterministic stages.
@@ -329,30 +388,37 @@ k_colsum_partial(const float* __restrict__ src, long rows, float* __restrict__ p
     *(f32x4*)(partial + (long)blockIdx.x * C + cg * 4) = t;
   }
 }
-// generic (any C): one thread per column, used for the few wide-and-short cases (Dense bias: 256 x 3072)
+// generic (any C): one thread per column, used for the few wide-and-short cases (Dense bias: 256 x 3072);
+// grid = (row blocks, column chunks of blockDim.x)
 __global__ void k_colsum_partial_any(const float* __restrict__ src, long rows, int C, float* __restrict__ partial,
                                      long rows_per_blk) {
   const long r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += src[r * C + c];
-    partial[(long)blockIdx.x * C + c] = s;
-  }
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  long r = r0;
+  for (; r + 1 < r1; r += 2) { s0 += src[r * C + c]; s1 += src[(r + 1) * C + c]; }
+  if (r < r1) s0 += src[r * C + c];
+  partial[(long)blockIdx.x * C + c] = s0 + s1;
 }
-// stage 2: out[c] = sum_k partial[k][c]; block = 64 columns x 4 partial groups
+// stage 2: out[c] = sum_k partial[k][c]; block = 16 columns x 16 partial groups, folded in a fixed order
 __global__ void __launch_bounds__(256)
 k_reduce_partials(const float* __restrict__ partial, int nsplit, int n, float* __restrict__ out) {
   __shared__ float red[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
   float s0 = 0.f, s1 = 0.f;
   if (c < n) {
     int k = g;
-    for (; k + 4 < nsplit; k += 8) { s0 += partial[(long)k * n + c]; s1 += partial[(long)(k + 4) * n + c]; }
+    for (; k + 16 < nsplit; k += 32) { s0 += partial[(long)k * n + c]; s1 += partial[(long)(k + 16) * n + c]; }
     if (k < nsplit) s0 += partial[(long)k * n + c];
   }
   red[threadIdx.x] = s0 + s1;
   __syncthreads();
-  if (g == 0 && c < n) out[c] = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
+  if (g == 0 && c < n) {
+    float s = red[threadIdx.x];
+    for (int j = 1; j < 16; ++j) s += red[j * 16 + threadIdx.x];
+    out[c] = s;
+  }
 }
 
 // col2im of the D1 input gradient restricted to the sample channel (channel 0):

@@ -372,6 +372,46 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   // stores + 16*TM dependent table loads (VMEM instructions issue slowly beside a partner wave's MFMA stream; stamps
   // put the scalar epilogue at 21 % of a workgroup's lifetime).
   constexpr bool LDS_EPI = BK == 32;
+  if constexpr (LDS_EPI && BN == 32) {
+    if (mode == RD_EPI_TAPGATHER) {
+      // rows padded to 33 floats: the gather below walks rows with consecutive lanes
+      constexpr int CST = BN + 1;
+      float* Cs = smem;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Cs[row * CST + wn * WTN + j * 32 + l31] = acc[i][j][r];
+        }
+      __syncthreads();
+      const int Wd = epi.gw, HW = epi.ghw, NQ = epi.gq, Hd = HW / Wd;
+      for (int o = tid; o < BM * NQ; o += 256) {
+        const int r = o % BM, j = o / BM;
+        const long m = (long)m0 + r;
+        if (m >= rows) continue;
+        const long pl = m / HW;
+        const int hw = (int)(m - pl * HW), hh = hw / Wd, ww = hw - hh * Wd;
+        float s = 0.f;
+        if (NQ == 9) {
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            if ((unsigned)(ww + kw - 1) < (unsigned)Wd) s += Cs[(r + kw - 1) * CST + j * 3 + kw];
+        } else {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            if ((unsigned)(hh + kh - 1) >= (unsigned)Hd) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+              if ((unsigned)(ww + kw - 1) < (unsigned)Wd) s += Cs[(r + (kh - 1) * Wd + kw - 1) * CST + (j * 3 + kh) * 3 + kw];
+          }
+        }
+        dst[(pl * NQ + j) * HW + hw] = s;
+      }
+      return;
+    }
+  }
   if constexpr (LDS_EPI) {
     float* Cs = smem;                                   // [BM][BN]
     int* Rb = (int*)(smem + BM * BN);                   // [BM][2]: destination row base (floats, 64-bit) or -1
@@ -725,23 +765,40 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
     }
 }
 
-// fold the split partials and scatter rows (tap,c) to their place in the weight gradient
-__global__ void k_wgrad_reduce(const RdPlan* __restrict__ plan, const float* __restrict__ partial, int nsplit,
-                               RdWgradTiling T, int BR, float* __restrict__ dW, int ldw) {
+// fold the split partials and scatter rows (tap,c) to their place in the weight gradient.
+// 256 threads = `outs` output float4s x (256/outs) slices of the split range; the slices are folded through LDS in a
+// fixed order (deterministic).  Few outputs with many splits (D1, the last generator conv) take outs = 16.
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce(const RdPlan* __restrict__ plan, const float* __restrict__ partial, int nsplit,
+               RdWgradTiling T, int BR, float* __restrict__ dW, int ldw, int outs) {
+  __shared__ f32x4 red[256];
   const int N = plan->N;
   const int n4s = N / 4;
   const long total = (long)T.RT * BR * n4s;
   const RdPhase& P = plan->ph[blockIdx.y];
   const long stride = (long)T.RT * BR * N;
   const float* pbase = partial + (long)blockIdx.y * nsplit * stride;
-  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
-    int R = (int)(f / n4s), n = (int)(f - (long)R * n4s) * 4;
-    int rt = R / BR, r = R - rt * BR, tap, c;
+  const int ks = 256 / outs, o = threadIdx.x % outs, sl = threadIdx.x / outs;
+  const long f = (long)blockIdx.x * outs + o;
+  int tap = 0, c = 0, n = 0;
+  bool ok = f < total;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
+    int R = (int)(f / n4s);
+    n = (int)(f - (long)R * n4s) * 4;
+    int rt = R / BR, r = R - rt * BR;
     rd_wgrad_tile_row(T, BR, rt, r, tap, c);
-    if (tap >= P.ntaps || c >= plan->SC) continue;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const float* p = pbase + (long)R * N + n;
-    for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(p + k * stride);
-    *(f32x4*)(dW + P.w_off + ((long)P.tap[tap].w * plan->w_rows_per_tap + c) * ldw + n) = s;
+    ok = tap < P.ntaps && c < plan->SC;
+    if (ok) {
+      const float* p = pbase + (long)R * N + n;
+      for (int k = sl; k < nsplit; k += ks) s += *(const f32x4*)(p + k * stride);
+    }
   }
+  if (ks > 1) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0)
+      for (int j = 1; j < ks; ++j) s += red[j * outs + o];
+  }
+  if (ok && sl == 0) *(f32x4*)(dW + P.w_off + ((long)P.tap[tap].w * plan->w_rows_per_tap + c) * ldw + n) = s;
 }

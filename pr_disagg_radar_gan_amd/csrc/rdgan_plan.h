@@ -54,8 +54,12 @@ struct RdPlan {
 
 // epilogue modes of the conv GEMM
 // RD_EPI_BIAS_PN_LRELU: bias, PixelNormalization over the N channels of the row, LeakyReLU (needs BN == N)
+// RD_EPI_TAPGATHER (BN == 32, last generator conv 64 -> 1 as a column GEMM over its 27 taps): the tile's columns
+//   P[row][tap] are summed over the taps whose neighbour rows lie inside the tile -- over (kh,kw) when the tile holds
+//   whole (h,w) planes (gq = 3 sums per row, one per kd), over kw only when it holds whole w rows (gq = 9, one per
+//   (kd,kh)) -- and written as Q[plane][gq][h][w]; k_tapsum_softmax finishes the sum and the softmax
 enum { RD_EPI_PLAIN = 0, RD_EPI_BIAS = 1, RD_EPI_BIAS_LRELU = 2, RD_EPI_BIAS_LRELU_DROP = 3, RD_EPI_GATE_AUX = 4,
-       RD_EPI_BIAS_PN_LRELU = 5 };
+       RD_EPI_BIAS_PN_LRELU = 5, RD_EPI_TAPGATHER = 6 };
 
 struct RdEpi {
   int mode;
@@ -70,4 +74,5 @@ struct RdEpi {
   float* kpart;
   long kstride;
   float* rinv;                 // RD_EPI_BIAS_PN_LRELU: per-pixel 1/sqrt(mean(y^2)+eps), kept for the backward pass
+  int gw, ghw, gq;             // RD_EPI_TAPGATHER: plane width W, plane size H*W, sums per row (3 or 9)
 };

@@ -211,3 +211,55 @@ def test_full_size_properties():
         assert np.all(np.isfinite(sl)) and sl[eng.n_critic + 4] == 0
     finally:
         eng.close()
+
+
+def test_forced_split_k_in_producer_consumer_kernels(eng16):
+    """"ws_ksplit" > 1 forces the K split of the producer/consumer conv kernel (normally chosen only for mid-size
+    launches at large batch): forward and both step gradients must still agree with the oracle."""
+    eng16.set_option("collapse", 1)
+    eng16.set_option("wave_specialized", 2)
+    g, d = _params(16, 15)
+    try:
+        for ks in (2, 3):
+            eng16.set_option("ws_ksplit", ks)
+            x, cond, z = ot.synthetic_batch(3, 16, 8)
+            ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
+            out = eng16.gen_forward(eng16.to_slab(g), dev(z), dev(cond)).cpu().numpy()
+            np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-7)
+
+            def run_critic(data_seed):
+                x, cond, z = ot.synthetic_batch(3, 16, data_seed)
+                losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
+                                                     torch.from_numpy(cond).double(), torch.from_numpy(z).double(), 5)
+                slab = eng16.critic_grad(eng16.to_slab(d), eng16.to_slab(g), dev(x), dev(cond), dev(z), 5).cpu().numpy()
+                np.testing.assert_allclose(slab[eng16.n_critic:eng16.n_critic + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+                return _grad_errors(slab[:eng16.n_critic], grads, eng16.critic_shapes)
+
+            def run_gen(data_seed):
+                x, cond, z = ot.synthetic_batch(2, 16, data_seed)
+                loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 6)
+                slab = eng16.gen_grad(eng16.to_slab(d), eng16.to_slab(g), dev(z), dev(cond), 6).cpu().numpy()
+                return _grad_errors(slab[:eng16.n_gen], grads, eng16.gen_shapes)
+
+            _parity_over_batches(run_critic)
+            _parity_over_batches(run_gen)
+    finally:
+        eng16.set_option("ws_ksplit", 1)
+        eng16.set_option("wave_specialized", 1)
+
+
+@pytest.mark.parametrize("nd,tapgather", [(8, 1), (16, 0), (24, 1), (32, 1), (32, 0)])
+def test_last_conv_paths_other_domains(nd, tapgather):
+    """The last generator conv + softmax has three forms: tap sums over whole planes in the GEMM epilogue (nd 8, 16),
+    over whole rows (nd 32, 64, 128), and the full column matrix + gather kernel (any other nd, or "tapgather" 0)."""
+    eng = Engine(ndomain=nd, max_batch=3)
+    try:
+        eng.set_option("tapgather", tapgather)
+        g, _ = _params(nd, 31)
+        x, cond, z = ot.synthetic_batch(3, nd, 9)
+        ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
+        out = eng.gen_forward(eng.to_slab(g), dev(z), dev(cond)).cpu().numpy()
+        np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-7)          # north_star tolerance
+        assert rel_err(out, ref) < 2e-5
+    finally:
+        eng.close()
