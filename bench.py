@@ -27,14 +27,17 @@ N_CRITIC = 1
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
-def gconv3_flops(batch, nd=NDOMAIN, collapsed=True):
-    """Algorithmic FLOPs of ONE launch of the dominant kernel: the forward GEMM of the generator's
-    third UpSampling3D+Conv3D block (128 -> 64 channels onto the 24 x nd x nd grid).
-    Executed (collapsed) form: 8 taps on the un-upsampled grid, 2 * B * (24*nd*nd) * 8*128 * 64
-    (805.3 MFLOP per sample at nd=16); the reference's direct form has 27 taps
-    (2 717.9 MFLOP per sample) and is reported beside it as ``direct_equiv``."""
-    taps = 8 if collapsed else 27
+def gconv3_flops(batch, nd=NDOMAIN, taps=4):
+    """Algorithmic (executed) FLOPs of ONE launch of the dominant kernel: the difference-part GEMM of the generator's
+    third UpSampling3D+Conv3D block (128 -> 64 channels onto the 24 x nd x nd grid) in the shared-centre form
+    (DESIGN.md 5b): 8 output-parity phases x 4 taps on the un-upsampled grid, 2 * B * (24*nd*nd) * 4*128 * 64
+    = 402.7 MFLOP per sample at nd=16.  (The shared part T = S x of the same block is a separate, smaller launch.)"""
     return 2.0 * batch * 24 * nd * nd * taps * 128 * 64
+
+
+# SURVEY 8d: FLOPs of one iteration (n_critic critic steps + 1 generator step) per sample in the reference's direct
+# 27-tap form, nd = 16; used to price the measured iteration time as "direct-equivalent" TFLOP/s
+DIRECT_GF_PER_SAMPLE = {"critic_step": 5.41, "gen_step": 13.54}
 
 
 def cpu_baseline(iters=3, batch=32):
@@ -82,6 +85,8 @@ def main():
     ap.add_argument("--ndomain", type=int, default=NDOMAIN, help="16 = BASELINE metric; 64 = large-domain variant (extra data point)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="rdgan_set_option override for A/B runs (e.g. --opt fast_bwd=0); the default run sets none")
     args = ap.parse_args()
 
     import torch
@@ -114,6 +119,9 @@ def main():
     B = args.batch
     ND = args.ndomain
     eng = Engine(ndomain=ND, max_batch=B, device=dev)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        eng.set_option(name, int(value))
     rng = np.random.default_rng(0)                  # identical initial weights on every rank
     trainer = WGANGPTrainer(eng, W.init_generator(rng, ND), W.init_critic(rng, ND), n_disc=args.n_critic,
                             process_group=pg, world_size=world, rank=rank, base_seed=1234 + 1000 * 2)
@@ -159,8 +167,13 @@ def main():
     if rank == 0:
         value = world * B * args.steps / dt
         avg_ms = kern_ms / max(kern_n, 1)
-        achieved = gconv3_flops(B, ND) / (avg_ms * 1e-3) / 1e12 if kern_n else None
-        direct_equiv = gconv3_flops(B, ND, collapsed=False) / (avg_ms * 1e-3) / 1e12 if kern_n else None
+        opts = dict(kv.split("=") for kv in args.opt)     # A/B runs: the tagged launch is the whole block in the other forms
+        taps = 27 if opts.get("collapse") == "0" else (8 if opts.get("fast_fwd") == "0" else 4)
+        achieved = gconv3_flops(B, ND, taps) / (avg_ms * 1e-3) / 1e12 if kern_n else None
+        direct_equiv = None
+        if ND == 16:
+            gf = args.n_critic * DIRECT_GF_PER_SAMPLE["critic_step"] + DIRECT_GF_PER_SAMPLE["gen_step"]
+            direct_equiv = gf * 1e9 * B * args.steps / dt / 1e12          # per GPU
         out = {
             "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256" if ND == 16 else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles (extra data point)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,12 +183,13 @@ def main():
                                    + (" (BASELINE configs[1])" if (ND, B, args.n_critic) == (16, 256, 1) else ""),
                        "global_batch": world * B, "n_critic": args.n_critic, "parallelism": f"dp{world}",
                        "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_ws<256,64,4,1> generator block 3 forward (upsample+Conv3D 128->64 + bias + PixelNorm + LeakyReLU, 8-tap collapsed form)",
+            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_ws<256,64,4,1>, generator block 3 forward, difference part (E x U over 8 parity "
+                                                    "phases x 4 taps + shared part T + bias + PixelNorm + LeakyReLU in the epilogue)",
                          "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
-                         "flops_per_launch": gconv3_flops(B, ND),
-                         "direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2)},
+                         "flops_per_launch": gconv3_flops(B, ND, taps),
+                         "iteration_direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2)},
             "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},
         }
         if world == 1 and not args.no_cpu_baseline and ND == 16:

@@ -88,6 +88,12 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "ws_ksplit" (default 1): mid-size producer/consumer launches whose workgroup count would leave part of the 256 CUs
  * idle in the last round split their K loop over 2..8 workgroups (partials folded by a finish kernel, fixed order);
  * 0 = never, n > 1 = force n-way splits wherever the shape allows (tests).
+ * "fast_fwd" / "fast_bwd" (default 1, need "collapse" 1): generator blocks 2 and 3 (block inputs with >= 6 hour
+ * planes) in the shared-centre form along the hour axis: out[2s] = S x[s] - W0 E[s], out[2s+1] = S x[s] + W2 E[s+1]
+ * with E[j] = x[j] - x[j-1] and S = W0+W1+W2, so both outputs of a source position share the S x[s] product -- 48
+ * instead of 64 tap products per position, algebraically identical.  Forward: T = S x once per output plane pair,
+ * then the difference part adds T in its epilogue; backward: plane-pair sums of the output gradient feed the S part,
+ * the gradient wrt E is folded back by the adjoint of the differencing.  0 = the 64-tap collapsed form.
  * "tapgather" (default 1): the last generator conv (64 -> 1, T:345) runs as a column GEMM over its 27 taps whose
  * epilogue already sums the taps that fall inside the 256-row tile (ndomain 8/16: whole planes, 32/64/128: whole
  * rows), writing 3 or 9 floats per grid point instead of 32; 0 (and every other ndomain) = full column matrix +

@@ -161,6 +161,103 @@ static RdPlan plan_upconv_dgrad_collapsed(int D, int H, int W, int Cin, int Cout
   return p;
 }
 
+// ---- shared-centre form along d for the backward pass of a generator block (rdgan_elem.hip.h).
+// U block index: u = g*16 + (ph*2+th)*4 + (pw*2+tw), g = 0 (A': -W0 on E[s]), 1 (S: W0+W1+W2 on x[s]), 2 (D: W2 on E[s+1]).
+// On a collapsed axis (p,t) reads source offset p-1+t and sums the kernel taps {0},{1,2},{0,1},{2}.
+static void fastd_weight_map(RdWeightMap& T) {
+  static const int td[3][3] = {{-1, 0, 0}, {1, 1, 1}, {0, 0, 1}};
+  static const int tc[4][3] = {{1, 0, 0}, {0, 1, 1}, {1, 1, 0}, {0, 0, 1}};
+  memset(&T, 0, sizeof(T));
+  for (int g = 0; g < 3; ++g)
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b)
+        for (int k = 0; k < 27; ++k)
+          T.c[g * 16 + a * 4 + b][k] = (int8_t)(td[g][k / 9] * tc[a][(k / 3) % 3] * tc[b][k % 3]);
+}
+// weight gradient of group g: A = E at j = s against the even output planes, S = x against the plane sums gS,
+// D = E at j = s+1 against the odd output planes.  D,H,W = un-upsampled extents.
+static RdPlan plan_fastd_wgrad(int D, int H, int W, int Cin, int Cout, int g) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 4; p.SD = g == 1 ? D : D + 1; p.SH = H; p.SW = W; p.s_shift = 0; p.s_cstride = Cin; p.SC = Cin;
+  p.w_rows_per_tap = Cin; p.DD = g == 1 ? D : 2 * D; p.DH = 2 * H; p.DW = 2 * W; p.d_cstride = Cout; p.N = Cout;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      RdPhase& q = p.ph[ph * 2 + pw];
+      phase_defaults(q, D, H, W);
+      q.o_mul[0] = g == 1 ? 1 : 2; q.o_off[0] = g == 2 ? 1 : 0;
+      q.o_mul[1] = 2; q.o_off[1] = ph; q.o_mul[2] = 2; q.o_off[2] = pw;
+      q.ntaps = 4;
+      for (int t = 0; t < 4; ++t) {
+        const int th = t >> 1, tw = t & 1;
+        q.tap_off[t][0] = (int8_t)(g == 2 ? 1 : 0); q.tap_off[t][1] = (int8_t)(ph - 1 + th); q.tap_off[t][2] = (int8_t)(pw - 1 + tw);
+        q.tap[t].w = g * 16 + (ph * 2 + th) * 4 + (pw * 2 + tw);
+      }
+    }
+  return p;
+}
+// forward, difference part: E (D+1,H,W) -> out (2D,2H,2W); phase (pd,ph,pw): pd = 0 reads E[s] with A' = -W0,
+// pd = 1 reads E[s+1] with D = W2; the shared S x[s] part comes from plan_fastd_wgrad(g = 1) run as a forward plan
+// into T (one hour plane per output plane pair) and is added in the epilogue (RdEpi::addt)
+static RdPlan plan_fastd_fwd_e(int D, int H, int W, int Cin, int Cout) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 8; p.SD = D + 1; p.SH = H; p.SW = W; p.s_shift = 0; p.s_cstride = Cin; p.SC = Cin;
+  p.w_rows_per_tap = Cin; p.DD = 2 * D; p.DH = 2 * H; p.DW = 2 * W; p.d_cstride = Cout; p.N = Cout;
+  for (int i = 0; i < 8; ++i) {
+    const int pd = i >> 2, ph = (i >> 1) & 1, pw = i & 1;
+    RdPhase& q = p.ph[i];
+    phase_defaults(q, D, H, W);
+    for (int a = 0; a < 3; ++a) q.o_mul[a] = 2;
+    q.o_off[0] = pd; q.o_off[1] = ph; q.o_off[2] = pw;
+    q.ntaps = 4;
+    for (int t = 0; t < 4; ++t) {
+      const int th = t >> 1, tw = t & 1;
+      q.tap_off[t][0] = (int8_t)pd; q.tap_off[t][1] = (int8_t)(ph - 1 + th); q.tap_off[t][2] = (int8_t)(pw - 1 + tw);
+      q.tap[t].w = (pd ? 32 : 0) + (ph * 2 + th) * 4 + (pw * 2 + tw);
+    }
+  }
+  return p;
+}
+// input gradient, shared-centre part: gS (D,2H,2W) -> dxS (D,H,W), 16 taps (positions 2u+q-1 on h and w); weights UT[0..16)
+static RdPlan plan_fastd_dgrad_s(int D, int H, int W, int Cin, int Cout) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 1; p.SD = D; p.SH = 2 * H; p.SW = 2 * W; p.s_shift = 0; p.s_cstride = Cout; p.SC = Cout;
+  p.w_rows_per_tap = Cout; p.DD = D; p.DH = H; p.DW = W; p.d_cstride = Cin; p.N = Cin;
+  RdPhase& q = p.ph[0];
+  phase_defaults(q, D, H, W);
+  q.s_mul[1] = 2; q.s_mul[2] = 2;
+  q.ntaps = 16;
+  for (int t = 0; t < 16; ++t) {
+    q.tap_off[t][0] = 0; q.tap_off[t][1] = (int8_t)((t >> 2) - 1); q.tap_off[t][2] = (int8_t)((t & 3) - 1);
+    q.tap[t].w = t;
+  }
+  return p;
+}
+// input gradient, difference part: g (2D,2H,2W) -> dE (D+1,H,W): E[j] feeds output plane 2j through A' and plane 2j-1
+// through D; 32 taps, weights UT[16..48)
+static RdPlan plan_fastd_dgrad_e(int D, int H, int W, int Cin, int Cout) {
+  RdPlan p; memset(&p, 0, sizeof(p));
+  p.nphases = 1; p.SD = 2 * D; p.SH = 2 * H; p.SW = 2 * W; p.s_shift = 0; p.s_cstride = Cout; p.SC = Cout;
+  p.w_rows_per_tap = Cout; p.DD = D + 1; p.DH = H; p.DW = W; p.d_cstride = Cin; p.N = Cin;
+  RdPhase& q = p.ph[0];
+  phase_defaults(q, D + 1, H, W);
+  for (int a = 0; a < 3; ++a) q.s_mul[a] = 2;
+  q.ntaps = 32;
+  for (int t = 0; t < 32; ++t) {
+    q.tap_off[t][0] = (int8_t)(t < 16 ? 0 : -1); q.tap_off[t][1] = (int8_t)(((t >> 2) & 3) - 1); q.tap_off[t][2] = (int8_t)((t & 3) - 1);
+    q.tap[t].w = 16 + t;
+  }
+  return p;
+}
+// UT[slice] = U[map[slice]]^T for the two plans above: per axis position q = 0..3 is (p,t) = (1,1),(0,1),(1,0),(0,0)
+static void fastd_dgrad_slice_map(int16_t map[64]) {
+  const int qi[4] = {3, 1, 2, 0};    // p*2 + t
+  for (int i = 0; i < 64; ++i) map[i] = 0;
+  for (int t = 0; t < 16; ++t) {
+    const int hw = qi[t >> 2] * 4 + qi[t & 3];
+    map[t] = (int16_t)(16 + hw); map[16 + t] = (int16_t)hw; map[32 + t] = (int16_t)(32 + hw);
+  }
+}
+
 // plain row GEMM: rows (D,H,W) of `cstride` floats, first SC used -> [rows][dcs], N columns
 static RdPlan plan_rows(int D, int H, int W, int SC, int cstride, int N, int dcs) {
   RdPlan p; memset(&p, 0, sizeof(p));
@@ -235,7 +332,9 @@ static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
 enum {
   PL_GDENSE = 0, PL_G1F, PL_G2F, PL_G3F, PL_G9F, PL_G1B, PL_G2B, PL_G3B, PL_G9B,
   PL_D1F, PL_D2F, PL_D3F, PL_D4F, PL_D2B, PL_D3B, PL_D4B, PL_D1B,
-  PL_G1FC, PL_G2FC, PL_G3FC, PL_G1BC, PL_G2BC, PL_G3BC, PL_COUNT
+  PL_G1FC, PL_G2FC, PL_G3FC, PL_G1BC, PL_G2BC, PL_G3BC,
+  PL_F1WA, PL_F2WA, PL_F3WA, PL_F1WS, PL_F2WS, PL_F3WS, PL_F1WD, PL_F2WD, PL_F3WD,   // shared-centre backward (fast_bwd)
+  PL_F1BS, PL_F2BS, PL_F3BS, PL_F1BE, PL_F2BE, PL_F3BE, PL_F1FE, PL_F2FE, PL_F3FE, PL_COUNT
 };
 
 struct rdgan_handle {
@@ -265,6 +364,11 @@ struct rdgan_handle {
   float *wpartial, *cpartial, *kpartial;
   size_t wpartial_cap = 0, cpartial_cap = 0, kpartial_cap = 0;
   float *DWT[5], *W1T, *GWT[4], *W9T, *W1P, *dW1P;
+  // shared-centre form: per block the hour differences E of its input and the 48 weight forms U (written by the forward,
+  // reused by the backward); T / plane sums gS, the gradient wrt E, weight-form gradients and transposes (scratch)
+  float *fE[4], *fU[4], *fgS, *fdE, *fdU, *fUT;
+  int fast_fwd = 1;               // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products)
+  int fast_bwd = 1;               // 1: generator blocks' weight/input gradients in the shared-centre form along d (48 instead of 64 tap products)
   float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
   int collapse = 1;               // 1: 8-tap collapsed generator blocks (default); 0: direct 27-tap form
   int tapgather = 1;              // 1: last generator conv sums its in-tile taps in the GEMM epilogue; 0: full column matrix + gather kernel
@@ -329,7 +433,7 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
 #else
   // the BK = 32 kernels reuse the staging LDS for the output tile + BM row bases in the epilogue
   constexpr size_t lds_loop = 2 * (size_t)(BM * AST + BK * BST) * sizeof(float);
-  constexpr size_t lds_epi = BK == 32 ? ((size_t)BM * BN * sizeof(float) + (size_t)BM * 8) : 0;
+  constexpr size_t lds_epi = BK == 32 ? ((size_t)BM * BN * sizeof(float) + (size_t)BM * 16) : 0;
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
 #endif
   static bool attr_done = false;
@@ -351,7 +455,8 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   e2.ksplit = 1; e2.kpart = nullptr; e2.kstride = 0;
   const long nch = (long)hp.ph[0].ntaps * ((hp.SC + BK - 1) / BK);
   const long total = (long)B * hp.dst_sample;
-  if (h && blocks < 256 && nch >= 16 && hp.d_cstride == hp.N && hp.N % 4 == 0 && epi.mode != RD_EPI_BIAS_PN_LRELU) {
+  if (epi.addt && BK != 32) return bad_arg(h, "conv: the shared-centre epilogue needs the BK = 32 kernels");
+  if (h && blocks < 256 && nch >= 16 && hp.d_cstride == hp.N && hp.N % 4 == 0 && epi.mode != RD_EPI_BIAS_PN_LRELU && !epi.addt) {
     long ks = std::min<long>(std::min<long>(8, 640 / blocks), nch / 4);
     for (int i = 1; i < hp.nphases; ++i) ks = std::min<long>(ks, (long)hp.ph[i].ntaps * ((hp.SC + BK - 1) / BK) / 2);
     if (ks >= 2 && (size_t)(ks * total) <= h->kpartial_cap) { e2.ksplit = (int)ks; e2.kpart = h->kpartial; e2.kstride = total; }
@@ -369,7 +474,7 @@ template <int BM, int BN, int WM, int WN>
 static int launch_conv_ws_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                               const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
   constexpr size_t lds_loop = 2 * (size_t)(BM * 32 + 32 * BN) * sizeof(float);
-  constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float) + (size_t)BM * 8;
+  constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float) + (size_t)BM * 16;
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static bool attr_done = false;
   auto kern = k_conv_gemm_ws<BM, BN, WM, WN>;
@@ -389,7 +494,7 @@ static int launch_conv_ws_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* d
   // its last round.  Split K so that the workgroup count fills whole rounds; the partial sums cost one extra pass over
   // the (small) output, priced at 3 % per split.
   const long total = (long)B * hp.dst_sample;
-  if (h && h->ws_ksplit && blocks < 1024 && hp.d_cstride == hp.N && epi.mode != RD_EPI_BIAS_PN_LRELU) {
+  if (h && h->ws_ksplit && blocks < 1024 && hp.d_cstride == hp.N && epi.mode != RD_EPI_BIAS_PN_LRELU && !epi.addt) {
     long nch = (long)hp.ph[0].ntaps * (hp.SC / 32);
     for (int i = 1; i < hp.nphases; ++i) nch = std::min<long>(nch, (long)hp.ph[i].ntaps * (hp.SC / 32));
     auto cost = [&](long ks) { double r = (double)(blocks * ks) / 256.0; return std::ceil(r) / r * (1.0 + 0.03 * (ks - 1)); };
@@ -632,6 +737,19 @@ static int launch_pn_bwd(rdgan_handle* h, const float* g, const float* hh, const
   return 0;
 }
 
+// PixelNorm+LeakyReLU backward over hour-plane pairs, also writing the pair sums gS (shared-centre backward)
+static int launch_pn_bwd_pairs(rdgan_handle* h, const float* g, const float* hh, const float* rinv, float* dy, float* gS,
+                               long npair, long HW, int C, hipStream_t st) {
+  long threads = npair * (C / 4);
+  dim3 grid((unsigned)((threads + 255) / 256));
+  if (C == 256) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<64>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
+  else if (C == 128) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<32>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
+  else if (C == 64) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<16>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
+  else return bad_arg(h, "pixelnorm bwd: C must be 64/128/256");
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------
 // create / destroy
 // ------------------------------------------------------------------------------------
@@ -689,6 +807,11 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->plans[PL_G1B + l - 1] = plan_conv_dgrad_s1(od[0], od[1], od[2], gch[l - 1], gch[l]);
     h->plans[PL_G1FC + l - 1] = plan_upconv_fwd_collapsed(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
     h->plans[PL_G1BC + l - 1] = plan_upconv_dgrad_collapsed(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
+    for (int g = 0; g < 3; ++g)
+      h->plans[PL_F1WA + 3 * g + l - 1] = plan_fastd_wgrad(sd[0], sd[1], sd[2], gch[l - 1], gch[l], g);
+    h->plans[PL_F1BS + l - 1] = plan_fastd_dgrad_s(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
+    h->plans[PL_F1BE + l - 1] = plan_fastd_dgrad_e(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
+    h->plans[PL_F1FE + l - 1] = plan_fastd_fwd_e(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
   }
   {
     const int* g3 = h->gdim[3];
@@ -722,7 +845,8 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
   const long MB = h->MB, NB = h->NB;
   size_t wneed = 0;
   {
-    const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B, PL_G1FC, PL_G2FC, PL_G3FC};
+    const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B, PL_G1FC, PL_G2FC, PL_G3FC,
+                      PL_F1WA, PL_F2WA, PL_F3WA, PL_F1WS, PL_F2WS, PL_F3WS, PL_F1WD, PL_F2WD, PL_F3WD};
     for (int id : wg) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)MB));
     const int wd[] = {PL_D1F, PL_D2F, PL_D3F, PL_D4F};
     for (int id : wd) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)NB));
@@ -777,6 +901,22 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->GWC[0] = h->GWD[0] = nullptr;
     for (int l = 1; l <= 3; ++l) { carve(h->GWC[l], 64L * gch[l - 1] * gch[l]); carve(h->GWD[l], 64L * gch[l - 1] * gch[l]); }
     carve(h->dWc, 64L * 256 * 256);
+    {
+      size_t ne = 0, ns = 0;
+      for (int l = 1; l <= 3; ++l) {
+        const int* sd = h->gdim[l - 1];
+        ne = std::max(ne, (size_t)(sd[0] + 1) * sd[1] * sd[2] * gch[l - 1]);
+        ns = std::max(ns, (size_t)sd[0] * 4 * sd[1] * sd[2] * gch[l]);
+      }
+      h->fE[0] = h->fU[0] = nullptr;
+      for (int l = 1; l <= 3; ++l) {
+        const int* sd = h->gdim[l - 1];
+        carve(h->fE[l], MB * (size_t)(sd[0] + 1) * sd[1] * sd[2] * gch[l - 1]);
+        carve(h->fU[l], 48L * gch[l - 1] * gch[l]);
+      }
+      carve(h->fdE, MB * ne); carve(h->fgS, MB * ns);
+      carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
+    }
     { float* f = nullptr; carve(f, 64); if (pass == 1) h->d_flag = (int*)f; }
     if (pass == 0) {
       h->ws_bytes = off + 256;
@@ -820,6 +960,8 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!h || !name) return -2;
   if (!strcmp(name, "collapse")) { h->collapse = value ? 1 : 0; return 0; }
   if (!strcmp(name, "wave_specialized")) { h->wave_spec = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }   // 2 = also for small problems (tests)
+  if (!strcmp(name, "fast_fwd")) { h->fast_fwd = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "ws_ksplit")) { h->ws_ksplit = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }   // > 1 = force (tests)
   return bad_arg(h, "set_option: unknown option");
@@ -861,7 +1003,13 @@ static RdEpi epi_make(int mode, const float* bias = nullptr, const float* aux = 
                       uint32_t key = 0, uint32_t idx_base = 0) {
   RdEpi e; e.mode = mode; e.use_drop = use_drop; e.key = key; e.idx_base = idx_base; e.bias = bias; e.aux = aux;
   e.ksplit = 1; e.kpart = nullptr; e.kstride = 0; e.rinv = nullptr; e.gw = e.ghw = e.gq = 0;
+  e.addt = nullptr; e.addt_plane = 0;
   return e;
+}
+
+// the shared-centre form pays where the hour axis of the block input is long enough for its (D+1)/D boundary plane
+static bool gen_block_fast(const rdgan_handle* h, int l, int enabled) {
+  return h->collapse && enabled && h->gdim[l - 1][0] >= 6;
 }
 
 static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, const float* cond, float* out, int B,
@@ -883,6 +1031,33 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     // UpSampling3D + Conv3D + bias (T:330-331), then PixelNorm + LeakyReLU (T:332-333)
     const float* Wl = gp + h->goff[2 * l];
     int pl = PL_G1F + l - 1;
+    if (gen_block_fast(h, l, h->fast_fwd)) {
+      // shared-centre form along the hour axis: T = S x[s] once per output plane pair, then the difference part
+      const int* sd = h->gdim[l - 1];
+      const long P = (long)sd[1] * sd[2] * h->gch[l - 1];
+      const long cc = (long)h->gch[l - 1] * h->gch[l];
+      RdWeightMap wm;
+      fastd_weight_map(wm);
+      {
+        ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+        hipLaunchKernelGGL(k_diff_d, dim3(ew_blocks((long)B * (sd[0] + 1) * P / 4)), dim3(256), 0, st, hs[l - 1], h->fE[l], B, sd[0], P);
+        hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, Wl, h->fU[l], (int)cc, 48, wm);
+      }
+      const int pls = PL_F1WS + l - 1, ple = PL_F1FE + l - 1;
+      RD_TRY(launch_conv(h, h->plans[pls], h->d_plans + pls, B, hs[l - 1], h->fU[l], h->gch[l], h->fgS, epi_make(RD_EPI_PLAIN), st,
+                         RDGAN_TAG_GCONV_FWD));
+      const bool fuse = conv_rows_owned(h->plans[ple], B);
+      RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
+      ep.rinv = rs[l];
+      ep.addt = h->fgS; ep.addt_plane = 4 * sd[1] * sd[2] * h->gch[l];
+      RD_TRY(launch_conv(h, h->plans[ple], h->d_plans + ple, B, h->fE[l], h->fU[l], h->gch[l], hs[l], ep, st,
+                         l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
+      if (!fuse) {
+        ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+        RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st));
+      }
+      continue;
+    }
     if (h->collapse) {
       hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * h->gch[l - 1] * h->gch[l])), dim3(256), 0, st, Wl,
                          h->GWC[l], h->gch[l - 1] * h->gch[l]);
@@ -1117,19 +1292,71 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
   if (col) {
     RdSliceMap map;
     collapsed_dgrad_slice_map(map.src);
-    for (int l = 1; l <= 3; ++l)   // Wd[q][Cout][Cin] <- Wc (written by gen_forward_impl above)
+    for (int l = 1; l <= 3; ++l) {   // Wd[q][Cout][Cin] <- Wc (written by gen_forward_impl above unless that block ran in the shared-centre form)
+      if (gen_block_fast(h, l, h->fast_bwd)) continue;
+      if (gen_block_fast(h, l, h->fast_fwd))
+        hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * h->gch[l - 1] * h->gch[l])), dim3(256), 0, st,
+                           gp + h->goff[2 * l], h->GWC[l], h->gch[l - 1] * h->gch[l]);
       hipLaunchKernelGGL(k_transpose_map, dim3((h->gch[l] + 31) / 32, (h->gch[l - 1] + 31) / 32, 64), dim3(256), 0, st,
                          h->GWC[l], h->GWD[l], h->gch[l - 1], h->gch[l], map);
+    }
   }
   for (int l = 3; l >= 1; --l) {
-    {
+    // shared-centre backward only where the hour axis is long enough to pay for its (D+1)/D boundary plane
+    const bool fast = gen_block_fast(h, l, h->fast_bwd);
+    if (fast) {
+      ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+      const long HW = (long)h->gdim[l][1] * h->gdim[l][2];
+      RD_TRY(launch_pn_bwd_pairs(h, l == 3 ? h->gh3 : gups[l + 1], hs[l], rs[l], dys[l], h->fgS, (long)B * h->gdim[l - 1][0] * HW,
+                                 HW, h->gch[l], st));
+    } else {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
       if (l == 3) RD_TRY(launch_pn_bwd(h, h->gh3, hs[3], rs[3], dys[3], npix3, 64, 0, 0, 0, 0, st));
       else RD_TRY(launch_pn_bwd(h, gups[l + 1], hs[l], rs[l], dys[l], (long)B * h->gpix[l], h->gch[l], col ? 0 : 1,
                                 h->gdim[l][0], h->gdim[l][1], h->gdim[l][2], st));
     }
     const long cc = (long)h->gch[l - 1] * h->gch[l];
-    if (col) {
+    if (fast) {
+      // shared-centre form along d: E = d-differences of the block input, gS = sums of the output-gradient plane pairs
+      const int* sd = h->gdim[l - 1];
+      const int D = sd[0];
+      const long P = (long)sd[1] * sd[2] * h->gch[l - 1];
+      RdWeightMap wm;
+      fastd_weight_map(wm);
+      {
+        ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+        if (!gen_block_fast(h, l, h->fast_fwd)) {      // (otherwise the forward pass above has left both)
+          hipLaunchKernelGGL(k_diff_d, dim3(ew_blocks((long)B * (D + 1) * P / 4)), dim3(256), 0, st, hs[l - 1], h->fE[l], B, D, P);
+          hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, gp + h->goff[2 * l], h->fU[l],
+                             (int)cc, 48, wm);
+        }
+      }
+      const float* wsrc[3] = {h->fE[l], hs[l - 1], h->fE[l]};
+      const float* wdy[3] = {dys[l], h->fgS, dys[l]};
+      for (int g = 0; g < 3; ++g) {
+        const int pl = PL_F1WA + 3 * g + l - 1;
+        RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, B, wsrc[g], wdy[g], h->fdU, h->wpartial, h->wpartial_cap, st,
+                            RDGAN_TAG_GCONV_WGRAD));
+      }
+      hipLaunchKernelGGL(k_weight_transform_adj, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->fdU, grad + h->goff[2 * l],
+                         (int)cc, 48, wm);
+      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
+      {
+        RdSliceMap map;
+        fastd_dgrad_slice_map(map.src);
+        hipLaunchKernelGGL(k_transpose_map, dim3((h->gch[l] + 31) / 32, (h->gch[l - 1] + 31) / 32, 48), dim3(256), 0, st, h->fU[l],
+                           h->fUT, h->gch[l - 1], h->gch[l], map);
+      }
+      const int pbs = PL_F1BS + l - 1, pbe = PL_F1BE + l - 1;
+      RD_TRY(launch_conv(h, h->plans[pbs], h->d_plans + pbs, B, h->fgS, h->fUT, h->gch[l - 1], gups[l], epi_make(RD_EPI_PLAIN), st,
+                         RDGAN_TAG_GCONV_DGRAD));
+      RD_TRY(launch_conv(h, h->plans[pbe], h->d_plans + pbe, B, dys[l], h->fUT, h->gch[l - 1], h->fdE, epi_make(RD_EPI_PLAIN), st,
+                         RDGAN_TAG_GCONV_DGRAD));
+      {
+        ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+        hipLaunchKernelGGL(k_combine_dx, dim3(ew_blocks((long)B * D * P / 4)), dim3(256), 0, st, gups[l], h->fdE, B, D, P);
+      }
+    } else if (col) {
       int plf = PL_G1FC + l - 1, plb = PL_G1BC + l - 1;
       RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap,
                           st, RDGAN_TAG_GCONV_WGRAD));

@@ -65,6 +65,24 @@ __global__ void k_pixelnorm_lrelu_fwd(const float* __restrict__ y, float* __rest
 //   n = h>0 ? h : h/alpha ; gn = gh*slope(h) ; dy = rinv*(gn - n*mean_c(gn*n))
 // gh is either given on the same grid (POOL=0) or as the gradient on the 2x upsampled grid of the
 // next block's conv input, in which case the 8 children are summed first (adjoint of UpSampling3D, T:335).
+template <int LP>
+__device__ __forceinline__ f32x4 rd_pn_lrelu_bwd_row(f32x4 gh, f32x4 hv, float ri) {
+  constexpr int C = LP * 4;
+  f32x4 n, gn;
+  n.x = hv.x > 0.f ? hv.x : hv.x * (1.0f / RD_LRELU_ALPHA);
+  n.y = hv.y > 0.f ? hv.y : hv.y * (1.0f / RD_LRELU_ALPHA);
+  n.z = hv.z > 0.f ? hv.z : hv.z * (1.0f / RD_LRELU_ALPHA);
+  n.w = hv.w > 0.f ? hv.w : hv.w * (1.0f / RD_LRELU_ALPHA);
+  gn.x = gh.x * rd_lrelu_slope_from_out(hv.x);
+  gn.y = gh.y * rd_lrelu_slope_from_out(hv.y);
+  gn.z = gh.z * rd_lrelu_slope_from_out(hv.z);
+  gn.w = gh.w * rd_lrelu_slope_from_out(hv.w);
+  const float dot = rd_seg_sum<LP>(gn.x * n.x + gn.y * n.y + gn.z * n.z + gn.w * n.w) * (1.0f / C);
+  f32x4 o;
+  o.x = ri * (gn.x - n.x * dot); o.y = ri * (gn.y - n.y * dot);
+  o.z = ri * (gn.z - n.z * dot); o.w = ri * (gn.w - n.w * dot);
+  return o;
+}
 template <int LP, int POOL>
 __global__ void k_pn_lrelu_bwd(const float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ rinv,
                                float* __restrict__ dy, long npix, int D, int H, int W) {
@@ -93,21 +111,34 @@ __global__ void k_pn_lrelu_bwd(const float* __restrict__ g, const float* __restr
       gh = *(const f32x4*)(g + pix * C + sub * 4);
     }
   }
-  f32x4 n, gn;
-  n.x = hv.x > 0.f ? hv.x : hv.x * (1.0f / RD_LRELU_ALPHA);
-  n.y = hv.y > 0.f ? hv.y : hv.y * (1.0f / RD_LRELU_ALPHA);
-  n.z = hv.z > 0.f ? hv.z : hv.z * (1.0f / RD_LRELU_ALPHA);
-  n.w = hv.w > 0.f ? hv.w : hv.w * (1.0f / RD_LRELU_ALPHA);
-  gn.x = gh.x * rd_lrelu_slope_from_out(hv.x);
-  gn.y = gh.y * rd_lrelu_slope_from_out(hv.y);
-  gn.z = gh.z * rd_lrelu_slope_from_out(hv.z);
-  gn.w = gh.w * rd_lrelu_slope_from_out(hv.w);
-  float dot = rd_seg_sum<LP>(gn.x * n.x + gn.y * n.y + gn.z * n.z + gn.w * n.w) * (1.0f / C);
+  const f32x4 o = rd_pn_lrelu_bwd_row<LP>(gh, hv, ri);
+  if (ok) *(f32x4*)(dy + pix * C + sub * 4) = o;
+}
+// same (POOL = 0) over PAIRS of hour planes (2s, 2s+1) of a block output, additionally writing their sum
+// gS[b][s][h][w][:] = dy[b][2s][h][w][:] + dy[b][2s+1][h][w][:] for the shared-centre backward (k_presum_d fused in).
+// npair = B * Ds * HW pixel pairs, HW = pixels per hour plane.
+template <int LP>
+__global__ void k_pn_lrelu_bwd_pairs(const float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ rinv,
+                                     float* __restrict__ dy, float* __restrict__ gS, long npair, long HW) {
+  constexpr int C = LP * 4;
+  const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long pr = gid / LP;
+  const int sub = (int)(gid % LP);
+  const bool ok = pr < npair;
+  const long bs = pr / HW, hw = pr - bs * HW;
+  const long pixA = (2 * bs) * HW + hw, pixB = pixA + HW;
+  f32x4 ga = {0.f, 0.f, 0.f, 0.f}, ha = ga, gb = ga, hb = ga;
+  float ra = 0.f, rb = 0.f;
   if (ok) {
-    f32x4 o;
-    o.x = ri * (gn.x - n.x * dot); o.y = ri * (gn.y - n.y * dot);
-    o.z = ri * (gn.z - n.z * dot); o.w = ri * (gn.w - n.w * dot);
-    *(f32x4*)(dy + pix * C + sub * 4) = o;
+    ga = *(const f32x4*)(g + pixA * C + sub * 4); ha = *(const f32x4*)(h + pixA * C + sub * 4); ra = rinv[pixA];
+    gb = *(const f32x4*)(g + pixB * C + sub * 4); hb = *(const f32x4*)(h + pixB * C + sub * 4); rb = rinv[pixB];
+  }
+  const f32x4 oa = rd_pn_lrelu_bwd_row<LP>(ga, ha, ra);
+  const f32x4 ob = rd_pn_lrelu_bwd_row<LP>(gb, hb, rb);
+  if (ok) {
+    *(f32x4*)(dy + pixA * C + sub * 4) = oa;
+    *(f32x4*)(dy + pixB * C + sub * 4) = ob;
+    *(f32x4*)(gS + pr * C + sub * 4) = oa + ob;
   }
 }
 
@@ -639,5 +670,67 @@ __global__ void k_unpad_w1(const float* __restrict__ wp, float* __restrict__ w, 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     int co = i % 64, c = (i / 64) % Cin, t = i / (64 * Cin);
     w[i] = wp[(t * CP + c) * 64 + co];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Shared-centre form of UpSampling3D(2)+Conv3D(3^3,'same') along the hour axis d (backward pass).
+// Per axis the two outputs of a source position are  out[2s] = W0 x[s-1] + (W1+W2) x[s],  out[2s+1] = (W0+W1) x[s] +
+// W2 x[s+1].  With E[j] = x[j] - x[j-1] (x zero-extended, j = 0..D) and S = W0+W1+W2 this is
+//   out[2s] = S x[s] - W0 E[s],   out[2s+1] = S x[s] + W2 E[s+1]:
+// the S x[s] product is shared by both outputs, so the weight and input gradients need 3 instead of 4 tap products per
+// source position on that axis (48 instead of 64 per position overall; the other two axes keep the collapsed form).
+// U[u] = sum_k c[u][k] W[k] with u = (group A',S,D) x (ph,th) x (pw,tw) and c in {-1,0,1}.
+// ------------------------------------------------------------------------------------
+struct RdWeightMap { int8_t c[48][27]; };
+
+__global__ void k_weight_transform(const float* __restrict__ W, float* __restrict__ U, int CC, int nu, RdWeightMap T) {
+  const int c4s = CC / 4;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < (long)nu * c4s; f += (long)gridDim.x * blockDim.x) {
+    const int u = (int)(f / c4s), e = (int)(f - (long)u * c4s) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 27; ++k) {
+      const int c = T.c[u][k];
+      if (c) { const f32x4 w = *(const f32x4*)(W + (long)k * CC + e); s += c > 0 ? w : -w; }
+    }
+    *(f32x4*)(U + (long)u * CC + e) = s;
+  }
+}
+// adjoint: dW[k] = sum_u c[u][k] dU[u]
+__global__ void k_weight_transform_adj(const float* __restrict__ dU, float* __restrict__ dW, int CC, int nu, RdWeightMap T) {
+  const int c4s = CC / 4;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < 27L * c4s; f += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(f / c4s), e = (int)(f - (long)k * c4s) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < nu; ++u) {
+      const int c = T.c[u][k];
+      if (c) { const f32x4 w = *(const f32x4*)(dU + (long)u * CC + e); s += c > 0 ? w : -w; }
+    }
+    *(f32x4*)(dW + (long)k * CC + e) = s;
+  }
+}
+// E[b][j][:] = x[b][j][:] - x[b][j-1][:], j = 0..D, x zero outside [0,D); P = floats per d-plane (multiple of 4)
+__global__ void k_diff_d(const float* __restrict__ x, float* __restrict__ E, int B, int D, long P) {
+  const long p4 = P / 4, total = (long)B * (D + 1) * p4;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+    const long i = f % p4; const long bj = f / p4;
+    const int j = (int)(bj % (D + 1)); const long b = bj / (D + 1);
+    const float* xb = x + (b * D) * P + i * 4;
+    f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = hi;
+    if (j < D) hi = *(const f32x4*)(xb + (long)j * P);
+    if (j > 0) lo = *(const f32x4*)(xb + (long)(j - 1) * P);
+    *(f32x4*)(E + f * 4) = hi - lo;
+  }
+}
+// dx[b][d][:] += dE[b][d][:] - dE[b][d+1][:]   (adjoint of k_diff_d added to the shared-centre part already in dx)
+__global__ void k_combine_dx(float* __restrict__ dx, const float* __restrict__ dE, int B, int D, long P) {
+  const long p4 = P / 4, total = (long)B * D * p4;
+  for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+    const long i = f % p4; const long bd = f / p4;
+    const int d = (int)(bd % D); const long b = bd / D;
+    const float* e = dE + ((b * (D + 1) + d) * P) + i * 4;
+    f32x4 v = *(const f32x4*)(dx + f * 4);
+    v += *(const f32x4*)e - *(const f32x4*)(e + P);
+    *(f32x4*)(dx + f * 4) = v;
   }
 }

@@ -423,15 +423,19 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 #pragma unroll
         for (int j = 0; j < TN; ++j) Cs[row * BN + wn * WTN + j * 32 + l31] = acc[i][j][r];
       }
+    int* Tb = Rb + 2 * BM;                              // [BM][2]: row base inside epi.addt (shared-centre forward)
     if (tid < BM) {
-      long rb = -1;
+      long rb = -1, tb = 0;
       if (m0 + tid < rows) {
         int l = l0 + tid, bb = b0;
         if (L >= BM) { if (l >= L) { l -= L; bb += 1; } }
         else { int qd = l / L; l -= qd * L; bb += qd; }
-        rb = (long)bb * dsample + tab[l].z;
+        const int z = tab[l].z;
+        rb = (long)bb * dsample + z;
+        if (epi.addt) tb = (long)bb * (dsample >> 1) + z - (long)((z / epi.addt_plane + 1) >> 1) * epi.addt_plane;
       }
       Rb[2 * tid] = (int)(rb & 0xFFFFFFFFll); Rb[2 * tid + 1] = (int)(rb >> 32);
+      Tb[2 * tid] = (int)(tb & 0xFFFFFFFFll); Tb[2 * tid + 1] = (int)(tb >> 32);
     }
     __syncthreads();
     constexpr int F4R = BN / 4;                         // float4s per row; 256 % F4R == 0, so a thread's columns are fixed
@@ -452,6 +456,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
         *(f32x4*)(epi.kpart + (long)blockIdx.y * epi.kstride + idx0) = v;
         continue;
       }
+      if (epi.addt) v += *(const f32x4*)(epi.addt + ((((long)Tb[2 * row + 1] << 32) | (unsigned)Tb[2 * row]) + col));
       if (mode == RD_EPI_BIAS) {
         v += bias4;
       } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {

@@ -212,6 +212,7 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
   const int mode = epi.mode;
   float* Cs = smem;
   int* Rb = (int*)(smem + BM * BN);
+  int* Tb = Rb + 2 * BM;                                 // row base inside epi.addt (shared-centre forward)
   if (is_compute) {
     const int wm = wave / WN, wn = wave % WN;
 #pragma unroll
@@ -224,14 +225,17 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       }
   } else if (tid - 256 < BM) {
     const int row = tid - 256;
-    long rb = -1;
+    long rb = -1, tb = 0;
     if (m0 + row < rows) {
       int l = l0 + row, bb = b0;
       if (L >= BM) { if (l >= L) { l -= L; bb += 1; } }
       else { int qd = l / L; l -= qd * L; bb += qd; }
-      rb = (long)bb * dsample + tab[l].z;
+      const int z = tab[l].z;
+      rb = (long)bb * dsample + z;
+      if (epi.addt) tb = (long)bb * (dsample >> 1) + z - (long)((z / epi.addt_plane + 1) >> 1) * epi.addt_plane;
     }
     Rb[2 * row] = (int)(rb & 0xFFFFFFFFll); Rb[2 * row + 1] = (int)(rb >> 32);
+    Tb[2 * row] = (int)(tb & 0xFFFFFFFFll); Tb[2 * row + 1] = (int)(tb >> 32);
   }
   __syncthreads();
   constexpr int F4R = BN / 4;
@@ -252,6 +256,7 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       *(f32x4*)(epi.kpart + (long)blockIdx.y * epi.kstride + idx0) = v;
       continue;
     }
+    if (epi.addt) v += *(const f32x4*)(epi.addt + ((((long)Tb[2 * row + 1] << 32) | (unsigned)Tb[2 * row]) + col));
     if (mode == RD_EPI_BIAS) {
       v += bias4;
     } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {

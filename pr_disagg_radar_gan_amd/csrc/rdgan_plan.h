@@ -75,4 +75,8 @@ struct RdEpi {
   long kstride;
   float* rinv;                 // RD_EPI_BIAS_PN_LRELU: per-pixel 1/sqrt(mean(y^2)+eps), kept for the backward pass
   int gw, ghw, gq;             // RD_EPI_TAPGATHER: plane width W, plane size H*W, sums per row (3 or 9)
+  // shared-centre forward (second GEMM): before the mode's own work add T[b][plane >> 1][...] to the row, where
+  // plane = (offset of the row inside its sample) / addt_plane is the output hour plane; T holds one plane per PAIR
+  const float* addt;
+  int addt_plane;              // floats per output hour plane (2H * 2W * Cout)
 };

@@ -33,11 +33,12 @@ def eng16():
     e.close()
 
 
-@pytest.mark.parametrize("collapse,ws", [(1, 1), (0, 1), (1, 2)])
+@pytest.mark.parametrize("collapse,ws,fast", [(1, 1, 1), (0, 1, 0), (1, 2, 1), (1, 1, 0), (1, 2, 0)])
 @pytest.mark.parametrize("B", [1, 2, 5])
-def test_generator_forward_parity(eng16, B, collapse, ws):
+def test_generator_forward_parity(eng16, B, collapse, ws, fast):
     eng16.set_option("collapse", collapse)      # 8-tap collapsed blocks (default) vs the direct 27-tap form
     eng16.set_option("wave_specialized", ws)    # 2 = force the producer/consumer (LDS-DMA) kernel at these small sizes
+    eng16.set_option("fast_fwd", fast)          # shared-centre form of blocks 2, 3 (48 vs 64 tap products)
     g, _ = _params(16, 11)
     x, cond, z = ot.synthetic_batch(B, 16, 3)
     ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
@@ -128,11 +129,13 @@ def test_critic_step_grads_parity(eng16, B, seed, ws):
     _parity_over_batches(run_case)
 
 
-@pytest.mark.parametrize("collapse,ws", [(1, 1), (0, 1), (1, 2)])
+@pytest.mark.parametrize("collapse,ws,fast", [(1, 1, 1), (0, 1, 0), (1, 2, 1), (1, 1, 0), (1, 2, 0)])
 @pytest.mark.parametrize("B,seed", [(2, 4321), (3, 0)])
-def test_gen_step_grads_parity(eng16, B, seed, collapse, ws):
+def test_gen_step_grads_parity(eng16, B, seed, collapse, ws, fast):
     eng16.set_option("collapse", collapse)
     eng16.set_option("wave_specialized", ws)
+    eng16.set_option("fast_bwd", fast)          # shared-centre form of the blocks' weight / input gradients (48 vs 64 tap products)
+    eng16.set_option("fast_fwd", (fast + B) % 2)   # every forward/backward combination occurs
     g, d = _params(16, 14)
 
     def run_case(data_seed):
