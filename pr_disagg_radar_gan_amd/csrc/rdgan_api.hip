@@ -470,14 +470,26 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   return 0;
 }
 
+template <int BM, int BN, int WM, int WN, int TG>
+static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
+                             const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st);
+// TG = taps whose gather offsets a loader wave keeps in registers: 4 when no phase has more (shared-centre plans)
 template <int BM, int BN, int WM, int WN>
 static int launch_conv_ws_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                               const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
+  int maxtaps = 0;
+  for (int i = 0; i < hp.nphases; ++i) maxtaps = std::max(maxtaps, hp.ph[i].ntaps);
+  if (maxtaps <= 4) return launch_conv_ws_tg<BM, BN, WM, WN, 4>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  return launch_conv_ws_tg<BM, BN, WM, WN, 8>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+}
+template <int BM, int BN, int WM, int WN, int TG>
+static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
+                             const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
   constexpr size_t lds_loop = 2 * (size_t)(BM * 32 + 32 * BN) * sizeof(float);
   constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float) + (size_t)BM * 16;
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static bool attr_done = false;
-  auto kern = k_conv_gemm_ws<BM, BN, WM, WN>;
+  auto kern = k_conv_gemm_ws<BM, BN, WM, WN, TG>;
   if (!attr_done) {
     RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -487,6 +499,7 @@ static int launch_conv_ws_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* d
   long minL = hp.ph[0].L;
   for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
   if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
+  if ((BM / minL + 2) * hp.dst_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: destination tile span exceeds 2 GiB");
   RdEpi e2 = epi;
   e2.ksplit = 1; e2.kpart = nullptr; e2.kstride = 0;
   const long blocks = tm * (hp.N / BN);
@@ -1545,6 +1558,13 @@ extern "C" int rdgan_debug_stamps(unsigned long long* out, int reset) {
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess && out) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(rd_stamp_acc), sizeof(z));
   if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(rd_stamp_acc), z, sizeof(z));
+  return (int)e;
+}
+extern "C" int rdgan_debug_stamps_ws(unsigned long long* out, int reset) {
+  unsigned long long z[8] = {0};
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess && out) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(rd_stamp_ws), sizeof(z));
+  if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(rd_stamp_ws), z, sizeof(z));
   return (int)e;
 }
 #endif

@@ -19,6 +19,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 #define RD_LRELU_ALPHA 0.2f
 #ifndef RD_PRIO_LOAD
@@ -148,19 +149,30 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(W + P.w_off);
 
   // ---- per-thread A rows: byte offset relative to sample b0 (incl. this thread's channel group), validity bits
+  // (branch-free: the A_P row-table loads are issued back to back and waited for once)
   int roff[A_P], rbits[A_P], rcode[A_P];
   const int a_c4 = (tid % A_F4) * 4;
+  {
+    int rl[A_P], rb_[A_P];
+    bool rok[A_P];
 #pragma unroll
-  for (int i = 0; i < A_P; ++i) {
-    int r = tid / A_F4 + i * A_RPP;
-    roff[i] = 0; rbits[i] = 0; rcode[i] = 0;
-    if (r < BM && m0 + r < rows) {
+    for (int i = 0; i < A_P; ++i) {
+      const int r = tid / A_F4 + i * A_RPP;
       int l = l0 + r, bb = 0;
       if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
       else { bb = l / L; l -= bb * L; }
-      RdRow e = rd_row(tab, l);
-      roff[i] = (bb * ssample + e.x + a_c4) * 4;
-      rbits[i] = e.y; rcode[i] = e.w;
+      rok[i] = r < BM && m0 + r < rows;
+      rl[i] = rok[i] ? l : 0;
+      rb_[i] = bb;
+    }
+    RdRow e[A_P];
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) e[i] = rd_row(tab, rl[i]);
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      roff[i] = rok[i] ? (rb_[i] * ssample + e[i].x + a_c4) * 4 : 0;
+      rbits[i] = rok[i] ? e[i].y : 0;
+      rcode[i] = rok[i] ? e[i].w : 0;
     }
   }
   // ---- per-thread B (weight) rows

@@ -14,17 +14,38 @@
 #pragma once
 #include "rdgan_gemm.hip.h"
 
+#ifdef RD_STAMP
+__device__ unsigned long long rd_stamp_ws[8];   // diagnostic build only: cumulative s_memtime marks of k_conv_gemm_ws (scratch/stamp_ws.py)
+#endif
 // 16 bytes per lane, global -> LDS, no VGPR destination: LDS address = wave-uniform `lds` + lane*16
 __device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void rd_buf_store4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void rd_buf_store1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, 0);
+}
+// sum over an aligned group of N lanes (N = 16: one DPP row, four rotate-adds; N = 32: plus one cross-row exchange)
+template <int N>
+__device__ __forceinline__ float rd_lanes_sum(float v) {
+  static_assert(N == 16 || N == 32, "row group");
+#define RD_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  RD_DPP_ADD(0x128); RD_DPP_ADD(0x124); RD_DPP_ADD(0x122); RD_DPP_ADD(0x121);   // row_ror:8, 4, 2, 1
+#undef RD_DPP_ADD
+  if (N == 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN, int TG>
 __global__ void __launch_bounds__(512, 4)
 k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
                const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {
   static_assert(WM * WN == 4, "4 compute waves");
-  constexpr int BK = 32, TG = 8;
+  constexpr int BK = 32;
+  static_assert(TG == 4 || TG == 8, "taps per register group");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   constexpr int STAGE = BM * BK + BK * BN;                 // floats per LDS stage
   constexpr int NI_A = BM / 32;                            // A DMA instructions (1 KiB = 8 rows) per loader wave and chunk
@@ -38,15 +59,31 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_compute = wave < 4;
   const int l31 = lane & 31, lhalf = lane >> 5;
+  // everything outside the MFMA loop runs at raised priority: beside the other resident workgroup's MFMA stream a
+  // priority-0 wave gets about one issue slot per 64-cycle MFMA
+  __builtin_amdgcn_s_setprio(3);
+#ifdef RD_STAMP
+  const unsigned long long ws_t0 = rd_stamp();
+  const bool ws_st = BM == 256 && epi.addt != nullptr && lane == 0;
+#endif
 
   // ---- which phase / tile (wave-uniform)
-  const int NTn = plan->N / BN;
+  // (every instruction in front of the first DMA delays the first MFMA by ~50 cycles beside the other resident
+  // workgroup's MFMA stream, so the decode avoids integer divisions: N / BN and the phase count of an interleaved plan
+  // are powers of two)
+  constexpr int BN_LOG2 = BN == 128 ? 7 : 6;
+  static_assert(BN == 128 || BN == 64, "BN");
+  const int ntn_log2 = __builtin_ctz(plan->N >> BN_LOG2);
   const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
-  const int ntile = swz % NTn;
-  int mt = swz / NTn, pidx = 0;
-  if (plan->interleave) {
-    pidx = mt % plan->nphases;
-    mt /= plan->nphases;
+  const int ntile = swz & ((1 << ntn_log2) - 1);
+  int mt = swz >> ntn_log2, pidx = 0;
+  const int nph = plan->nphases;
+  if (plan->interleave && (nph & (nph - 1)) == 0) {
+    pidx = mt & (nph - 1);
+    mt >>= __builtin_ctz(nph);
+  } else if (plan->interleave) {
+    pidx = mt % nph;
+    mt /= nph;
   } else {
     for (int p = 0; p < plan->nphases; ++p) {
       int nt = (B * plan->ph[p].L + BM - 1) / BM;
@@ -67,9 +104,12 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
   const int CPT = SC / BK;
   const int nch_all = ntaps * CPT;
   const int ksplit = epi.ksplit > 1 ? epi.ksplit : 1;
-  const int per_split = (nch_all + ksplit - 1) / ksplit;
-  const int q0 = (int)blockIdx.y * per_split;
-  const int nchunks = max(0, min(nch_all, q0 + per_split) - q0);
+  int q0 = 0, nchunks = nch_all;
+  if (ksplit > 1) {
+    const int per_split = (nch_all + ksplit - 1) / ksplit;
+    q0 = (int)blockIdx.y * per_split;
+    nchunks = max(0, min(nch_all, q0 + per_split) - q0);
+  }
 
   f32x16 acc[TM][TN];
 
@@ -79,18 +119,30 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
     const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)b0 * plan->src_sample);
     const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(W + P.w_off);
     // A: instruction k of this wave fills rows wl*(BM/4) + 8k .. +7; this lane: row +(lane>>3), physical chunk lane&7
+    // (branch-free, so that the NI_A row-table loads go out back to back and are waited for once: with a branch per
+    // row hipcc serialises them, one memory round trip each, and the first DMA leaves ~10 us late)
     int roff[NI_A], rbits[NI_A];
+    {
+      int rl[NI_A], rb_[NI_A];
 #pragma unroll
-    for (int k = 0; k < NI_A; ++k) {
-      const int r = wl * (BM / 4) + k * 8 + (lane >> 3);
-      const int c_log = (lane & 7) ^ ((r >> 1) & 7);
-      roff[k] = 0; rbits[k] = 0;
-      if (m0 + r < rows) {
+      for (int k = 0; k < NI_A; ++k) {
+        const int r = wl * (BM / 4) + k * 8 + (lane >> 3);
         int l = l0 + r, bb = 0;
         if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
         else { bb = l / L; l -= bb * L; }
-        roff[k] = (bb * ssample + tab[l].x + c_log * 4) * 4;
-        rbits[k] = tab[l].y;
+        rl[k] = m0 + r < rows ? l : 0;
+        rb_[k] = bb;
+      }
+      int ex[NI_A], ey[NI_A];
+#pragma unroll
+      for (int k = 0; k < NI_A; ++k) { ex[k] = tab[rl[k]].x; ey[k] = tab[rl[k]].y; }
+#pragma unroll
+      for (int k = 0; k < NI_A; ++k) {
+        const int r = wl * (BM / 4) + k * 8 + (lane >> 3);
+        const int c_log = (lane & 7) ^ ((r >> 1) & 7);
+        const bool ok = m0 + r < rows;
+        roff[k] = ok ? (rb_[k] * ssample + ex[k] + c_log * 4) * 4 : 0;
+        rbits[k] = ok ? ey[k] : 0;
       }
     }
     int boff[NI_B];
@@ -99,6 +151,8 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       const int kk = (wl * NI_B + j) * B_RPI + lane / B_LPR;
       boff[j] = (kk * ldw + n0 + (lane % B_LPR) * 4) * 4;
     }
+    // gather offsets of the current group of TG taps (TG = 4 for the 4-tap plans of the shared-centre form: half the
+    // mask/select work in front of the first DMA)
     unsigned voffs[NI_A][TG];
     int tapw[TG];
     auto build_group = [&](int g) {
@@ -112,8 +166,8 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
           voffs[k][t] = ((rbits[k] & ti.mask) == ti.mask) ? (unsigned)(roff[k] + ti.delta) : RD_OOB;
       }
     };
-    int ld_g, ld_cc, ld_t, ld_gt;
-    {
+    int ld_g = 0, ld_cc = 0, ld_t = 0, ld_gt = min(TG, ntaps);
+    if (q0 != 0) {
       const int full = TG * CPT;
       ld_g = q0 / full;
       const int rem = q0 - ld_g * full;
@@ -136,15 +190,24 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
         rd_lds_dma16(rsB, Bs + j * 256, boff[j], sB);
     };
     auto load_chunk = [&](int stage) {
-      switch (ld_t) {
-        case 0: issue(stage, std::integral_constant<int, 0>{}); break;
-        case 1: issue(stage, std::integral_constant<int, 1>{}); break;
-        case 2: issue(stage, std::integral_constant<int, 2>{}); break;
-        case 3: issue(stage, std::integral_constant<int, 3>{}); break;
-        case 4: issue(stage, std::integral_constant<int, 4>{}); break;
-        case 5: issue(stage, std::integral_constant<int, 5>{}); break;
-        case 6: issue(stage, std::integral_constant<int, 6>{}); break;
-        default: issue(stage, std::integral_constant<int, 7>{}); break;
+      if constexpr (TG == 4) {
+        switch (ld_t) {
+          case 0: issue(stage, std::integral_constant<int, 0>{}); break;
+          case 1: issue(stage, std::integral_constant<int, 1>{}); break;
+          case 2: issue(stage, std::integral_constant<int, 2>{}); break;
+          default: issue(stage, std::integral_constant<int, 3>{}); break;
+        }
+      } else {
+        switch (ld_t) {
+          case 0: issue(stage, std::integral_constant<int, 0>{}); break;
+          case 1: issue(stage, std::integral_constant<int, 1>{}); break;
+          case 2: issue(stage, std::integral_constant<int, 2>{}); break;
+          case 3: issue(stage, std::integral_constant<int, 3>{}); break;
+          case 4: issue(stage, std::integral_constant<int, 4>{}); break;
+          case 5: issue(stage, std::integral_constant<int, 5>{}); break;
+          case 6: issue(stage, std::integral_constant<int, 6>{}); break;
+          default: issue(stage, std::integral_constant<int, 7>{}); break;
+        }
       }
       if (++ld_t == ld_gt) {
         ld_t = 0;
@@ -157,6 +220,9 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       }
     };
     if (nchunks > 0) load_chunk(0);
+#ifdef RD_STAMP
+    if (ws_st && wave == 4) atomicAdd(&rd_stamp_ws[4], rd_stamp() - ws_t0);
+#endif
     __syncthreads();                                     // (hipcc waits vmcnt(0) in front of the barrier: chunk 0 has landed)
     for (int q = 0; q < nchunks; ++q) {
       // stage (q+1)&1 was last read during chunk q-1, whose closing barrier every wave has passed
@@ -174,6 +240,10 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int a_sw = (l31 >> 1) & 7;
     __syncthreads();
+#ifdef RD_STAMP
+    if (ws_st && wave == 0) atomicAdd(&rd_stamp_ws[0], rd_stamp() - ws_t0);
+#endif
+    __builtin_amdgcn_s_setprio(0);
     for (int q = 0; q < nchunks; ++q) {
       const int buf = q & 1;
       const float* As = smem + buf * STAGE + (wm * WTM + l31) * BK;
@@ -205,14 +275,22 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       }
       __syncthreads();
     }
+    __builtin_amdgcn_s_setprio(3);
   }
 
-  // ---- epilogue (all 8 waves): tile through LDS, coalesced float4 rows (see k_conv_gemm)
-  const long dsample = plan->dst_sample;
+#ifdef RD_STAMP
+  const unsigned long long ws_t2 = rd_stamp();
+  if (ws_st && wave == 0) { atomicAdd(&rd_stamp_ws[1], ws_t2 - ws_t0); atomicAdd(&rd_stamp_ws[5], 1ull); }
+#endif
+  // ---- epilogue (all 8 waves): tile through LDS, coalesced float4 rows.
+  // Next to the other resident workgroup's MFMA stream every instruction here waits for an issue slot (stamps: ~50
+  // cycles each), so the row loop is kept short: 32-bit byte offsets inside buffer windows based at sample b0 (rows
+  // without a destination carry RD_OOB: their loads return 0 and their stores are dropped, no branch), v_rsq, DPP sums.
+  const int dsample = (int)plan->dst_sample;
   const int mode = epi.mode;
   float* Cs = smem;
-  int* Rb = (int*)(smem + BM * BN);
-  int* Tb = Rb + 2 * BM;                                 // row base inside epi.addt (shared-centre forward)
+  unsigned* Rb = (unsigned*)(smem + BM * BN);            // [BM] byte offset of the row in the destination window
+  unsigned* Tb = Rb + BM;                                // [BM] byte offset of the row in the epi.addt window
   if (is_compute) {
     const int wm = wave / WN, wn = wave % WN;
 #pragma unroll
@@ -225,68 +303,90 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       }
   } else if (tid - 256 < BM) {
     const int row = tid - 256;
-    long rb = -1, tb = 0;
+    unsigned rb = RD_OOB, tb = RD_OOB;
     if (m0 + row < rows) {
-      int l = l0 + row, bb = b0;
-      if (L >= BM) { if (l >= L) { l -= L; bb += 1; } }
-      else { int qd = l / L; l -= qd * L; bb += qd; }
+      int l = l0 + row, bb = 0;
+      if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
+      else { bb = l / L; l -= bb * L; }
       const int z = tab[l].z;
-      rb = (long)bb * dsample + z;
-      if (epi.addt) tb = (long)bb * (dsample >> 1) + z - (long)((z / epi.addt_plane + 1) >> 1) * epi.addt_plane;
+      rb = (unsigned)(bb * dsample + z) * 4u;
+      if (epi.addt) tb = (unsigned)(bb * (dsample >> 1) + z - ((z / epi.addt_plane + 1) >> 1) * epi.addt_plane) * 4u;
     }
-    Rb[2 * row] = (int)(rb & 0xFFFFFFFFll); Rb[2 * row + 1] = (int)(rb >> 32);
-    Tb[2 * row] = (int)(tb & 0xFFFFFFFFll); Tb[2 * row + 1] = (int)(tb >> 32);
+    Rb[row] = rb; Tb[row] = tb;
   }
   __syncthreads();
+#ifdef RD_STAMP
+  if (ws_st && wave == 0) atomicAdd(&rd_stamp_ws[2], rd_stamp() - ws_t0);
+#endif
   constexpr int F4R = BN / 4;
   constexpr int RPP = 512 / F4R;
   const int c4 = (tid % F4R) * 4;
-  const int col = n0 + c4;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (ksplit == 1 && (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP ||
-                      mode == RD_EPI_BIAS_PN_LRELU))
-    bias4 = *(const f32x4*)(epi.bias + col);
+  const unsigned colb = (unsigned)(n0 + c4) * 4u;
+  const long dbase = (long)b0 * dsample;
+  if (ksplit > 1) {
+    const __amdgpu_buffer_rsrc_t rsK = rd_make_rsrc(epi.kpart + (long)blockIdx.y * epi.kstride + dbase);
 #pragma unroll 4
-  for (int row = tid / F4R; row < BM; row += RPP) {
-    const long rb = ((long)Rb[2 * row + 1] << 32) | (unsigned)Rb[2 * row];
-    if (rb < 0) continue;
-    const long idx0 = rb + col;
-    f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
-    if (ksplit > 1) {
-      *(f32x4*)(epi.kpart + (long)blockIdx.y * epi.kstride + idx0) = v;
-      continue;
-    }
-    if (epi.addt) v += *(const f32x4*)(epi.addt + ((((long)Tb[2 * row + 1] << 32) | (unsigned)Tb[2 * row]) + col));
-    if (mode == RD_EPI_BIAS) {
-      v += bias4;
-    } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
-      v += bias4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float x = rd_lrelu(v[e]);
-        if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
-        v[e] = x;
-      }
-    } else if (mode == RD_EPI_BIAS_PN_LRELU) {
-      v += bias4;
-      float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-#pragma unroll
-      for (int o = F4R / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-      const float ri = 1.0f / sqrtf(ss * (1.0f / BN) + 1.0e-8f);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = rd_lrelu(v[e] * ri);
-      if (c4 == 0 && epi.rinv) epi.rinv[rb / BN] = ri;
-    } else if (mode == RD_EPI_GATE_AUX) {
-      const f32x4 a4 = *(const f32x4*)(epi.aux + idx0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float g = rd_lrelu_slope_from_out(a4[e]);
-        if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
-        v[e] *= g;
-      }
-    }
-    *(f32x4*)(dst + idx0) = v;
+    for (int row = tid / F4R; row < BM; row += RPP)
+      rd_buf_store4(rsK, Rb[row] + colb, *(const f32x4*)&Cs[row * BN + c4]);
+    return;
   }
+  const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc(dst + dbase);
+  const __amdgpu_buffer_rsrc_t rsT = rd_make_rsrc(epi.addt ? epi.addt + (long)b0 * (dsample >> 1) : dst);
+  const bool has_t = epi.addt != nullptr;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP || mode == RD_EPI_BIAS_PN_LRELU)
+    bias4 = *(const f32x4*)(epi.bias + n0 + c4);
+  if (mode == RD_EPI_BIAS_PN_LRELU) {
+    // PixelNormalization (T:255-266) + LeakyReLU (T:333): the F4R lanes holding a row are an aligned lane group
+    const __amdgpu_buffer_rsrc_t rsR = rd_make_rsrc(epi.rinv ? epi.rinv + dbase / BN : dst);
+    const unsigned rmask = (c4 == 0 && epi.rinv) ? 0u : RD_OOB;      // one lane per row stores 1/l2
+#pragma unroll 4
+    for (int row = tid / F4R; row < BM; row += RPP) {
+      const unsigned rb = Rb[row];
+      f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
+      if (has_t) v += rd_buf_load4(rsT, Tb[row] + colb);
+      v += bias4;
+      const float ss = rd_lanes_sum<F4R>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+      const float ri = __builtin_amdgcn_rsqf(ss * (1.0f / BN) + 1.0e-8f);      // v_rsq_f32: 1 ulp
+      v *= ri;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], RD_LRELU_ALPHA * v[e]);     // LeakyReLU for alpha < 1
+      rd_buf_store1(rsR, (rb / BN) | (rb & RD_OOB) | rmask, ri);
+      rd_buf_store4(rsD, rb + colb, v);
+    }
+  } else {
+    const __amdgpu_buffer_rsrc_t rsX = rd_make_rsrc(mode == RD_EPI_GATE_AUX ? epi.aux + dbase : dst);
+    const uint32_t ibase = (uint32_t)dbase + epi.idx_base + (uint32_t)(n0 + c4);
+#pragma unroll 4
+    for (int row = tid / F4R; row < BM; row += RPP) {
+      const unsigned rb = Rb[row];
+      f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
+      if (has_t) v += rd_buf_load4(rsT, Tb[row] + colb);
+      if (mode == RD_EPI_BIAS) {
+        v += bias4;
+      } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
+        v += bias4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = rd_lrelu(v[e]);
+          if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+          v[e] = x;
+        }
+      } else if (mode == RD_EPI_GATE_AUX) {
+        const f32x4 a4 = rd_buf_load4(rsX, rb + colb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float g = rd_lrelu_slope_from_out(a4[e]);
+          if (epi.use_drop) g *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+          v[e] *= g;
+        }
+      }
+      rd_buf_store4(rsD, rb + colb, v);
+    }
+  }
+#ifdef RD_STAMP
+  if (ws_st && wave == 0) atomicAdd(&rd_stamp_ws[3], rd_stamp() - ws_t0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------
