@@ -175,7 +175,8 @@ def main():
             gf = args.n_critic * DIRECT_GF_PER_SAMPLE["critic_step"] + DIRECT_GF_PER_SAMPLE["gen_step"]
             direct_equiv = gf * 1e9 * B * args.steps / dt / 1e12          # per GPU
         out = {
-            "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256" if ND == 16 else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles (extra data point)",
+            "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256" if (ND, B) == (16, 256)
+                      else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles, bs={B} (extra data point)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
