@@ -35,6 +35,12 @@ def gconv3_flops(batch, nd=NDOMAIN, taps=4):
     return 2.0 * batch * 24 * nd * nd * taps * 128 * 64
 
 
+# HBM traffic of ONE launch of the dominant kernel at the default configuration, from separate rocprofv3 --pmc passes
+# (scripts/gpu_pmc_traffic.sh -> profiles/r01_e_pmc_hbm_traffic_gen_forward.json): FETCH_SIZE 241.6 MB x 2 (gfx950 counts
+# half the bytes of wide streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE 399.4 MB.  Algorithmic: E 109 MB + T 2 x 201 MB
+# read, 403 MB output + 6 MB 1/l2 written.  Not measurable inside this process, hence a recorded constant.
+DOMINANT_TRAFFIC_BYTES = 2 * 241.6e6 + 399.4e6
+
 # FLOPs of one iteration (n_critic critic steps + 1 generator step) per sample in the reference's direct
 # 27-tap form, nd = 16; used to price the measured iteration time as "direct-equivalent" TFLOP/s
 DIRECT_GF_PER_SAMPLE = {"critic_step": 5.41, "gen_step": 13.54}
@@ -188,7 +194,9 @@ def main():
                                                     "phases x 4 taps + shared part T + bias + PixelNorm + LeakyReLU in the epilogue)",
                          "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
+                         "traffic": DOMINANT_TRAFFIC_BYTES if (ND, B, taps) == (16, 256, 4) else None,
+                         "traffic_source": "profiles/r01_e_pmc_hbm_traffic_gen_forward.json (separate --pmc passes, bytes per launch)",
+                         "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": gconv3_flops(B, ND, taps),
                          "iteration_direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2)},
             "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},
