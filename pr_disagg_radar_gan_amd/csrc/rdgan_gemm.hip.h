@@ -121,7 +121,9 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 
   // ---- which phase / tile (all wave-uniform); 1-D grid, N tile fastest so both N tiles of an M tile run together
   const int NTn = plan->N / BN;
-  const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
+  // phases of unequal length (stride-2 input gradients: 8, 4, 4, 2, 4, 2, 2, 1 taps) are laid out one after the other:
+  // a contiguous range per XCD would hand one XCD all the 8-tap tiles, so those plans keep the round-robin dealing
+  const int swz = (plan->nphases > 1 && !plan->interleave) ? (int)blockIdx.x : rd_xcd_swizzle(blockIdx.x, gridDim.x);
   const int ntile = swz % NTn;
   int mt = swz / NTn, pidx = 0;
   if (plan->interleave) {

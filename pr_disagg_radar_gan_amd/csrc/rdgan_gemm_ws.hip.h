@@ -74,7 +74,9 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
   constexpr int BN_LOG2 = BN == 128 ? 7 : 6;
   static_assert(BN == 128 || BN == 64, "BN");
   const int ntn_log2 = __builtin_ctz(plan->N >> BN_LOG2);
-  const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
+  // phases of unequal length (stride-2 input gradients: 8, 4, 4, 2, 4, 2, 2, 1 taps) are laid out one after the other:
+  // a contiguous range per XCD would hand one XCD all the 8-tap tiles, so those plans keep the round-robin dealing
+  const int swz = (plan->nphases > 1 && !plan->interleave) ? (int)blockIdx.x : rd_xcd_swizzle(blockIdx.x, gridDim.x);
   const int ntile = swz & ((1 << ntn_log2) - 1);
   int mt = swz >> ntn_log2, pidx = 0;
   const int nph = plan->nphases;
