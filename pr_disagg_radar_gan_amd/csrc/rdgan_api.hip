@@ -277,7 +277,7 @@ static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
   const int Dd[3] = {p.DD, p.DH, p.DW};
   p.interleave = p.nphases > 1;
   for (int pi = 1; pi < p.nphases; ++pi)
-    if (p.ph[pi].L != p.ph[0].L) p.interleave = 0;
+    if (p.ph[pi].L != p.ph[0].L || p.ph[pi].ntaps != p.ph[0].ntaps) p.interleave = 0;   // (unequal tap counts: longest phases first)
   p.src_sample = (long)p.SD * p.SH * p.SW * p.s_cstride;
   p.dst_sample = (long)p.DD * p.DH * p.DW * p.d_cstride;
   int first = 0;
@@ -546,7 +546,13 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
     if (hp.N % 128 == 0) return launch_conv_ws_cfg<128, 128, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
     if (hp.N == 64) return launch_conv_ws_cfg<256, 64, 4, 1>(h, hp, dp, B, src, W, ldw, dst, epi, st);
   }
-  if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200) {
+  // phases of unequal length (stride-2 input gradients: 8 ... 1 taps): the 8-tap workgroups set the launch time, so a
+  // mid-size launch takes the narrower tile (twice the workgroups, half the work each)
+  int tmin = hp.ph[0].ntaps, tmax = tmin;
+  for (int i = 1; i < hp.nphases; ++i) { tmin = std::min(tmin, hp.ph[i].ntaps); tmax = std::max(tmax, hp.ph[i].ntaps); }
+  const bool uneven = tmax >= 2 * tmin;
+  if (hp.N % 128 == 0 && plan_tiles(hp, B, 128) * (hp.N / 128) >= 200 &&
+      !(uneven && ws_ok && plan_tiles(hp, B, 128) * (hp.N / 128) < 1024)) {
     if (ws_ok) return launch_conv_ws_cfg<128, 128, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
     RD_CONV(128, 128, 2, 2);
   }
