@@ -596,6 +596,9 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   const RdPhase& q = p.ph[0];
   BR = p.SC >= 128 ? 128 : 64;
   BN = (p.N % 128 == 0) ? 128 : 64;
+  // 64 input channels against >= 128 output channels (critic layer 2): two taps per 128-row tile, so every wave owns a
+  // 64x64 tile (4 fragment reads per 4 MFMAs instead of 3 per 2)
+  if (p.SC == 64 && BN == 128 && q.ntaps >= 2 && p.nphases == 1 && !p.s_shift) BR = 128;
   if (BN == 64 && p.SC == 128 && q.ntaps % 2 == 0 && (long)B * q.L >= 65536) BR = 256;   // two taps per tile, 4 accumulators per wave
   if (p.SC >= BR) {
     T.tiles_per_tap = (p.SC + BR - 1) / BR; T.cw = BR; T.taps_per_tile = 1; T.RT = q.ntaps * T.tiles_per_tap;
@@ -674,7 +677,7 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   } while (0)
   float* partial_buf = partial_ws;
   const long wrows = (long)B * hp.ph[0].L;
-  const bool ws = h && h->wave_spec && !partial && !shift && (h->wave_spec == 2 || wrows * hp.nphases >= 16384);
+  const bool ws = h && h->wave_spec && !partial && !shift && (h->wave_spec == 2 || wrows * hp.nphases >= 1024);
   if (ws && BR == 256) RD_TRY((launch_wgrad_ws_cfg<256, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
   else if (ws && BR == 128 && BN == 128) RD_TRY((launch_wgrad_ws_cfg<128, 128>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
   else if (ws && BR == 128) RD_TRY((launch_wgrad_ws_cfg<128, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
