@@ -448,6 +448,7 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
     long minL = hp.ph[0].L;
     for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
     if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
+    if ((BM / minL + 2) * hp.dst_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: destination tile span exceeds 2 GiB");
   }
   const long blocks = tm * (hp.N / BN);
   // split-K for small-M / large-K layers (critic tail, Dense, first generator block): few workgroups, long K loops

@@ -47,6 +47,23 @@ __device__ __forceinline__ f32x4 rd_buf_load4_if(__amdgpu_buffer_rsrc_t rsrc, bo
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rd_make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, RD_RSRC_BYTES, 0x00020000);
 }
+__device__ __forceinline__ void rd_buf_store4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void rd_buf_store1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, 0);
+}
+// sum over an aligned group of N lanes (N = 16: one DPP row, four rotate-adds; N = 32: plus one cross-row exchange)
+template <int N>
+__device__ __forceinline__ float rd_lanes_sum(float v) {
+  static_assert(N == 16 || N == 32, "row group");
+#define RD_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+  RD_DPP_ADD(0x128); RD_DPP_ADD(0x124); RD_DPP_ADD(0x122); RD_DPP_ADD(0x121);   // row_ror:8, 4, 2, 1
+#undef RD_DPP_ADD
+  if (N == 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
 // s_shift == 1 (direct form of the folded upsample): per-row element delta of a tap from the 2-bit codes
 __device__ __forceinline__ int rd_shift_delta(int w, int sd, int sh_, int sw, int SH, int SW, int cstride) {
   int dd = ((w >> sd) & 3) - 1, dh = ((w >> sh_) & 3) - 1, dw = ((w >> sw) & 3) - 1;
@@ -427,8 +444,11 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
     }
   }
   if constexpr (LDS_EPI) {
+    // same lean row loop as k_conv_gemm_ws: 32-bit byte offsets inside buffer windows based at sample b0, rows without a
+    // destination carry RD_OOB (loads return 0, stores are dropped), v_rsq and DPP row sums for PixelNorm
     float* Cs = smem;                                   // [BM][BN]
-    int* Rb = (int*)(smem + BM * BN);                   // [BM][2]: destination row base (floats, 64-bit) or -1
+    unsigned* Rb = (unsigned*)(smem + BM * BN);         // [BM] byte offset of the row in the destination window
+    unsigned* Tb = Rb + BM;                             // [BM] byte offset of the row in the epi.addt window
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -437,72 +457,90 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 #pragma unroll
         for (int j = 0; j < TN; ++j) Cs[row * BN + wn * WTN + j * 32 + l31] = acc[i][j][r];
       }
-    int* Tb = Rb + 2 * BM;                              // [BM][2]: row base inside epi.addt (shared-centre forward)
+    const int dsmp = (int)dsample;
     if (tid < BM) {
-      long rb = -1, tb = 0;
+      unsigned rb = RD_OOB, tb = RD_OOB;
       if (m0 + tid < rows) {
-        int l = l0 + tid, bb = b0;
-        if (L >= BM) { if (l >= L) { l -= L; bb += 1; } }
-        else { int qd = l / L; l -= qd * L; bb += qd; }
+        int l = l0 + tid, bb = 0;
+        if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
+        else { bb = l / L; l -= bb * L; }
         const int z = tab[l].z;
-        rb = (long)bb * dsample + z;
-        if (epi.addt) tb = (long)bb * (dsample >> 1) + z - (long)((z / epi.addt_plane + 1) >> 1) * epi.addt_plane;
+        rb = (unsigned)(bb * dsmp + z) * 4u;
+        if (epi.addt) tb = (unsigned)(bb * (dsmp >> 1) + z - ((z / epi.addt_plane + 1) >> 1) * epi.addt_plane) * 4u;
       }
-      Rb[2 * tid] = (int)(rb & 0xFFFFFFFFll); Rb[2 * tid + 1] = (int)(rb >> 32);
-      Tb[2 * tid] = (int)(tb & 0xFFFFFFFFll); Tb[2 * tid + 1] = (int)(tb >> 32);
+      Rb[tid] = rb; Tb[tid] = tb;
     }
     __syncthreads();
     constexpr int F4R = BN / 4;                         // float4s per row; 256 % F4R == 0, so a thread's columns are fixed
     constexpr int RPP = 256 / F4R;                      // rows per pass
     const int c4 = (tid % F4R) * 4;
-    const int col = n0 + c4;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (ksplit == 1 && (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP ||
-                        mode == RD_EPI_BIAS_PN_LRELU))
-      bias4 = *(const f32x4*)(epi.bias + col);
+    const unsigned colb = (unsigned)(n0 + c4) * 4u;
+    const long dbase = (long)b0 * dsample;
+    if (ksplit > 1) {
+      const __amdgpu_buffer_rsrc_t rsK = rd_make_rsrc(epi.kpart + (long)blockIdx.y * epi.kstride + dbase);
 #pragma unroll 4
-    for (int row = tid / F4R; row < BM; row += RPP) {
-      const long rb = ((long)Rb[2 * row + 1] << 32) | (unsigned)Rb[2 * row];
-      if (rb < 0) continue;
-      const long idx0 = rb + col;
-      f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
-      if (ksplit > 1) {
-        *(f32x4*)(epi.kpart + (long)blockIdx.y * epi.kstride + idx0) = v;
-        continue;
-      }
-      if (epi.addt) v += *(const f32x4*)(epi.addt + ((((long)Tb[2 * row + 1] << 32) | (unsigned)Tb[2 * row]) + col));
-      if (mode == RD_EPI_BIAS) {
-        v += bias4;
-      } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
-        v += bias4;
+      for (int row = tid / F4R; row < BM; row += RPP)
+        rd_buf_store4(rsK, Rb[row] + colb, *(const f32x4*)&Cs[row * BN + c4]);
+      return;
+    }
+    const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc(dst + dbase);
+    const __amdgpu_buffer_rsrc_t rsT = rd_make_rsrc(epi.addt ? epi.addt + (long)b0 * (dsmp >> 1) : dst);
+    const bool has_t = epi.addt != nullptr;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP || mode == RD_EPI_BIAS_PN_LRELU)
+      bias4 = *(const f32x4*)(epi.bias + n0 + c4);
+    bool pn_done = false;
+    if constexpr (F4R >= 16) {
+      if (mode == RD_EPI_BIAS_PN_LRELU) {
+        // PixelNormalization (T:255-266) + LeakyReLU (T:333): the F4R lanes holding a row are an aligned lane group
+        pn_done = true;
+        const __amdgpu_buffer_rsrc_t rsR = rd_make_rsrc(epi.rinv ? epi.rinv + dbase / BN : dst);
+        const unsigned rmask = (c4 == 0 && epi.rinv) ? 0u : RD_OOB;      // one lane per row stores 1/l2
+#pragma unroll 4
+        for (int row = tid / F4R; row < BM; row += RPP) {
+          const unsigned rb = Rb[row];
+          f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
+          if (has_t) v += rd_buf_load4(rsT, Tb[row] + colb);
+          v += bias4;
+          const float ss = rd_lanes_sum<F4R>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+          const float ri = __builtin_amdgcn_rsqf(ss * (1.0f / BN) + 1.0e-8f);      // v_rsq_f32: 1 ulp
+          v *= ri;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = rd_lrelu(v[e]);
-          if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
-          v[e] = x;
-        }
-      } else if (mode == RD_EPI_BIAS_PN_LRELU) {
-        // PixelNormalization (T:255-266) + LeakyReLU (T:333): the F4R lanes holding this row are an aligned lane group
-        v += bias4;
-        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-#pragma unroll
-        for (int o = F4R / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        // one reciprocal per row and four multiplies (an IEEE division is ~10 instructions, and every non-MFMA
-        // instruction here waits for a slot between the partner wave's MFMAs); <= 1 ulp from x / l2
-        const float ri = 1.0f / sqrtf(ss * (1.0f / BN) + 1.0e-8f);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rd_lrelu(v[e] * ri);
-        if (c4 == 0 && epi.rinv) epi.rinv[rb / BN] = ri;
-      } else if (mode == RD_EPI_GATE_AUX) {
-        const f32x4 a4 = *(const f32x4*)(epi.aux + idx0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float g = rd_lrelu_slope_from_out(a4[e]);
-          if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)(idx0 + e) + epi.idx_base);
-          v[e] *= g;
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], RD_LRELU_ALPHA * v[e]);     // LeakyReLU for alpha < 1
+          rd_buf_store1(rsR, (rb / BN) | (rb & RD_OOB) | rmask, ri);
+          rd_buf_store4(rsD, rb + colb, v);
         }
       }
-      *(f32x4*)(dst + idx0) = v;
+    }
+    if (!pn_done) {
+      const __amdgpu_buffer_rsrc_t rsX = rd_make_rsrc(mode == RD_EPI_GATE_AUX ? epi.aux + dbase : dst);
+      const uint32_t ibase = (uint32_t)dbase + epi.idx_base + (uint32_t)(n0 + c4);
+#pragma unroll 4
+      for (int row = tid / F4R; row < BM; row += RPP) {
+        const unsigned rb = Rb[row];
+        f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
+        if (has_t) v += rd_buf_load4(rsT, Tb[row] + colb);
+        if (mode == RD_EPI_BIAS) {
+          v += bias4;
+        } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
+          v += bias4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = rd_lrelu(v[e]);
+            if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+            v[e] = x;
+          }
+        } else if (mode == RD_EPI_GATE_AUX) {
+          const f32x4 a4 = rd_buf_load4(rsX, rb + colb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float g = rd_lrelu_slope_from_out(a4[e]);
+            if (epi.use_drop) g *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+            v[e] *= g;
+          }
+        }
+        rd_buf_store4(rsD, rb + colb, v);
+      }
     }
   } else {
 #pragma unroll

@@ -22,23 +22,6 @@ __device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float*
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-__device__ __forceinline__ void rd_buf_store4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)voff, 0, 0);
-}
-__device__ __forceinline__ void rd_buf_store1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, 0);
-}
-// sum over an aligned group of N lanes (N = 16: one DPP row, four rotate-adds; N = 32: plus one cross-row exchange)
-template <int N>
-__device__ __forceinline__ float rd_lanes_sum(float v) {
-  static_assert(N == 16 || N == 32, "row group");
-#define RD_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
-  RD_DPP_ADD(0x128); RD_DPP_ADD(0x124); RD_DPP_ADD(0x122); RD_DPP_ADD(0x121);   // row_ror:8, 4, 2, 1
-#undef RD_DPP_ADD
-  if (N == 32) v += __shfl_xor(v, 16, 64);
-  return v;
-}
-
 template <int BM, int BN, int WM, int WN, int TG>
 __global__ void __launch_bounds__(512, 4)
 k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
