@@ -266,3 +266,38 @@ def test_last_conv_paths_other_domains(nd, tapgather):
         assert rel_err(out, ref) < 2e-5
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("B", [9, 33])
+def test_odd_batches_default_options(B):
+    """Batches that leave partial tiles everywhere (rows % 128 != 0, tiles spanning several samples), default options:
+    generator forward against the oracle, and the critic / generator step gradients at B = 9."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 41)
+        x, cond, z = ot.synthetic_batch(B, 16, 17)
+        ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        out = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+        np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-7)
+        if B > 9:
+            return
+
+        def run_critic(data_seed):
+            x, cond, z = ot.synthetic_batch(B, 16, data_seed)
+            losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
+                                                 torch.from_numpy(cond).double(), torch.from_numpy(z).double(), 11)
+            slab = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 11).cpu().numpy()
+            np.testing.assert_allclose(slab[eng.n_critic:eng.n_critic + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+            return _grad_errors(slab[:eng.n_critic], grads, eng.critic_shapes)
+
+        def run_gen(data_seed):
+            x, cond, z = ot.synthetic_batch(B, 16, data_seed)
+            loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 12)
+            slab = eng.gen_grad(ds, gs, dev(z), dev(cond), 12).cpu().numpy()
+            return _grad_errors(slab[:eng.n_gen], grads, eng.gen_shapes)
+
+        _parity_over_batches(run_critic)
+        _parity_over_batches(run_gen)
+    finally:
+        eng.close()
