@@ -25,6 +25,7 @@ NDOMAIN = 16
 BATCH_PER_GPU = 256
 N_CRITIC = 1
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+BF16_MFMA_PEAK_TFLOPS = 2516.6     # dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles): 16x the fp32 rate; only with --opt mfma_bf16=1
 
 
 def gconv3_flops(batch, nd=NDOMAIN, taps=4):
@@ -175,6 +176,8 @@ def main():
         avg_ms = kern_ms / max(kern_n, 1)
         opts = dict(kv.split("=") for kv in args.opt)     # A/B runs: the tagged launch is the whole block in the other forms
         taps = 27 if opts.get("collapse") == "0" else (8 if opts.get("fast_fwd") == "0" else 4)
+        bf16 = opts.get("mfma_bf16") == "1" and taps == 4     # mixed mode: bf16 operands in the shared-centre GEMMs of blocks 2, 3
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         achieved = gconv3_flops(B, ND, taps) / (avg_ms * 1e-3) / 1e12 if kern_n else None
         direct_equiv = None
         if ND == 16:
@@ -185,16 +188,17 @@ def main():
                       else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles, bs={B} (extra data point)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16 operands (generator blocks 2, 3 forward / input gradient) + f32" if bf16 else "f32",
+            "data": "synthetic",
             "config": {"workload": f"ndomain={ND}, 24h, bs={B} fp32 per GPU, {args.n_critic} critic step + 1 gen step"
                                    + (" (BASELINE configs[1])" if (ND, B, args.n_critic) == (16, 256, 1) else ""),
                        "global_batch": world * B, "n_critic": args.n_critic, "parallelism": f"dp{world}",
                        "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
             "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_ws<256,64,4,1>, generator block 3 forward, difference part (E x U over 8 parity "
                                                     "phases x 4 taps + shared part T + bias + PixelNorm + LeakyReLU in the epilogue)",
-                         "achieved": None if achieved is None else round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": DOMINANT_TRAFFIC_BYTES if (ND, B, taps) == (16, 256, 4) else None,
+                         "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
+                         "traffic": DOMINANT_TRAFFIC_BYTES if (ND, B, taps, bf16) == (16, 256, 4, False) else None,
                          "traffic_source": "profiles/r01_e_pmc_hbm_traffic_gen_forward.json (separate --pmc passes, bytes per launch)",
                          "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": gconv3_flops(B, ND, taps),

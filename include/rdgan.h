@@ -94,6 +94,11 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * instead of 64 tap products per position, algebraically identical.  Forward: T = S x once per output plane pair,
  * then the difference part adds T in its epilogue; backward: plane-pair sums of the output gradient feed the S part,
  * the gradient wrt E is folded back by the adjoint of the differencing.  0 = the 64-tap collapsed form.
+ * "mfma_bf16" (default 0; needs the shared-centre form): the forward and input-gradient GEMMs of generator blocks 2
+ * and 3 read bf16 copies of their operands (block input, hour differences, plane sums, output gradient, weight forms
+ * stored [N][K]) and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; every tensor the caller or another kernel
+ * sees stays fp32, weight gradients stay fp32.  Mixed-precision mode for BASELINE configs 3-5; results move by bf16
+ * rounding (2^-9 per operand), so it is NOT the mode the fp32 metric is measured in.
  * "tapgather" (default 1): the last generator conv (64 -> 1, T:345) runs as a column GEMM over its 27 taps whose
  * epilogue already sums the taps that fall inside the 256-row tile (ndomain 8/16: whole planes, 32/64/128: whole
  * rows), writing 3 or 9 floats per grid point instead of 32; 0 (and every other ndomain) = full column matrix +
@@ -140,11 +145,20 @@ int rdgan_crps_ensemble(const float* ens, const float* obs, const float* scale, 
 int rdgan_op_conv3d(const float* x, const float* w, const float* bias, float* y, int B, int D, int H,
                     int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d,
                     int pad_h, int pad_w, int upsample, void* stream);
+/* the same contraction with bf16 operands (x and w rounded to nearest-even bf16 on the device, fp32 accumulation and
+ * output; v_mfma_f32_32x32x16_bf16): the GEMM of the "mfma_bf16" option.  No folded upsample; Cin, Cout % 64 == 0. */
+int rdgan_op_conv3d_bf16(const float* x, const float* w, const float* bias, float* y, int B, int D, int H,
+                         int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d,
+                         int pad_h, int pad_w, void* stream);
 /* input gradient of the above for stride 2 (parity-phase plan) or stride 1: gy -> gx (same dims as x,
  * on the upsampled grid when the forward had upsample=1: D,H,W are the conv's input extents). */
 int rdgan_op_conv3d_dgrad(const float* gy, const float* w, float* gx, int B, int D, int H, int W,
                           int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h,
                           int pad_w, void* stream);
+/* the same input gradient with bf16 operands (gy, w rounded to bf16; fp32 accumulation): Cin, Cout % 64 == 0. */
+int rdgan_op_conv3d_dgrad_bf16(const float* gy, const float* w, float* gx, int B, int D, int H, int W,
+                               int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h,
+                               int pad_w, void* stream);
 /* weight gradient dW [3,3,3,Cin,Cout] of the forward above. */
 int rdgan_op_conv3d_wgrad(const float* x, const float* gy, float* dw, int B, int D, int H, int W,
                           int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h,

@@ -367,6 +367,10 @@ struct rdgan_handle {
   // shared-centre form: per block the hour differences E of its input and the 48 weight forms U (written by the forward,
   // reused by the backward); T / plane sums gS, the gradient wrt E, weight-form gradients and transposes (scratch)
   float *fE[4], *fU[4], *fgS, *fdE, *fdU, *fUT;
+  // "mfma_bf16": bf16 copies of the operands of the shared-centre GEMMs (block input x, differences E, plane sums gS,
+  // output gradient dy, weight forms in [N][K] layout)
+  void *bX[4], *bE[4], *bU[4], *bUT, *bgS, *bdy;
+  int mfma_bf16 = 0;              // 1: shared-centre forward / input-gradient GEMMs of blocks 2, 3 on bf16 operands (fp32 accumulate, fp32 tensors everywhere else)
   int fast_fwd = 1;               // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products)
   int fast_bwd = 1;               // 1: generator blocks' weight/input gradients in the shared-centre form along d (48 instead of 64 tap products)
   float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
@@ -471,26 +475,29 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int TG>
+template <int BM, int BN, int WM, int WN, int TG, bool BF>
 static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                              const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st);
-// TG = taps whose gather offsets a loader wave keeps in registers: 4 when no phase has more (shared-centre plans)
-template <int BM, int BN, int WM, int WN>
+// TG = taps whose gather offsets a loader wave keeps in registers: 4 when no phase has more (shared-centre plans).
+// BF = bf16 operands (src / W point at bf16 data, W stored [tap block][N][K]); see k_conv_gemm_ws.
+template <int BM, int BN, int WM, int WN, bool BF = false>
 static int launch_conv_ws_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                               const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
   int maxtaps = 0;
   for (int i = 0; i < hp.nphases; ++i) maxtaps = std::max(maxtaps, hp.ph[i].ntaps);
-  if (maxtaps <= 4) return launch_conv_ws_tg<BM, BN, WM, WN, 4>(h, hp, dp, B, src, W, ldw, dst, epi, st);
-  return launch_conv_ws_tg<BM, BN, WM, WN, 8>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  if (maxtaps <= 4) return launch_conv_ws_tg<BM, BN, WM, WN, 4, BF>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  return launch_conv_ws_tg<BM, BN, WM, WN, 8, BF>(h, hp, dp, B, src, W, ldw, dst, epi, st);
 }
-template <int BM, int BN, int WM, int WN, int TG>
+template <int BM, int BN, int WM, int WN, int TG, bool BF>
 static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                              const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
   constexpr size_t lds_loop = 2 * (size_t)(BM * 32 + 32 * BN) * sizeof(float);
   constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float) + (size_t)BM * 16;
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   static bool attr_done = false;
-  auto kern = k_conv_gemm_ws<BM, BN, WM, WN, TG>;
+  auto kern = k_conv_gemm_ws<BM, BN, WM, WN, TG, BF>;
+  constexpr int KCH = BF ? 64 : 32;                    // K elements per chunk
+  if (BF && hp.SC % 64) return bad_arg(h, "conv: bf16 operands need a multiple of 64 channels per tap");
   if (!attr_done) {
     RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -509,8 +516,8 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
   // the (small) output, priced at 3 % per split.
   const long total = (long)B * hp.dst_sample;
   if (h && h->ws_ksplit && blocks < 1024 && hp.d_cstride == hp.N && epi.mode != RD_EPI_BIAS_PN_LRELU && !epi.addt) {
-    long nch = (long)hp.ph[0].ntaps * (hp.SC / 32);
-    for (int i = 1; i < hp.nphases; ++i) nch = std::min<long>(nch, (long)hp.ph[i].ntaps * (hp.SC / 32));
+    long nch = (long)hp.ph[0].ntaps * (hp.SC / KCH);
+    for (int i = 1; i < hp.nphases; ++i) nch = std::min<long>(nch, (long)hp.ph[i].ntaps * (hp.SC / KCH));
     auto cost = [&](long ks) { double r = (double)(blocks * ks) / 256.0; return std::ceil(r) / r * (1.0 + 0.03 * (ks - 1)); };
     long best = 1;
     for (long ks = 2; ks <= 8; ++ks)
@@ -580,6 +587,30 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
     return launch_conv_cfg<128, 32, 4, 1, 32, false, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
 #undef RD_CONV
   return bad_arg(h, "conv: unsupported N");
+}
+
+static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>((n + per - 1) / per, 8192); }
+
+// bf16-operand conv GEMM (fp32 accumulate / output): src16 = bf16 NDHWC activations, w16 = bf16 weights [tap block][N][K]
+static int launch_conv16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* w16,
+                         float* dst, const RdEpi& epi, hipStream_t st, int tag) {
+  ProfScope ps(h, tag, st);
+  if (hp.s_shift || hp.SC % 64 || hp.N % 64) return bad_arg(h, "conv16: needs SC % 64 == 0, N % 64 == 0, no folded upsample");
+  const float* s = (const float*)src16; const float* w = (const float*)w16;
+  if (hp.N % 128 == 0) return launch_conv_ws_cfg<128, 128, 2, 2, true>(h, hp, dp, B, s, w, 0, dst, epi, st);
+  if (hp.N == 64 && plan_tiles(hp, B, 256) >= 512) return launch_conv_ws_cfg<256, 64, 4, 1, true>(h, hp, dp, B, s, w, 0, dst, epi, st);
+  return launch_conv_ws_cfg<128, 64, 2, 2, true>(h, hp, dp, B, s, w, 0, dst, epi, st);
+}
+// fp32 -> bf16 copies (round to nearest even) of an activation tensor and of a weight-form stack [T][K][N] -> [T][N][K]
+static int launch_to_bf16(rdgan_handle* h, const float* in, void* out, long n, hipStream_t st) {
+  hipLaunchKernelGGL(k_to_bf16, dim3(ew_blocks(n / 8)), dim3(256), 0, st, in, (unsigned short*)out, n);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+static int launch_weights_to_bf16_t(rdgan_handle* h, const float* in, void* out, int T, int K, int N, hipStream_t st) {
+  hipLaunchKernelGGL(k_weights_to_bf16_t, dim3((N + 31) / 32, (K + 31) / 32, T), dim3(256), 0, st, in, (unsigned short*)out, K, N);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
 }
 
 // true when launch_conv will pick a tile whose BN equals the plan's N, i.e. a workgroup owns whole output rows
@@ -705,8 +736,6 @@ static size_t wgrad_partial_need(const RdPlan& hp, int B) {
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
   return (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
 }
-
-static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>((n + per - 1) / per, 8192); }
 
 // out[c] = sum over rows of src[rows][C]
 static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, float* out, hipStream_t st) {
@@ -938,6 +967,20 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(h->fU[l], 48L * gch[l - 1] * gch[l]);
       }
       carve(h->fdE, MB * ne); carve(h->fgS, MB * ns);
+      {   // bf16 operand copies (2 bytes per element: half the floats)
+        float* p = nullptr;
+        h->bX[0] = h->bE[0] = h->bU[0] = nullptr;
+        for (int l = 1; l <= 3; ++l) {
+          const int* sd = h->gdim[l - 1];
+          const size_t nx = MB * (size_t)(sd[0] + 1) * sd[1] * sd[2] * gch[l - 1];
+          carve(p, nx / 2 + 8); h->bX[l] = p;
+          carve(p, nx / 2 + 8); h->bE[l] = p;
+          carve(p, 24L * gch[l - 1] * gch[l] + 8); h->bU[l] = p;
+        }
+        carve(p, 24L * 256 * 256 + 8); h->bUT = p;
+        carve(p, MB * ns / 2 + 8); h->bgS = p;
+        carve(p, MB * ns + 8); h->bdy = p;
+      }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
     }
     { float* f = nullptr; carve(f, 64); if (pass == 1) h->d_flag = (int*)f; }
@@ -983,6 +1026,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!h || !name) return -2;
   if (!strcmp(name, "collapse")) { h->collapse = value ? 1 : 0; return 0; }
   if (!strcmp(name, "wave_specialized")) { h->wave_spec = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }   // 2 = also for small problems (tests)
+  if (!strcmp(name, "mfma_bf16")) { h->mfma_bf16 = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fast_fwd")) { h->fast_fwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
@@ -1067,12 +1111,25 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
         hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, Wl, h->fU[l], (int)cc, 48, wm);
       }
       const int pls = PL_F1WS + l - 1, ple = PL_F1FE + l - 1;
+      const bool bf = h->mfma_bf16 && h->gch[l - 1] % 64 == 0;
+      if (bf) {
+        ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+        RD_TRY(launch_to_bf16(h, hs[l - 1], h->bX[l], (long)B * sd[0] * P, st));
+        RD_TRY(launch_to_bf16(h, h->fE[l], h->bE[l], (long)B * (sd[0] + 1) * P, st));
+        RD_TRY(launch_weights_to_bf16_t(h, h->fU[l], h->bU[l], 48, h->gch[l - 1], h->gch[l], st));
+      }
+      if (bf) RD_TRY(launch_conv16(h, h->plans[pls], h->d_plans + pls, B, h->bX[l], h->bU[l], h->fgS, epi_make(RD_EPI_PLAIN), st,
+                                   RDGAN_TAG_GCONV_FWD));
+      else
       RD_TRY(launch_conv(h, h->plans[pls], h->d_plans + pls, B, hs[l - 1], h->fU[l], h->gch[l], h->fgS, epi_make(RD_EPI_PLAIN), st,
                          RDGAN_TAG_GCONV_FWD));
       const bool fuse = conv_rows_owned(h->plans[ple], B);
       RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
       ep.rinv = rs[l];
       ep.addt = h->fgS; ep.addt_plane = 4 * sd[1] * sd[2] * h->gch[l];
+      if (bf) RD_TRY(launch_conv16(h, h->plans[ple], h->d_plans + ple, B, h->bE[l], h->bU[l], hs[l], ep, st,
+                                   l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
+      else
       RD_TRY(launch_conv(h, h->plans[ple], h->d_plans + ple, B, h->fE[l], h->fU[l], h->gch[l], hs[l], ep, st,
                          l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
       if (!fuse) {
@@ -1371,10 +1428,29 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
                            h->fUT, h->gch[l - 1], h->gch[l], map);
       }
       const int pbs = PL_F1BS + l - 1, pbe = PL_F1BE + l - 1;
+      if (h->mfma_bf16 && h->gch[l] % 64 == 0) {
+        // bf16 operands: plane sums, output gradient, and the forward forms U re-ordered by tap ([Cin][Cout] is already the
+        // [N][K] layout of these GEMMs)
+        RdSliceMap map;
+        fastd_dgrad_slice_map(map.src);
+        const long HWo = (long)h->gdim[l][1] * h->gdim[l][2] * h->gch[l];
+        {
+          ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+          RD_TRY(launch_to_bf16(h, h->fgS, h->bgS, (long)B * D * HWo, st));
+          RD_TRY(launch_to_bf16(h, dys[l], h->bdy, (long)B * 2 * D * HWo, st));
+          hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 48), dim3(256), 0, st,
+                             h->fU[l], (unsigned short*)h->bUT, cc, map);
+        }
+        RD_TRY(launch_conv16(h, h->plans[pbs], h->d_plans + pbs, B, h->bgS, h->bUT, gups[l], epi_make(RD_EPI_PLAIN), st,
+                             RDGAN_TAG_GCONV_DGRAD));
+        RD_TRY(launch_conv16(h, h->plans[pbe], h->d_plans + pbe, B, h->bdy, h->bUT, h->fdE, epi_make(RD_EPI_PLAIN), st,
+                             RDGAN_TAG_GCONV_DGRAD));
+      } else {
       RD_TRY(launch_conv(h, h->plans[pbs], h->d_plans + pbs, B, h->fgS, h->fUT, h->gch[l - 1], gups[l], epi_make(RD_EPI_PLAIN), st,
                          RDGAN_TAG_GCONV_DGRAD));
       RD_TRY(launch_conv(h, h->plans[pbe], h->d_plans + pbe, B, dys[l], h->fUT, h->gch[l - 1], h->fdE, epi_make(RD_EPI_PLAIN), st,
                          RDGAN_TAG_GCONV_DGRAD));
+      }
       {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
         hipLaunchKernelGGL(k_combine_dx, dim3(ew_blocks((long)B * D * P / 4)), dim3(256), 0, st, gups[l], h->fdE, B, D, P);
@@ -1460,6 +1536,30 @@ extern "C" int rdgan_op_conv3d(const float* x, const float* w, const float* bias
   return (int)hipStreamSynchronize(st);
 }
 
+// bf16-operand variant of the above for stride-1/2 convs without folded upsample (tests): x and w are rounded to
+// bf16 (nearest even) on the device, products accumulate in fp32.  Cin % 64 == 0, Cout % 64 == 0.
+extern "C" int rdgan_op_conv3d_bf16(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W,
+                                    int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h, int pad_w,
+                                    void* stream) {
+  if (!x || !w || !y || Cin % 64 || Cout % 64) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  TmpPlan tp;
+  tp.host = plan_conv_fwd(D, H, W, Cin, Cout, Do, Ho, Wo, stride, pad_d, pad_h, pad_w, 0);
+  RD_TRY(tp.upload());
+  const long nx = (long)B * D * H * W * Cin, nw = 27L * Cin * Cout;
+  void *xb = nullptr, *wb = nullptr;
+  hipError_t e = hipMalloc(&xb, nx * 2);
+  if (e == hipSuccess) e = hipMalloc(&wb, nw * 2);
+  int rc = (int)e;
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) rc = launch_weights_to_bf16_t(nullptr, w, wb, 27, Cin, Cout, st);
+  if (rc == 0) rc = launch_conv16(nullptr, tp.host, tp.dev, B, xb, wb, y, epi_make(bias ? RD_EPI_BIAS : RD_EPI_PLAIN, bias), st, -1);
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  if (xb) (void)hipFree(xb);
+  if (wb) (void)hipFree(wb);
+  return rc;
+}
+
 extern "C" int rdgan_op_conv3d_dgrad(const float* gy, const float* w, float* gx, int B, int D, int H, int W, int Cin,
                                      int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h, int pad_w,
                                      void* stream) {
@@ -1481,6 +1581,36 @@ extern "C" int rdgan_op_conv3d_dgrad(const float* gy, const float* w, float* gx,
   if (rc == 0) rc = launch_conv(nullptr, tp.host, tp.dev, B, gy, wt, Cin, gx, epi_make(RD_EPI_PLAIN), st, -1);
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   (void)hipFree(wt);
+  return rc;
+}
+
+// input gradient with bf16 operands (tests): gy and w rounded to bf16, fp32 accumulation.  The [tap][Cin][Cout] kernel IS
+// the [tap block][N][K] layout of this GEMM (N = Cin, K = Cout), so the weights are only converted.
+extern "C" int rdgan_op_conv3d_dgrad_bf16(const float* gy, const float* w, float* gx, int B, int D, int H, int W, int Cin,
+                                          int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h, int pad_w,
+                                          void* stream) {
+  if (!gy || !w || !gx || Cout % 64 || Cin % 64) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  TmpPlan tp;
+  if (stride == 1) {
+    if (pad_d != 1 || pad_h != 1 || pad_w != 1 || Do != D || Ho != H || Wo != W) return -2;
+    tp.host = plan_conv_dgrad_s1(D, H, W, Cin, Cout);
+  } else {
+    int pad[3] = {pad_d, pad_h, pad_w};
+    tp.host = plan_conv_dgrad_s2(D, H, W, Cin, Do, Ho, Wo, Cout, pad);
+  }
+  const long ng = (long)B * Do * Ho * Wo * Cout, nw = 27L * Cin * Cout;
+  void *gb = nullptr, *wb = nullptr;
+  hipError_t e = hipMalloc(&gb, ng * 2);
+  if (e == hipSuccess) e = hipMalloc(&wb, nw * 2);
+  int rc = (int)e;
+  if (rc == 0) rc = tp.upload();
+  if (rc == 0) rc = launch_to_bf16(nullptr, gy, gb, ng, st);
+  if (rc == 0) rc = launch_to_bf16(nullptr, w, wb, nw, st);
+  if (rc == 0) rc = launch_conv16(nullptr, tp.host, tp.dev, B, gb, wb, gx, epi_make(RD_EPI_PLAIN), st, -1);
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  if (gb) (void)hipFree(gb);
+  if (wb) (void)hipFree(wb);
   return rc;
 }
 

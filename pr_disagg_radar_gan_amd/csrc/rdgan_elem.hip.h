@@ -734,3 +734,49 @@ __global__ void k_combine_dx(float* __restrict__ dx, const float* __restrict__ d
     *(f32x4*)(dx + f * 4) = v;
   }
 }
+
+// ------------------------------------------------------------------------------------
+// bf16 operand copies for the bf16-MFMA conv GEMM (fp32 -> bf16, round to nearest even; v_cvt_pk_bf16_f32)
+// ------------------------------------------------------------------------------------
+typedef __bf16 rd_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rd_pack_bf16(float a, float b) {
+  rd_bf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+// n % 8 == 0
+__global__ void k_to_bf16(const float* __restrict__ in, unsigned short* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n / 8; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 a = *(const f32x4*)(in + 8 * i), b = *(const f32x4*)(in + 8 * i + 4);
+    u32x4_t o = {rd_pack_bf16(a.x, a.y), rd_pack_bf16(a.z, a.w), rd_pack_bf16(b.x, b.y), rd_pack_bf16(b.z, b.w)};
+    *(u32x4_t*)(out + 8 * i) = o;
+  }
+}
+// out[t][n][k] = bf16(in[t][k][n]): the weight layout of the bf16 conv GEMM (K contiguous); grid (N/32, K/32, T)
+__global__ void k_weights_to_bf16_t(const float* __restrict__ in, unsigned short* __restrict__ out, int K, int N) {
+  __shared__ float tile[32][33];
+  const long t = blockIdx.z;
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int k = k0 + i, n = n0 + tx;
+    tile[i][tx] = (k < K && n < N) ? in[(t * K + k) * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, k = k0 + tx;
+    if (n < N && k < K) {
+      const __bf16 v = (__bf16)tile[tx][i];
+      out[(t * N + n) * K + k] = __builtin_bit_cast(unsigned short, v);
+    }
+  }
+}
+// out[q][:] = bf16(in[map[q]][:]) for q < gridDim.y, cc floats per block (cc % 8 == 0): the input-gradient weight forms of the
+// bf16 conv GEMM are the forward forms U themselves ([Cin][Cout] = [N][K] of that GEMM), re-ordered by tap
+__global__ void k_blocks_to_bf16(const float* __restrict__ in, unsigned short* __restrict__ out, long cc, RdSliceMap map) {
+  const long q = blockIdx.y, t = map.src[blockIdx.y];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < cc / 8; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 a = *(const f32x4*)(in + t * cc + 8 * i), b = *(const f32x4*)(in + t * cc + 8 * i + 4);
+    u32x4_t o = {rd_pack_bf16(a.x, a.y), rd_pack_bf16(a.z, a.w), rd_pack_bf16(b.x, b.y), rd_pack_bf16(b.z, b.w)};
+    *(u32x4_t*)(out + q * cc + 8 * i) = o;
+  }
+}

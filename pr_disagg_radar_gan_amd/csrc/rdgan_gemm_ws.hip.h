@@ -22,7 +22,13 @@ __device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float*
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int TG>
+// BF = true: bf16 operands, fp32 accumulation and output (v_mfma_f32_32x32x16_bf16).  `src` then points at bf16
+// activations in the same NDHWC layout and `W` at bf16 weights stored [tap block][N][K per tap] (K contiguous, so both
+// operands are 16-byte fragments); a K chunk is 64 elements, i.e. the same 128-byte LDS rows, DMA pattern and swizzle as
+// the fp32 kernel, and B uses A's row image.  Plans need SC % 64 == 0.  Everything else (tile decode, row tables, tap
+// masks, epilogue) is shared.
+typedef __bf16 rd_bf16x8 __attribute__((ext_vector_type(8)));
+template <int BM, int BN, int WM, int WN, int TG, bool BF = false>
 __global__ void __launch_bounds__(512, 4)
 k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
                const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {
@@ -86,7 +92,9 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
   const int ssample = (int)plan->src_sample;
   const int ntaps = P.ntaps;
   const RdRowTab tab = rd_row_tab(plan, P.tab);
-  const int CPT = SC / BK;
+  constexpr int ESZ = BF ? 2 : 4;                        // operand element size
+  constexpr int KCH = BK * 4 / ESZ;                      // elements of K per chunk (one 128-byte row)
+  const int CPT = SC / KCH;
   const int nch_all = ntaps * CPT;
   const int ksplit = epi.ksplit > 1 ? epi.ksplit : 1;
   int q0 = 0, nchunks = nch_all;
@@ -101,8 +109,8 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
   if (!is_compute) {
     // =============================== loader waves ===============================
     const int wl = wave - 4;
-    const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)b0 * plan->src_sample);
-    const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(W + P.w_off);
+    const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc((const float*)((const char*)src + (long)b0 * plan->src_sample * ESZ));
+    const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc((const float*)((const char*)W + (long)P.w_off * ESZ));
     // A: instruction k of this wave fills rows wl*(BM/4) + 8k .. +7; this lane: row +(lane>>3), physical chunk lane&7
     // (branch-free, so that the NI_A row-table loads go out back to back and are waited for once: with a branch per
     // row hipcc serialises them, one memory round trip each, and the first DMA leaves ~10 us late)
@@ -126,15 +134,21 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
         const int r = wl * (BM / 4) + k * 8 + (lane >> 3);
         const int c_log = (lane & 7) ^ ((r >> 1) & 7);
         const bool ok = m0 + r < rows;
-        roff[k] = ok ? (rb_[k] * ssample + ex[k] + c_log * 4) * 4 : 0;
+        roff[k] = ok ? (rb_[k] * ssample + ex[k] + c_log * (16 / ESZ)) * ESZ : 0;
         rbits[k] = ok ? ey[k] : 0;
       }
     }
     int boff[NI_B];
 #pragma unroll
     for (int j = 0; j < NI_B; ++j) {
-      const int kk = (wl * NI_B + j) * B_RPI + lane / B_LPR;
-      boff[j] = (kk * ldw + n0 + (lane % B_LPR) * 4) * 4;
+      if constexpr (BF) {      // B image = BN rows (n) of 128 bytes (64 k), swizzled like A; instruction j of this wave fills 8 rows
+        const int n = (wl * NI_B + j) * 8 + (lane >> 3);
+        const int c_log = (lane & 7) ^ ((n >> 1) & 7);
+        boff[j] = ((n0 + n) * wrpt + c_log * 8) * 2;
+      } else {
+        const int kk = (wl * NI_B + j) * B_RPI + lane / B_LPR;
+        boff[j] = (kk * ldw + n0 + (lane % B_LPR) * 4) * 4;
+      }
     }
     // gather offsets of the current group of TG taps (TG = 4 for the 4-tap plans of the shared-centre form: half the
     // mask/select work in front of the first DMA)
@@ -145,10 +159,11 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       for (int t = 0; t < TG; ++t) {
         const int tap = min(g * TG + t, ntaps - 1);
         const RdTap ti = P.tap[tap];
-        tapw[t] = ti.w * wrpt * ldw * 4;
+        tapw[t] = BF ? ti.w * wrpt * plan->N * 2 : ti.w * wrpt * ldw * 4;
+        const int tdelta = BF ? ti.delta >> 1 : ti.delta;     // plan deltas are fp32 byte offsets
 #pragma unroll
         for (int k = 0; k < NI_A; ++k)
-          voffs[k][t] = ((rbits[k] & ti.mask) == ti.mask) ? (unsigned)(roff[k] + ti.delta) : RD_OOB;
+          voffs[k][t] = ((rbits[k] & ti.mask) == ti.mask) ? (unsigned)(roff[k] + tdelta) : RD_OOB;
       }
     };
     int ld_g = 0, ld_cc = 0, ld_t = 0, ld_gt = min(TG, ntaps);
@@ -166,7 +181,7 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       float* As = smem + stage * STAGE + wl * (BM / 4) * BK;
       float* Bs = smem + stage * STAGE + BM * BK + wl * NI_B * 256;
       const int sA = ld_cc * BK * 4;
-      const int sB = tapw[t] + ld_cc * BK * ldw * 4;
+      const int sB = BF ? tapw[t] + ld_cc * BK * 4 : tapw[t] + ld_cc * BK * ldw * 4;
 #pragma unroll
       for (int k = 0; k < NI_A; ++k)
         rd_lds_dma16(rsA, As + k * 8 * BK, (int)voffs[k][t], sA);
@@ -229,6 +244,35 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
     if (ws_st && wave == 0) atomicAdd(&rd_stamp_ws[0], rd_stamp() - ws_t0);
 #endif
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (BF) {
+      for (int q = 0; q < nchunks; ++q) {
+        const int buf = q & 1;
+        const float* As = smem + buf * STAGE + (wm * WTM + l31) * BK;
+        const float* Bs = smem + buf * STAGE + BM * BK + (wn * WTN + l31) * BK;
+        // k-step kk covers 16 elements = the 16-byte chunks 2kk (lanes 0-31) and 2kk+1 (lanes 32-63) of a row
+        f32x4 fa[2][TM], fb[2][TN];
+        auto load_frag = [&](int slot, int kk) {
+          const int col = ((kk * 2 + lhalf) ^ a_sw) * 4;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[slot][i] = *(const f32x4*)&As[i * 32 * BK + col];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[slot][j] = *(const f32x4*)&Bs[j * 32 * BK + col];
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int cur = kk & 1;
+          if (kk + 1 < 4) load_frag(cur ^ 1, kk + 1);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, fa[cur][i]),
+                                                                  __builtin_bit_cast(rd_bf16x8, fb[cur][j]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    } else
     for (int q = 0; q < nchunks; ++q) {
       const int buf = q & 1;
       const float* As = smem + buf * STAGE + (wm * WTM + l31) * BK;

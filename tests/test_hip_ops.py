@@ -46,6 +46,30 @@ def test_conv3d_forward(g):
     assert rel_err(y.cpu().numpy(), ref) < 1e-5
 
 
+def _bf16_round(a):
+    """round to nearest-even bfloat16, returned as float32 (what v_cvt_pk_bf16_f32 does)"""
+    return torch.from_numpy(a).bfloat16().float().numpy()
+
+
+@pytest.mark.parametrize("g", [g for g in GEOMS if not g[8]], ids=[g[0] for g in GEOMS if not g[8]])
+def test_conv3d_bf16_operands(g):
+    """bf16-operand conv GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulation): against the oracle evaluated on the
+    bf16-rounded inputs the result must be as tight as the fp32 kernel's (only the summation order differs)."""
+    name, B, dims, cin, cout, od, stride, pad, up = g
+    rng = np.random.default_rng(hash(name) % 1000 + 7)
+    x = rng.standard_normal((B,) + dims + (cin,)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = _oracle_conv(_bf16_round(x), _bf16_round(w), b, g).numpy()
+    ref32 = _oracle_conv(x, w, b, g).numpy()
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    y = torch.full((B,) + od + (cout,), float("nan"), device="cuda")
+    rc = lib().rdgan_op_conv3d_bf16(ptr(xd), ptr(wd), ptr(bd), ptr(y), B, *dims, cin, cout, *od, stride, *pad, stream())
+    assert rc == 0
+    assert rel_err(y.cpu().numpy(), ref) < 1e-5
+    assert 1e-4 < rel_err(y.cpu().numpy(), ref32) < 3e-2          # and it really is bf16: ~2^-9 per operand
+
+
 @pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
 def test_conv3d_dgrad(g):
     name, B, dims, cin, cout, od, stride, pad, up = g
@@ -59,6 +83,24 @@ def test_conv3d_dgrad(g):
     gx = torch.full((B,) + in_dims + (cin,), float("nan"), device="cuda")
     gyd, wd = dev(gy), dev(w)            # keep the device tensors alive across the call
     rc = lib().rdgan_op_conv3d_dgrad(ptr(gyd), ptr(wd), ptr(gx), B, *in_dims, cin, cout, *od, stride, *pad, stream())
+    assert rc == 0
+    assert rel_err(gx.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("g", [g for g in GEOMS if not g[8]], ids=[g[0] for g in GEOMS if not g[8]])
+def test_conv3d_dgrad_bf16_operands(g):
+    """input gradient through the bf16-operand GEMM (parity-phase plans, weights un-transposed): exact against the oracle
+    on bf16-rounded gy and w up to fp32 summation order"""
+    name, B, dims, cin, cout, od, stride, pad, up = g
+    rng = np.random.default_rng(hash(name) % 1000 + 9)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cout)).astype(np.float32)
+    gy = rng.standard_normal((B,) + od + (cout,)).astype(np.float32)
+    xt = torch.zeros((B,) + dims + (cin,), dtype=torch.float64, requires_grad=True)
+    yt = ot._conv3d_tf(xt, torch.from_numpy(_bf16_round(w)).double(), None, stride, pad, od)
+    ref, = torch.autograd.grad(yt, xt, torch.from_numpy(_bf16_round(gy)).double())
+    gx = torch.full((B,) + dims + (cin,), float("nan"), device="cuda")
+    gyd, wd = dev(gy), dev(w)
+    rc = lib().rdgan_op_conv3d_dgrad_bf16(ptr(gyd), ptr(wd), ptr(gx), B, *dims, cin, cout, *od, stride, *pad, stream())
     assert rc == 0
     assert rel_err(gx.cpu().numpy(), ref.numpy()) < 1e-5
 

@@ -301,3 +301,31 @@ def test_odd_batches_default_options(B):
         _parity_over_batches(run_gen)
     finally:
         eng.close()
+
+
+def test_mfma_bf16_option(eng16):
+    """"mfma_bf16": the shared-centre forward / input-gradient GEMMs of generator blocks 2 and 3 take bf16 operand copies
+    (fp32 accumulation, fp32 tensors everywhere else; the kernel itself is pinned to 1e-5 against the oracle on
+    bf16-rounded inputs in test_hip_ops.py).  Against the fp32 oracle the results must sit within bf16 rounding
+    (2^-9 per operand) and must differ from the fp32 path, so the option really switches kernels."""
+    eng16.set_option("collapse", 1); eng16.set_option("wave_specialized", 1)
+    eng16.set_option("fast_fwd", 1); eng16.set_option("fast_bwd", 1)
+    g, d = _params(16, 51)
+    x, cond, z = ot.synthetic_batch(4, 16, 23)
+    gs, ds = eng16.to_slab(g), eng16.to_slab(d)
+    ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
+    loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 6)
+    out32 = eng16.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+    try:
+        eng16.set_option("mfma_bf16", 1)
+        out = eng16.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+        assert np.all(np.isfinite(out))
+        np.testing.assert_allclose(out.sum(axis=1), 1.0, rtol=0, atol=2e-6)
+        e16, e32 = rel_err(out, ref), rel_err(out32, ref)
+        assert e32 < 2e-5 and 1e-4 < e16 < 2e-2, (e16, e32)
+        slab = eng16.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
+        errs = _grad_errors(slab[:eng16.n_gen], grads, eng16.gen_shapes)
+        assert max(errs.values()) < 0.15, errs                       # bf16 operands + the LeakyReLU sign flips they cause in the critic
+        assert min(errs.values()) > 1e-5, errs
+    finally:
+        eng16.set_option("mfma_bf16", 0)
