@@ -370,6 +370,10 @@ struct rdgan_handle {
   // "mfma_bf16": bf16 copies of the operands of the shared-centre GEMMs (block input x, differences E, plane sums gS,
   // output gradient dy, weight forms in [N][K] layout)
   void *bX[4], *bE[4], *bU[4], *bUT, *bgS, *bdy;
+  void *bScr;                     // bf16 copy of the current GEMM's gathered operand (critic layers, generator block 1)
+  size_t bScr_elems = 0;
+  void *bWF[5], *bWB[5];          // critic layers 2-4: bf16 kernels [27][Cout][Cin] (forward) and [27][Cin][Cout] (input gradient)
+  void *bG1F, *bG1B;              // generator block 1: collapsed forms [64][Cout][Cin] and, re-ordered by tap, [64][Cin][Cout]
   int mfma_bf16 = 0;              // 1: shared-centre forward / input-gradient GEMMs of blocks 2, 3 on bf16 operands (fp32 accumulate, fp32 tensors everywhere else)
   int fast_fwd = 1;               // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products)
   int fast_bwd = 1;               // 1: generator blocks' weight/input gradients in the shared-centre form along d (48 instead of 64 tap products)
@@ -612,6 +616,10 @@ static int launch_weights_to_bf16_t(rdgan_handle* h, const float* in, void* out,
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
+
+// mixed mode: the GEMM reads a bf16 copy of its gathered operand made just before it (n_src floats of src) and bf16 weights
+static int conv_mixed(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, size_t n_src, const void* w16,
+                      float* dst, const RdEpi& epi, hipStream_t st, int tag);
 
 // true when launch_conv will pick a tile whose BN equals the plan's N, i.e. a workgroup owns whole output rows
 static bool conv_rows_owned(const RdPlan& hp, int B) {
@@ -980,6 +988,15 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, 24L * 256 * 256 + 8); h->bUT = p;
         carve(p, MB * ns / 2 + 8); h->bgS = p;
         carve(p, MB * ns + 8); h->bdy = p;
+        h->bScr_elems = std::max<size_t>((size_t)NB * h->dL[1] * 64, (size_t)MB * h->gpix[1] * 256);
+        carve(p, h->bScr_elems / 2 + 8); h->bScr = p;
+        h->bWF[0] = h->bWF[1] = h->bWB[0] = h->bWB[1] = nullptr;
+        for (int l = 2; l <= 4; ++l) {
+          carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->bWF[l] = p;
+          carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->bWB[l] = p;
+        }
+        carve(p, 32L * 256 * 256 + 8); h->bG1F = p;
+        carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
     }
@@ -1147,6 +1164,11 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     const bool fuse = conv_rows_owned(h->plans[pl], B);       // PixelNorm+LeakyReLU in the GEMM epilogue
     RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
     ep.rinv = rs[l];
+    if (h->collapse && h->mfma_bf16 && l == 1) {     // mixed mode: block 1 (collapsed form) on bf16 operands
+      RD_TRY(launch_weights_to_bf16_t(h, h->GWC[1], h->bG1F, 64, h->gch[0], h->gch[1], st));
+      RD_TRY(conv_mixed(h, h->plans[pl], h->d_plans + pl, B, hs[0], (size_t)B * h->gpix[0] * h->gch[0], h->bG1F, hs[1], ep, st,
+                        RDGAN_TAG_GCONV_FWD));
+    } else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], Wl, h->gch[l], hs[l], ep, st,
                        l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
     if (!fuse) {
@@ -1192,7 +1214,23 @@ static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st)
   // W1 [27*Cin][64] -> W1T [64][ldp1] (columns (tap,ci), zero padded)
   RD_TRY(launch_transpose(h, dp + h->doff[0], h->W1T, 1, 27 * h->Cin, 64, h->ldp1, st));
   if (h->CP != h->Cin) hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, dp + h->doff[0], h->W1P, h->Cin, h->CP);
+  if (h->mfma_bf16)
+    for (int l = 2; l <= 4; ++l) {
+      const float* w = dp + h->doff[2 * (l - 1)];
+      RD_TRY(launch_weights_to_bf16_t(h, w, h->bWF[l], 27, h->dch[l - 1], h->dch[l], st));
+      RD_TRY(launch_to_bf16(h, w, h->bWB[l], 27L * h->dch[l - 1] * h->dch[l], st));
+    }
   return 0;
+}
+
+static int conv_mixed(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, size_t n_src, const void* w16,
+                      float* dst, const RdEpi& epi, hipStream_t st, int tag) {
+  if (n_src > h->bScr_elems) return bad_arg(h, "conv_mixed: bf16 scratch too small");
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    RD_TRY(launch_to_bf16(h, src, h->bScr, (long)n_src, st));
+  }
+  return launch_conv16(h, hp, dp, B, h->bScr, w16, dst, epi, st, tag);
 }
 
 // D1's forward weights: the caller's [27][Cin][64] kernel, or its zero-padded [27][CP][64] copy when CP > Cin
@@ -1206,11 +1244,14 @@ static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64
   const float* in = h->cin;
   for (int l = 1; l <= 4; ++l) {
     int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
+    const RdEpi ep = epi_make(RD_EPI_BIAS_LRELU_DROP, dp + h->doff[2 * (l - 1) + 1], nullptr, use_drop,
+                              rd_make_key(seed, RD_STREAM_D1 + l - 1), 0);
+    if (l >= 2 && h->mfma_bf16)
+      RD_TRY(conv_mixed(h, h->plans[pl], h->d_plans + pl, NBt, in, (size_t)NBt * h->dL[l - 1] * h->dch[l - 1], h->bWF[l], h->dh[l], ep,
+                        st, RDGAN_TAG_CRITIC_GEMM));
+    else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
-                       h->dch[l], h->dh[l],
-                       epi_make(RD_EPI_BIAS_LRELU_DROP, dp + h->doff[2 * (l - 1) + 1], nullptr, use_drop,
-                                rd_make_key(seed, RD_STREAM_D1 + l - 1), 0),
-                       st, RDGAN_TAG_CRITIC_GEMM));
+                       h->dch[l], h->dh[l], ep, st, RDGAN_TAG_CRITIC_GEMM));
     in = h->dh[l];
   }
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
@@ -1229,9 +1270,13 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
   }
   for (int l = 4; l >= 2; --l) {
     int pl = PL_D2B + l - 2;
-    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->DWT[l], h->dch[l - 1], h->du[l - 1],
-                       epi_make(RD_EPI_GATE_AUX, nullptr, h->dh[l - 1], use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 2), 0),
-                       st, RDGAN_TAG_CRITIC_GEMM));
+    const RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, h->dh[l - 1], use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 2), 0);
+    if (h->mfma_bf16)
+      RD_TRY(conv_mixed(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], (size_t)NBt * h->dL[l] * h->dch[l], h->bWB[l], h->du[l - 1], ep,
+                        st, RDGAN_TAG_CRITIC_GEMM));
+    else
+    RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->DWT[l], h->dch[l - 1], h->du[l - 1], ep, st,
+                       RDGAN_TAG_CRITIC_GEMM));
   }
   return 0;
 }
@@ -1252,7 +1297,8 @@ extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params,
   if (!h || !critic_params || !sample || !cond || !out) return bad_arg(h, "critic_forward: null pointer");
   if (B < 1 || B > h->NB) return bad_arg(h, "critic_forward: B outside [1, 3*max_batch]");
   hipStream_t st = (hipStream_t)stream;
-  if (h->CP != h->Cin)
+  if (h->mfma_bf16) RD_TRY(prep_critic_weights(h, critic_params, st));      // (also makes the bf16 kernels of layers 2-4)
+  else if (h->CP != h->Cin)
     hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, critic_params + h->doff[0], h->W1P, h->Cin, h->CP);
   hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, sample,
                      (const float*)nullptr, cond, h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 2, 0u);
@@ -1294,11 +1340,13 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
       int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
       long third = (long)2 * B * h->dL[l] * h->dch[l];
       float* dst = h->dh[l] + third;
+      const RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, dst, use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 1), (uint32_t)third);
+      if (l >= 2 && h->mfma_bf16)
+        RD_TRY(conv_mixed(h, h->plans[pl], h->d_plans + pl, B, in, (size_t)B * h->dL[l - 1] * h->dch[l - 1], h->bWF[l], dst, ep, st,
+                          RDGAN_TAG_CRITIC_GEMM));
+      else
       RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
-                         h->dch[l], dst,
-                         epi_make(RD_EPI_GATE_AUX, nullptr, dst, use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 1),
-                                  (uint32_t)third),
-                         st, RDGAN_TAG_CRITIC_GEMM));
+                         h->dch[l], dst, ep, st, RDGAN_TAG_CRITIC_GEMM));
       in = dst;
     }
   }
@@ -1462,6 +1510,14 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
       hipLaunchKernelGGL(k_fold_collapsed_wgrad, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->dWc,
                          grad + h->goff[2 * l], (int)cc);
       RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
+      if (h->mfma_bf16 && l == 1) {      // mixed mode: the collapsed forms re-ordered by tap are already [N = Cin][K = Cout]
+        RdSliceMap map;
+        collapsed_dgrad_slice_map(map.src);
+        hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 64), dim3(256), 0, st,
+                           h->GWC[1], (unsigned short*)h->bG1B, cc, map);
+        RD_TRY(conv_mixed(h, h->plans[plb], h->d_plans + plb, B, dys[1], (size_t)B * h->gpix[1] * h->gch[1], h->bG1B, gups[1],
+                          epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
+      } else
       RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWD[l], h->gch[l - 1], gups[l],
                          epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
     } else {

@@ -323,6 +323,17 @@ def test_mfma_bf16_option(eng16):
         np.testing.assert_allclose(out.sum(axis=1), 1.0, rtol=0, atol=2e-6)
         e16, e32 = rel_err(out, ref), rel_err(out32, ref)
         assert e32 < 2e-5 and 1e-4 < e16 < 2e-2, (e16, e32)
+        # critic: forward and the critic-step gradients (layers 2-4 on bf16 operands)
+        masks = ot.critic_masks(7, 4, 16, torch.float64)
+        vref = ot.critic_forward(_t64(d), torch.from_numpy(x).double(), torch.from_numpy(cond).double(), masks).numpy()
+        v = eng16.critic_forward(ds, dev(x), dev(cond), seed=7).cpu().numpy()
+        assert 1e-5 < rel_err(v, vref) < 3e-2, rel_err(v, vref)
+        closs, cgrads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(), torch.from_numpy(cond).double(),
+                                             torch.from_numpy(z).double(), 9)
+        cslab = eng16.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 9).cpu().numpy()
+        np.testing.assert_allclose(cslab[eng16.n_critic:eng16.n_critic + 3], closs.numpy()[:3], rtol=5e-2, atol=5e-3)
+        cerrs = _grad_errors(cslab[:eng16.n_critic], cgrads, eng16.critic_shapes)
+        assert max(cerrs.values()) < 0.25, cerrs                     # (the penalty term squares the bf16 noise of the input gradient)
         slab = eng16.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
         errs = _grad_errors(slab[:eng16.n_gen], grads, eng16.gen_shapes)
         assert max(errs.values()) < 0.15, errs                       # bf16 operands + the LeakyReLU sign flips they cause in the critic
