@@ -163,6 +163,11 @@ int rdgan_op_conv3d_dgrad_bf16(const float* gy, const float* w, float* gx, int B
 int rdgan_op_conv3d_wgrad(const float* x, const float* gy, float* dw, int B, int D, int H, int W,
                           int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h,
                           int pad_w, int upsample, void* stream);
+/* weight gradient with bf16 operands (x, gy rounded to bf16; fp32 accumulation and output): Cin % 128 == 0 and
+ * Cout % 64 == 0, or Cin == 64 and Cout % 128 == 0 (tiles of 128 or 256 rows). */
+int rdgan_op_conv3d_wgrad_bf16(const float* x, const float* gy, float* dw, int B, int D, int H, int W,
+                               int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h,
+                               int pad_w, void* stream);
 /* PixelNormalization + LeakyReLU(0.2) forward (T:255-266, T:333) and its backward. C in {64,128,256}. */
 int rdgan_op_pixelnorm_lrelu(const float* y, float* h, float* rinv, long npix, int C, void* stream);
 int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* rinv, float* dy,

@@ -14,6 +14,7 @@
 #include "rdgan_rng.h"
 #include "rdgan_gemm.hip.h"
 #include "rdgan_gemm_ws.hip.h"
+#include "rdgan_gemm_ws16.hip.h"
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
 
@@ -370,7 +371,7 @@ struct rdgan_handle {
   // "mfma_bf16": bf16 copies of the operands of the shared-centre GEMMs (block input x, differences E, plane sums gS,
   // output gradient dy, weight forms in [N][K] layout)
   void *bX[4], *bE[4], *bU[4], *bUT, *bgS, *bdy;
-  void *bScr;                     // bf16 copy of the current GEMM's gathered operand (critic layers, generator block 1)
+  void *bScr, *bScr2;             // bf16 copies of the current GEMM's operands (critic layers, generator block 1)
   size_t bScr_elems = 0;
   void *bWF[5], *bWB[5];          // critic layers 2-4: bf16 kernels [27][Cout][Cin] (forward) and [27][Cin][Cout] (input gradient)
   void *bG1F, *bG1B;              // generator block 1: collapsed forms [64][Cout][Cin] and, re-ordered by tap, [64][Cin][Cout]
@@ -739,6 +740,56 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   return 0;
 }
 
+// bf16-operand weight gradient (mixed mode): src16 / dy16 = bf16 copies of the gathered tensor and of the output gradient;
+// same tiling, partial slabs and fold as launch_wgrad.  Tiles 256x64, 128x128, 128x64.
+template <int BR, int BN>
+static int launch_wgrad16_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int B, const void* src16, const void* dy16,
+                              float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
+  constexpr size_t lds_loop = 2 * (size_t)(64 * BR * 2 + 64 * BN * 2);
+  constexpr size_t lds_epi = (size_t)BR * BN * sizeof(float);
+  constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  static bool attr_done = false;
+  auto kern = k_wgrad_gemm_ws16<BR, BN>;
+  if (!attr_done) {
+    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dp, B, (const unsigned short*)src16, (const unsigned short*)dy16, partial, T);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+static bool wgrad16_ok(const RdPlan& hp, int B) {
+  int BR, BN, nsplit;
+  if (hp.s_shift || hp.SC % 64 || hp.N % 64) return false;
+  wgrad_tiling(hp, B, BR, BN, nsplit);
+  return BR >= 128;
+}
+static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* dy16,
+                          float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
+  ProfScope ps(h, tag, st);
+  if (!wgrad16_ok(hp, B)) return bad_arg(h, "wgrad16: needs SC % 64 == 0, N % 64 == 0, a 128- or 256-row tile, no folded upsample");
+  for (int i = 1; i < hp.nphases; ++i)
+    if (hp.ph[i].ntaps != hp.ph[0].ntaps || hp.ph[i].L != hp.ph[0].L) return bad_arg(h, "wgrad: phases must be congruent");
+  int BR, BN, nsplit;
+  RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
+  size_t need = (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
+  if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
+  if ((T.rows_per_split / hp.ph[0].L + 2) * std::max(hp.src_sample, hp.dst_sample) * 2 >= 0x7FFFFFF0L)
+    return bad_arg(h, "wgrad: split span exceeds 2 GiB");
+  const int np = hp.nphases;
+  if (BR == 256) RD_TRY((launch_wgrad16_cfg<256, 64>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
+  else if (BN == 128) RD_TRY((launch_wgrad16_cfg<128, 128>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
+  else RD_TRY((launch_wgrad16_cfg<128, 64>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
+  long total = (long)T.RT * BR * (hp.N / 4);
+  int outs = 256;
+  while (outs > 16 && (total + outs - 1) / outs * np < 512 && 256 / outs < nsplit) outs >>= 1;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + outs - 1) / outs), np), dim3(256), 0, st, dp, partial_ws,
+                     nsplit, T, BR, dW, hp.N, outs);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
 static size_t wgrad_partial_need(const RdPlan& hp, int B) {
   int BR, BN, nsplit;
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
@@ -990,6 +1041,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, MB * ns + 8); h->bdy = p;
         h->bScr_elems = std::max<size_t>((size_t)NB * h->dL[1] * 64, (size_t)MB * h->gpix[1] * 256);
         carve(p, h->bScr_elems / 2 + 8); h->bScr = p;
+        carve(p, h->bScr_elems / 2 + 8); h->bScr2 = p;
         h->bWF[0] = h->bWF[1] = h->bWB[0] = h->bWB[1] = nullptr;
         for (int l = 2; l <= 4; ++l) {
           carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->bWF[l] = p;
@@ -1232,6 +1284,17 @@ static int conv_mixed(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B
   }
   return launch_conv16(h, hp, dp, B, h->bScr, w16, dst, epi, st, tag);
 }
+// mixed mode weight gradient on bf16 copies made on the fly
+static int wgrad_mixed(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, size_t n_src, const float* dy,
+                       size_t n_dy, float* dW, hipStream_t st, int tag) {
+  if (n_src > h->bScr_elems || n_dy > h->bScr_elems) return bad_arg(h, "wgrad_mixed: bf16 scratch too small");
+  {
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    RD_TRY(launch_to_bf16(h, src, h->bScr, (long)n_src, st));
+    RD_TRY(launch_to_bf16(h, dy, h->bScr2, (long)n_dy, st));
+  }
+  return launch_wgrad16(h, hp, dp, B, h->bScr, h->bScr2, dW, h->wpartial, h->wpartial_cap, st, tag);
+}
 
 // D1's forward weights: the caller's [27][Cin][64] kernel, or its zero-padded [27][CP][64] copy when CP > Cin
 static inline const float* d1_weights(const rdgan_handle* h, const float* dp) {
@@ -1355,6 +1418,10 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
     int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
     const float* in = l == 1 ? h->cin : h->dh[l - 1];
     const bool padded = l == 1 && h->CP != h->Cin;   // D1 with padding channels: gradient of the padded kernel, then drop the pad rows
+    if (h->mfma_bf16 && l >= 2 && wgrad16_ok(h->plans[pl], NBt))     // layers 2-4 on bf16 operands
+      RD_TRY(wgrad_mixed(h, h->plans[pl], h->d_plans + pl, NBt, in, (size_t)NBt * h->dL[l - 1] * h->dch[l - 1], h->du[l],
+                         (size_t)NBt * h->dL[l] * h->dch[l], grad + h->doff[2 * (l - 1)], st, RDGAN_TAG_CRITIC_GEMM));
+    else
     RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], padded ? h->dW1P : grad + h->doff[2 * (l - 1)],
                         h->wpartial, h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM));
     if (padded) hipLaunchKernelGGL(k_unpad_w1, dim3(27), dim3(256), 0, st, h->dW1P, grad + h->doff[0], h->Cin, h->CP);
@@ -1459,10 +1526,22 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
                              (int)cc, 48, wm);
         }
       }
+      const bool bf = h->mfma_bf16 && gen_block_fast(h, l, h->fast_fwd) && wgrad16_ok(h->plans[PL_F1WS + l - 1], B);
+      if (bf) {      // bf16 copies of the plane sums and of the output gradient (x and E copies are the forward's)
+        ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+        const long HWo = (long)h->gdim[l][1] * h->gdim[l][2] * h->gch[l];
+        RD_TRY(launch_to_bf16(h, h->fgS, h->bgS, (long)B * D * HWo, st));
+        RD_TRY(launch_to_bf16(h, dys[l], h->bdy, (long)B * 2 * D * HWo, st));
+      }
       const float* wsrc[3] = {h->fE[l], hs[l - 1], h->fE[l]};
       const float* wdy[3] = {dys[l], h->fgS, dys[l]};
+      const void* wsrc16[3] = {h->bE[l], h->bX[l], h->bE[l]};
+      const void* wdy16[3] = {h->bdy, h->bgS, h->bdy};
       for (int g = 0; g < 3; ++g) {
         const int pl = PL_F1WA + 3 * g + l - 1;
+        if (bf) RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, B, wsrc16[g], wdy16[g], h->fdU, h->wpartial, h->wpartial_cap, st,
+                                      RDGAN_TAG_GCONV_WGRAD));
+        else
         RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, B, wsrc[g], wdy[g], h->fdU, h->wpartial, h->wpartial_cap, st,
                             RDGAN_TAG_GCONV_WGRAD));
       }
@@ -1484,8 +1563,10 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
         const long HWo = (long)h->gdim[l][1] * h->gdim[l][2] * h->gch[l];
         {
           ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-          RD_TRY(launch_to_bf16(h, h->fgS, h->bgS, (long)B * D * HWo, st));
-          RD_TRY(launch_to_bf16(h, dys[l], h->bdy, (long)B * 2 * D * HWo, st));
+          if (!bf) {
+            RD_TRY(launch_to_bf16(h, h->fgS, h->bgS, (long)B * D * HWo, st));
+            RD_TRY(launch_to_bf16(h, dys[l], h->bdy, (long)B * 2 * D * HWo, st));
+          }
           hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 48), dim3(256), 0, st,
                              h->fU[l], (unsigned short*)h->bUT, cc, map);
         }
@@ -1505,6 +1586,10 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
       }
     } else if (col) {
       int plf = PL_G1FC + l - 1, plb = PL_G1BC + l - 1;
+      if (h->mfma_bf16 && l == 1 && wgrad16_ok(h->plans[plf], B))
+        RD_TRY(wgrad_mixed(h, h->plans[plf], h->d_plans + plf, B, hs[0], (size_t)B * h->gpix[0] * h->gch[0], dys[1],
+                           (size_t)B * h->gpix[1] * h->gch[1], h->dWc, st, RDGAN_TAG_GCONV_WGRAD));
+      else
       RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap,
                           st, RDGAN_TAG_GCONV_WGRAD));
       hipLaunchKernelGGL(k_fold_collapsed_wgrad, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->dWc,
@@ -1590,6 +1675,34 @@ extern "C" int rdgan_op_conv3d(const float* x, const float* w, const float* bias
   hipStream_t st = (hipStream_t)stream;
   RD_TRY(launch_conv(nullptr, tp.host, tp.dev, B, x, w, Cout, y, epi_make(bias ? RD_EPI_BIAS : RD_EPI_PLAIN, bias), st, -1));
   return (int)hipStreamSynchronize(st);
+}
+
+// weight gradient with bf16 operands (tests): x and gy rounded to bf16 on the device, fp32 accumulation.  Cin % 128 == 0,
+// Cout % 64 == 0, no folded upsample.
+extern "C" int rdgan_op_conv3d_wgrad_bf16(const float* x, const float* gy, float* dw, int B, int D, int H, int W, int Cin,
+                                          int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h, int pad_w,
+                                          void* stream) {
+  if (!x || !gy || !dw || Cin % 64 || Cout % 64) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  TmpPlan tp;
+  tp.host = plan_conv_fwd(D, H, W, Cin, Cout, Do, Ho, Wo, stride, pad_d, pad_h, pad_w, 0);
+  RD_TRY(tp.upload());
+  if (!wgrad16_ok(tp.host, B)) return -2;
+  const long nx = (long)B * D * H * W * Cin, ng = (long)B * Do * Ho * Wo * Cout;
+  size_t need = wgrad_partial_need(tp.host, B);
+  void *xb = nullptr, *gb = nullptr; float* partial = nullptr;
+  hipError_t e = hipMalloc(&xb, nx * 2);
+  if (e == hipSuccess) e = hipMalloc(&gb, ng * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&partial, need * sizeof(float));
+  int rc = (int)e;
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) rc = launch_to_bf16(nullptr, gy, gb, ng, st);
+  if (rc == 0) rc = launch_wgrad16(nullptr, tp.host, tp.dev, B, xb, gb, dw, partial, need, st, -1);
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  if (xb) (void)hipFree(xb);
+  if (gb) (void)hipFree(gb);
+  if (partial) (void)hipFree(partial);
+  return rc;
 }
 
 // bf16-operand variant of the above for stride-1/2 convs without folded upsample (tests): x and w are rounded to

@@ -19,6 +19,7 @@ GEOMS = [
     ("D4", 7, (3, 2, 2), 256, 256, (2, 1, 1), 2, (1, 0, 0), 0),
     ("D2_nd64", 1, (11, 31, 31), 64, 128, (6, 16, 16), 2, (1, 1, 1), 0),
     ("plain_s1", 2, (5, 6, 7), 64, 64, (5, 6, 7), 1, (1, 1, 1), 0),
+    ("plain_128_64", 2, (5, 6, 7), 128, 64, (5, 6, 7), 1, (1, 1, 1), 0),
 ]
 
 
@@ -103,6 +104,27 @@ def test_conv3d_dgrad_bf16_operands(g):
     rc = lib().rdgan_op_conv3d_dgrad_bf16(ptr(gyd), ptr(wd), ptr(gx), B, *dims, cin, cout, *od, stride, *pad, stream())
     assert rc == 0
     assert rel_err(gx.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+_WG16 = [g for g in GEOMS if not g[8] and (g[3] % 128 == 0 or (g[3] == 64 and g[4] % 128 == 0))]   # tiles of 128+ rows
+
+
+@pytest.mark.parametrize("g", _WG16, ids=[g[0] for g in _WG16])
+def test_conv3d_wgrad_bf16_operands(g):
+    """weight gradient through the bf16-operand kernel (transposed LDS reads, ds_read_b64_tr_b16): exact against the oracle
+    on bf16-rounded x and gy up to fp32 summation order"""
+    name, B, dims, cin, cout, od, stride, pad, up = g
+    rng = np.random.default_rng(hash(name) % 1000 + 11)
+    x = rng.standard_normal((B,) + dims + (cin,)).astype(np.float32)
+    gy = rng.standard_normal((B,) + od + (cout,)).astype(np.float32)
+    wt = torch.zeros((3, 3, 3, cin, cout), dtype=torch.float64, requires_grad=True)
+    yt = ot._conv3d_tf(torch.from_numpy(_bf16_round(x)).double(), wt, None, stride, pad, od)
+    ref, = torch.autograd.grad(yt, wt, torch.from_numpy(_bf16_round(gy)).double())
+    dw = torch.full((3, 3, 3, cin, cout), float("nan"), device="cuda")
+    xd, gyd = dev(x), dev(gy)
+    rc = lib().rdgan_op_conv3d_wgrad_bf16(ptr(xd), ptr(gyd), ptr(dw), B, *dims, cin, cout, *od, stride, *pad, stream())
+    assert rc == 0
+    assert rel_err(dw.cpu().numpy(), ref.numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
