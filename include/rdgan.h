@@ -94,11 +94,11 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * instead of 64 tap products per position, algebraically identical.  Forward: T = S x once per output plane pair,
  * then the difference part adds T in its epilogue; backward: plane-pair sums of the output gradient feed the S part,
  * the gradient wrt E is folded back by the adjoint of the differencing.  0 = the 64-tap collapsed form.
- * "mfma_bf16" (default 0; needs the shared-centre form): the forward and input-gradient GEMMs of generator blocks 2
- * and 3 read bf16 copies of their operands (block input, hour differences, plane sums, output gradient, weight forms
- * stored [N][K]) and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; every tensor the caller or another kernel
- * sees stays fp32, weight gradients stay fp32.  Mixed-precision mode for BASELINE configs 3-5; results move by bf16
- * rounding (2^-9 per operand), so it is NOT the mode the fp32 metric is measured in.
+ * "mfma_bf16" (default 0; needs the shared-centre form): mixed mode for BASELINE configs 3-5.  The forward,
+ * input-gradient, second-sweep and weight-gradient GEMMs of generator blocks 1-3 and critic layers 2-4 read bf16
+ * copies of their operands (weight forms stored [N][K]) and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
+ * every tensor the caller or another kernel sees, all gradients and the optimizer state stay fp32.  Results move by
+ * bf16 rounding (2^-9 per operand), so it is NOT the mode the fp32 metric is measured in.
  * "tapgather" (default 1): the last generator conv (64 -> 1, T:345) runs as a column GEMM over its 27 taps whose
  * epilogue already sums the taps that fall inside the 256-row tile (ndomain 8/16: whole planes, 32/64/128: whole
  * rows), writing 3 or 9 floats per grid point instead of 32; 0 (and every other ndomain) = full column matrix +
