@@ -176,7 +176,7 @@ def main():
         avg_ms = kern_ms / max(kern_n, 1)
         opts = dict(kv.split("=") for kv in args.opt)     # A/B runs: the tagged launch is the whole block in the other forms
         taps = 27 if opts.get("collapse") == "0" else (8 if opts.get("fast_fwd") == "0" else 4)
-        bf16 = opts.get("mfma_bf16") == "1" and taps == 4     # mixed mode: bf16 operands in the shared-centre GEMMs of blocks 2, 3
+        bf16 = opts.get("mfma_bf16") == "1" and taps == 4     # mixed mode
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         achieved = gconv3_flops(B, ND, taps) / (avg_ms * 1e-3) / 1e12 if kern_n else None
         direct_equiv = None
@@ -188,7 +188,7 @@ def main():
                       else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles, bs={B} (extra data point)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16 operands (generator blocks 2, 3 forward / input gradient) + f32" if bf16 else "f32",
+            "vs_baseline": None, "dtype": "bf16 MFMA operands in every heavy GEMM, f32 accumulation / tensors / optimizer (mixed mode)" if bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"ndomain={ND}, 24h, bs={B} fp32 per GPU, {args.n_critic} critic step + 1 gen step"
                                    + (" (BASELINE configs[1])" if (ND, B, args.n_critic) == (16, 256, 1) else ""),
