@@ -850,12 +850,13 @@ static int launch_pn_bwd(rdgan_handle* h, const float* g, const float* hh, const
 
 // PixelNorm+LeakyReLU backward over hour-plane pairs, also writing the pair sums gS (shared-centre backward)
 static int launch_pn_bwd_pairs(rdgan_handle* h, const float* g, const float* hh, const float* rinv, float* dy, float* gS,
-                               long npair, long HW, int C, hipStream_t st) {
+                               long npair, long HW, int C, void* dy16v, void* gS16v, hipStream_t st) {
   long threads = npair * (C / 4);
   dim3 grid((unsigned)((threads + 255) / 256));
-  if (C == 256) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<64>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
-  else if (C == 128) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<32>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
-  else if (C == 64) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<16>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
+  unsigned short* dy16 = (unsigned short*)dy16v; unsigned short* gS16 = (unsigned short*)gS16v;
+  if (C == 256) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<64>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW, dy16, gS16);
+  else if (C == 128) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<32>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW, dy16, gS16);
+  else if (C == 64) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<16>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW, dy16, gS16);
   else return bad_arg(h, "pixelnorm bwd: C must be 64/128/256");
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -1176,15 +1177,15 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       fastd_weight_map(wm);
       {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-        hipLaunchKernelGGL(k_diff_d, dim3(ew_blocks((long)B * (sd[0] + 1) * P / 4)), dim3(256), 0, st, hs[l - 1], h->fE[l], B, sd[0], P);
+        const bool bf16 = h->mfma_bf16 && h->gch[l - 1] % 64 == 0;
+        hipLaunchKernelGGL(k_diff_d, dim3(ew_blocks((long)B * (sd[0] + 1) * P / 4)), dim3(256), 0, st, hs[l - 1], h->fE[l], B, sd[0], P,
+                           bf16 ? (unsigned short*)h->bX[l] : nullptr, bf16 ? (unsigned short*)h->bE[l] : nullptr);
         hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, Wl, h->fU[l], (int)cc, 48, wm);
       }
       const int pls = PL_F1WS + l - 1, ple = PL_F1FE + l - 1;
       const bool bf = h->mfma_bf16 && h->gch[l - 1] % 64 == 0;
       if (bf) {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-        RD_TRY(launch_to_bf16(h, hs[l - 1], h->bX[l], (long)B * sd[0] * P, st));
-        RD_TRY(launch_to_bf16(h, h->fE[l], h->bE[l], (long)B * (sd[0] + 1) * P, st));
         RD_TRY(launch_weights_to_bf16_t(h, h->fU[l], h->bU[l], 48, h->gch[l - 1], h->gch[l], st));
       }
       if (bf) RD_TRY(launch_conv16(h, h->plans[pls], h->d_plans + pls, B, h->bX[l], h->bU[l], h->fgS, epi_make(RD_EPI_PLAIN), st,
@@ -1502,8 +1503,9 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
     if (fast) {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
       const long HW = (long)h->gdim[l][1] * h->gdim[l][2];
+      const bool bf = h->mfma_bf16 != 0;       // the mixed mode's GEMMs read the bf16 copies written here
       RD_TRY(launch_pn_bwd_pairs(h, l == 3 ? h->gh3 : gups[l + 1], hs[l], rs[l], dys[l], h->fgS, (long)B * h->gdim[l - 1][0] * HW,
-                                 HW, h->gch[l], st));
+                                 HW, h->gch[l], bf ? h->bdy : nullptr, bf ? h->bgS : nullptr, st));
     } else {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
       if (l == 3) RD_TRY(launch_pn_bwd(h, h->gh3, hs[3], rs[3], dys[3], npix3, 64, 0, 0, 0, 0, st));
@@ -1521,18 +1523,14 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
       {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
         if (!gen_block_fast(h, l, h->fast_fwd)) {      // (otherwise the forward pass above has left both)
-          hipLaunchKernelGGL(k_diff_d, dim3(ew_blocks((long)B * (D + 1) * P / 4)), dim3(256), 0, st, hs[l - 1], h->fE[l], B, D, P);
+          hipLaunchKernelGGL(k_diff_d, dim3(ew_blocks((long)B * (D + 1) * P / 4)), dim3(256), 0, st, hs[l - 1], h->fE[l], B, D, P,
+                             (unsigned short*)nullptr, (unsigned short*)nullptr);
           hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, gp + h->goff[2 * l], h->fU[l],
                              (int)cc, 48, wm);
         }
       }
       const bool bf = h->mfma_bf16 && gen_block_fast(h, l, h->fast_fwd) && wgrad16_ok(h->plans[PL_F1WS + l - 1], B);
-      if (bf) {      // bf16 copies of the plane sums and of the output gradient (x and E copies are the forward's)
-        ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-        const long HWo = (long)h->gdim[l][1] * h->gdim[l][2] * h->gch[l];
-        RD_TRY(launch_to_bf16(h, h->fgS, h->bgS, (long)B * D * HWo, st));
-        RD_TRY(launch_to_bf16(h, dys[l], h->bdy, (long)B * 2 * D * HWo, st));
-      }
+      // (bf16 copies: plane sums and output gradient from k_pn_lrelu_bwd_pairs, x and E from the forward's k_diff_d)
       const float* wsrc[3] = {h->fE[l], hs[l - 1], h->fE[l]};
       const float* wdy[3] = {dys[l], h->fgS, dys[l]};
       const void* wsrc16[3] = {h->bE[l], h->bX[l], h->bE[l]};
@@ -1560,13 +1558,8 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
         // [N][K] layout of these GEMMs)
         RdSliceMap map;
         fastd_dgrad_slice_map(map.src);
-        const long HWo = (long)h->gdim[l][1] * h->gdim[l][2] * h->gch[l];
         {
           ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-          if (!bf) {
-            RD_TRY(launch_to_bf16(h, h->fgS, h->bgS, (long)B * D * HWo, st));
-            RD_TRY(launch_to_bf16(h, dys[l], h->bdy, (long)B * 2 * D * HWo, st));
-          }
           hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 48), dim3(256), 0, st,
                              h->fU[l], (unsigned short*)h->bUT, cc, map);
         }

@@ -17,6 +17,17 @@ __device__ __forceinline__ float rd_seg_sum(float v) {   // sum over aligned gro
   for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// two floats -> packed bf16 pair (round to nearest even; v_cvt_pk_bf16_f32), and a float4 -> 4 bf16 (8 bytes)
+typedef __bf16 rd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int rd_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rd_pack_bf16(float a, float b) {
+  rd_bf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ void rd_store_bf16x4(unsigned short* p, f32x4 v) {
+  rd_u32x2 o = {rd_pack_bf16(v.x, v.y), rd_pack_bf16(v.z, v.w)};
+  *(rd_u32x2*)p = o;
+}
 // block-wide sum, result valid in thread 0 (256 threads)
 __device__ __forceinline__ float rd_block_sum(float v, float* red) {
   v = rd_wave_sum(v);
@@ -117,9 +128,11 @@ __global__ void k_pn_lrelu_bwd(const float* __restrict__ g, const float* __restr
 // same (POOL = 0) over PAIRS of hour planes (2s, 2s+1) of a block output, additionally writing their sum
 // gS[b][s][h][w][:] = dy[b][2s][h][w][:] + dy[b][2s+1][h][w][:] for the shared-centre backward (k_presum_d fused in).
 // npair = B * Ds * HW pixel pairs, HW = pixels per hour plane.
+// dy16 / gS16 (optional): bf16 copies of both outputs for the mixed mode's GEMMs.
 template <int LP>
 __global__ void k_pn_lrelu_bwd_pairs(const float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ rinv,
-                                     float* __restrict__ dy, float* __restrict__ gS, long npair, long HW) {
+                                     float* __restrict__ dy, float* __restrict__ gS, long npair, long HW,
+                                     unsigned short* __restrict__ dy16, unsigned short* __restrict__ gS16) {
   constexpr int C = LP * 4;
   const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long pr = gid / LP;
@@ -139,6 +152,11 @@ __global__ void k_pn_lrelu_bwd_pairs(const float* __restrict__ g, const float* _
     *(f32x4*)(dy + pixA * C + sub * 4) = oa;
     *(f32x4*)(dy + pixB * C + sub * 4) = ob;
     *(f32x4*)(gS + pr * C + sub * 4) = oa + ob;
+    if (dy16) {
+      rd_store_bf16x4(dy16 + pixA * C + sub * 4, oa);
+      rd_store_bf16x4(dy16 + pixB * C + sub * 4, ob);
+      rd_store_bf16x4(gS16 + pr * C + sub * 4, oa + ob);
+    }
   }
 }
 
@@ -710,7 +728,9 @@ __global__ void k_weight_transform_adj(const float* __restrict__ dU, float* __re
   }
 }
 // E[b][j][:] = x[b][j][:] - x[b][j-1][:], j = 0..D, x zero outside [0,D); P = floats per d-plane (multiple of 4)
-__global__ void k_diff_d(const float* __restrict__ x, float* __restrict__ E, int B, int D, long P) {
+// x16 / E16 (optional): bf16 copies of the input (D planes per sample) and of E for the mixed mode's GEMMs.
+__global__ void k_diff_d(const float* __restrict__ x, float* __restrict__ E, int B, int D, long P,
+                         unsigned short* __restrict__ x16, unsigned short* __restrict__ E16) {
   const long p4 = P / 4, total = (long)B * (D + 1) * p4;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     const long i = f % p4; const long bj = f / p4;
@@ -720,6 +740,10 @@ __global__ void k_diff_d(const float* __restrict__ x, float* __restrict__ E, int
     if (j < D) hi = *(const f32x4*)(xb + (long)j * P);
     if (j > 0) lo = *(const f32x4*)(xb + (long)(j - 1) * P);
     *(f32x4*)(E + f * 4) = hi - lo;
+    if (E16) {
+      rd_store_bf16x4(E16 + f * 4, hi - lo);
+      if (j < D) rd_store_bf16x4(x16 + ((b * D + j) * P + i * 4), hi);
+    }
   }
 }
 // dx[b][d][:] += dE[b][d][:] - dE[b][d+1][:]   (adjoint of k_diff_d added to the shared-centre part already in dx)
@@ -738,11 +762,6 @@ __global__ void k_combine_dx(float* __restrict__ dx, const float* __restrict__ d
 // ------------------------------------------------------------------------------------
 // bf16 operand copies for the bf16-MFMA conv GEMM (fp32 -> bf16, round to nearest even; v_cvt_pk_bf16_f32)
 // ------------------------------------------------------------------------------------
-typedef __bf16 rd_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned rd_pack_bf16(float a, float b) {
-  rd_bf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;
-  return __builtin_bit_cast(unsigned, r);
-}
 // n % 8 == 0
 __global__ void k_to_bf16(const float* __restrict__ in, unsigned short* __restrict__ out, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n / 8; i += (long)gridDim.x * blockDim.x) {
