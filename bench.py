@@ -31,7 +31,7 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6     # dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cy
 def gconv3_flops(batch, nd=NDOMAIN, taps=4):
     """Algorithmic (executed) FLOPs of ONE launch of the dominant kernel: the difference-part GEMM of the generator's
     third UpSampling3D+Conv3D block (128 -> 64 channels onto the 24 x nd x nd grid) in the shared-centre form
-    (DESIGN.md 5b): 8 output-parity phases x 4 taps on the un-upsampled grid, 2 * B * (24*nd*nd) * 4*128 * 64
+    (DESIGN.md 4.2): 8 output-parity phases x 4 taps on the un-upsampled grid, 2 * B * (24*nd*nd) * 4*128 * 64
     = 402.7 MFLOP per sample at nd=16.  (The shared part T = S x of the same block is a separate, smaller launch.)"""
     return 2.0 * batch * 24 * nd * nd * taps * 128 * 64
 

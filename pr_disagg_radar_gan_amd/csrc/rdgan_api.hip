@@ -116,7 +116,7 @@ static RdPlan plan_conv_dgrad_s2(int D, int H, int W, int Cin, int Do, int Ho, i
   return p;
 }
 
-// UpSampling3D(2)+Conv3D 3^3 'same' collapsed onto the un-upsampled grid (DESIGN.md section 5):
+// UpSampling3D(2)+Conv3D 3^3 'same' collapsed onto the un-upsampled grid (DESIGN.md 4.1):
 // 8 output-parity phases x 8 taps; weights Wc[phase*8 + tap][Cin][Cout] from k_collapse_weights.
 static RdPlan plan_upconv_fwd_collapsed(int D, int H, int W, int Cin, int Cout) {
   RdPlan p; memset(&p, 0, sizeof(p));
@@ -162,7 +162,7 @@ static RdPlan plan_upconv_dgrad_collapsed(int D, int H, int W, int Cin, int Cout
   return p;
 }
 
-// ---- shared-centre form along d for the backward pass of a generator block (rdgan_elem.hip.h, DESIGN.md 5b).
+// ---- shared-centre form along d for the backward pass of a generator block (rdgan_elem.hip.h, DESIGN.md 4.2).
 // U block index: u = g*16 + (ph*2+th)*4 + (pw*2+tw), g = 0 (A': -W0 on E[s]), 1 (S: W0+W1+W2 on x[s]), 2 (D: W2 on E[s+1]).
 // On a collapsed axis (p,t) reads source offset p-1+t and sums the kernel taps {0},{1,2},{0,1},{2}.
 static void fastd_weight_map(RdWeightMap& T) {

@@ -597,7 +597,7 @@ __global__ void k_transpose(const float* __restrict__ in, float* __restrict__ ou
 }
 
 // ------------------------------------------------------------------------------------
-// Upsample collapse (exact algebra, DESIGN.md section 5): UpSampling3D(2) followed by a 3-tap 'same'
+// Upsample collapse (exact algebra, DESIGN.md 4.1): UpSampling3D(2) followed by a 3-tap 'same'
 // conv equals, per output parity p and per axis, a 2-tap conv on the un-upsampled grid with taps
 // p=0: (W0 | W1+W2) at offsets (-1, 0);  p=1: (W0+W1 | W2) at offsets (0, +1).
 // ------------------------------------------------------------------------------------
@@ -692,7 +692,7 @@ __global__ void k_unpad_w1(const float* __restrict__ wp, float* __restrict__ w, 
 }
 
 // ------------------------------------------------------------------------------------
-// Shared-centre form of UpSampling3D(2)+Conv3D(3^3,'same') along the hour axis d (backward pass).
+// Shared-centre form of UpSampling3D(2)+Conv3D(3^3,'same') along the hour axis d.
 // Per axis the two outputs of a source position are  out[2s] = W0 x[s-1] + (W1+W2) x[s],  out[2s+1] = (W0+W1) x[s] +
 // W2 x[s+1].  With E[j] = x[j] - x[j-1] (x zero-extended, j = 0..D) and S = W0+W1+W2 this is
 //   out[2s] = S x[s] - W0 E[s],   out[2s+1] = S x[s] + W2 E[s+1]:
