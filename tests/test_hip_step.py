@@ -340,3 +340,32 @@ def test_mfma_bf16_option(eng16):
         assert min(errs.values()) > 1e-5, errs
     finally:
         eng16.set_option("mfma_bf16", 0)
+
+
+def test_mfma_bf16_odd_batch_and_domain64():
+    """mixed mode at a batch that leaves partial tiles (B = 9, nd 16) and on the large domain (nd 64, B = 1): forward and
+    both gradient slabs stay within bf16 rounding of the fp32 path of the same engine."""
+    for nd, B in ((16, 9), (64, 1)):
+        eng = Engine(ndomain=nd, max_batch=B)
+        try:
+            g, d = _params(nd, 61)
+            x, cond, z = ot.synthetic_batch(B, nd, 29)
+            gs, ds = eng.to_slab(g), eng.to_slab(d)
+            ref_f = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+            ref_c = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 5).cpu().numpy()
+            ref_g = eng.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
+            eng.set_option("mfma_bf16", 1)
+            out_f = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+            out_c = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 5).cpu().numpy()
+            out_g = eng.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
+            assert 1e-5 < rel_err(out_f, ref_f) < 2e-2
+            for out, ref, n, shapes in ((out_c, ref_c, eng.n_critic, eng.critic_shapes), (out_g, ref_g, eng.n_gen, eng.gen_shapes)):
+                assert np.all(np.isfinite(out))
+                off = 0
+                for name, s in shapes:
+                    k = int(np.prod(s))
+                    if name != "conv3d_3/bias:0":
+                        assert rel_err(out[off:off + k], ref[off:off + k]) < 0.3, (nd, name)
+                    off += k
+        finally:
+            eng.close()
