@@ -99,6 +99,10 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * copies of their operands (weight forms stored [N][K]) and run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation;
  * every tensor the caller or another kernel sees, all gradients and the optimizer state stay fp32.  Results move by
  * bf16 rounding (2^-9 per operand), so it is NOT the mode the fp32 metric is measured in.
+ * "g9_direct" (default 1): backward of the last generator conv (64 -> 1) straight from the 1-channel dlogits with the
+ * neighbouring hour planes in LDS: weight gradient without the [rows][27] im2col matrix, input gradient fused with
+ * block 3's PixelNorm+LeakyReLU backward (no intermediate gradient tensor).  Needs 4 (nd+2)^2 floats of LDS (nd <= 72);
+ * 0 (and larger domains) = im2col + column GEMMs + separate PixelNorm backward.
  * "tapgather" (default 1): the last generator conv (64 -> 1, T:345) runs as a column GEMM over its 27 taps whose
  * epilogue already sums the taps that fall inside the 256-row tile (ndomain 8/16: whole planes, 32/64/128: whole
  * rows), writing 3 or 9 floats per grid point instead of 32; 0 (and every other ndomain) = full column matrix +

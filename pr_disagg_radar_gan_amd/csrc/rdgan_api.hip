@@ -376,6 +376,7 @@ struct rdgan_handle {
   void *bWF[5], *bWB[5];          // critic layers 2-4: bf16 kernels [27][Cout][Cin] (forward) and [27][Cin][Cout] (input gradient)
   void *bG1F, *bG1B;              // generator block 1: collapsed forms [64][Cout][Cin] and, re-ordered by tap, [64][Cin][Cout]
   int mfma_bf16 = 0;              // 1: shared-centre forward / input-gradient GEMMs of blocks 2, 3 on bf16 operands (fp32 accumulate, fp32 tensors everywhere else)
+  int g9_direct = 1;              // 1: backward of the 64 -> 1 conv straight from the dlogits (no im2col matrix), fused with block 3's PixelNorm backward
   int fast_fwd = 1;               // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products)
   int fast_bwd = 1;               // 1: generator blocks' weight/input gradients in the shared-centre form along d (48 instead of 64 tap products)
   float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
@@ -1097,6 +1098,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "collapse")) { h->collapse = value ? 1 : 0; return 0; }
   if (!strcmp(name, "wave_specialized")) { h->wave_spec = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }   // 2 = also for small problems (tests)
   if (!strcmp(name, "mfma_bf16")) { h->mfma_bf16 = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "g9_direct")) { h->g9_direct = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fast_fwd")) { h->fast_fwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
@@ -1470,15 +1472,37 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
     long ncol = (long)B * nd * nd;
     hipLaunchKernelGGL(k_softmax_bwd, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->fake, h->g0, h->dl, B,
                        RDGAN_NHOURS, nd, nd);
-    hipLaunchKernelGGL(k_dl_im2col, dim3(ew_blocks(npix3 * 8)), dim3(256), 0, st, h->dl, h->P9, B, RDGAN_NHOURS, nd, nd);
   }
-  // last conv (64 -> 1, T:345): weight grad [27][64], bias grad, input grad
-  RD_TRY(launch_wgrad(h, h->plans[PL_G9B], h->d_plans + PL_G9B, B, h->P9, h->h3, grad + h->goff[8], h->wpartial,
-                      h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
+  // last conv (64 -> 1, T:345): weight grad [27][64], bias grad, input grad.  Direct form (h->g9_direct): straight from the
+  // 1-channel dlogits with the four neighbouring hour planes in LDS -- no im2col matrix, and the input gradient goes
+  // through block 3's PixelNorm+LeakyReLU backward in the same kernel (below); needs the planes to fit in LDS.
+  const size_t g9_lds = 4 * (size_t)(nd + 2) * (nd + 2) * sizeof(float);
+  const bool g9_direct = h->g9_direct && g9_lds <= 96 * 1024 &&
+                         (size_t)B * (RDGAN_NHOURS / 2) * 1728 <= h->wpartial_cap;
+  if (g9_direct) {
+    ProfScope ps(h, RDGAN_TAG_GCONV_WGRAD, st);
+    const size_t lds = std::max<size_t>(g9_lds, 4 * 27 * 16 * sizeof(f32x4));
+    static bool attr_done = false;
+    if (!attr_done) {
+      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_wgrad_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_bwd_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_done = true;
+    }
+    const int nwg = B * (RDGAN_NHOURS / 2);
+    hipLaunchKernelGGL(k_g9_wgrad_pairs, dim3(nwg), dim3(256), lds, st, h->dl, h->h3, h->wpartial, RDGAN_NHOURS, nd, nd);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(256), 0, st, h->wpartial, nwg, 1728, grad + h->goff[8]);
+  } else {
+    {
+      ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+      hipLaunchKernelGGL(k_dl_im2col, dim3(ew_blocks(npix3 * 8)), dim3(256), 0, st, h->dl, h->P9, B, RDGAN_NHOURS, nd, nd);
+    }
+    RD_TRY(launch_wgrad(h, h->plans[PL_G9B], h->d_plans + PL_G9B, B, h->P9, h->h3, grad + h->goff[8], h->wpartial,
+                        h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
+    RD_TRY(launch_conv(h, h->plans[PL_G9B], h->d_plans + PL_G9B, B, h->P9, gp + h->goff[8], 64, h->gh3,
+                       epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
+  }
   RD_TRY(launch_colsum(h, h->dl, npix3 / 64, 64, h->ga0, st));   // 64 partial sums of dl (npix3 % 64 == 0)
   RD_TRY(launch_colsum(h, h->ga0, 64, 1, grad + h->goff[9], st));
-  RD_TRY(launch_conv(h, h->plans[PL_G9B], h->d_plans + PL_G9B, B, h->P9, gp + h->goff[8], 64, h->gh3,
-                     epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
   // three [upsample, conv, pixelnorm, lrelu] blocks, last to first
   float* hs[4] = {h->h0, h->h1, h->h2, h->h3};
   float* rs[4] = {nullptr, h->r1, h->r2, h->r3};
@@ -1500,7 +1524,15 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
   for (int l = 3; l >= 1; --l) {
     // shared-centre backward only where the hour axis is long enough to pay for its (D+1)/D boundary plane
     const bool fast = gen_block_fast(h, l, h->fast_bwd);
-    if (fast) {
+    if (l == 3 && g9_direct) {
+      // input gradient of the 64 -> 1 conv + block 3's PixelNorm+LeakyReLU backward (+ plane-pair sums, bf16 copies)
+      ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+      const bool bf = fast && h->mfma_bf16;
+      hipLaunchKernelGGL(k_g9_bwd_pairs, dim3(B * (RDGAN_NHOURS / 2)), dim3(256), g9_lds, st, h->dl, gp + h->goff[8], hs[3], rs[3],
+                         dys[3], fast ? h->fgS : (float*)nullptr, RDGAN_NHOURS, nd, nd,
+                         bf ? (unsigned short*)h->bdy : (unsigned short*)nullptr, bf ? (unsigned short*)h->bgS : (unsigned short*)nullptr);
+      RD_CHECK(h, hipGetLastError());
+    } else if (fast) {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
       const long HW = (long)h->gdim[l][1] * h->gdim[l][2];
       const bool bf = h->mfma_bf16 != 0;       // the mixed mode's GEMMs read the bf16 copies written here

@@ -160,6 +160,116 @@ __global__ void k_pn_lrelu_bwd_pairs(const float* __restrict__ g, const float* _
   }
 }
 
+// Backward of the last generator conv (64 -> 1, 3^3 'same', T:345) fused with the PixelNorm+LeakyReLU backward of block 3,
+// straight from the 1-channel dlogits dl (no im2col matrix, no intermediate gradient tensor):
+//   gh3[u][c] = sum_tap dl[u - off(tap)] * w9[tap][c];   dy = pn_lrelu_bwd(gh3, h3, rinv);   gS = dy[2s] + dy[2s+1]
+// One workgroup per (sample, hour-plane pair s); the four dl planes 2s-1 .. 2s+2 sit in LDS with a zero halo, a thread
+// owns one channel quad (its 27 x 4 kernel weights in registers) and walks the plane's pixels 16 at a time.
+// gS / dy16 / gS16 are optional (shared-centre backward, mixed mode).  H*W % 16 == 0.
+__global__ void __launch_bounds__(256)
+k_g9_bwd_pairs(const float* __restrict__ dl, const float* __restrict__ w9, const float* __restrict__ h3,
+               const float* __restrict__ rinv, float* __restrict__ dy, float* __restrict__ gS, int D, int H, int W,
+               unsigned short* __restrict__ dy16, unsigned short* __restrict__ gS16) {
+  extern __shared__ __attribute__((aligned(16))) float dls[];     // [4][H+2][W+2]
+  const int Ds = D / 2, PW = W + 2, PHW = (H + 2) * PW, HW = H * W;
+  const long b = blockIdx.x / Ds;
+  const int s = blockIdx.x % Ds;
+  for (int i = threadIdx.x; i < 4 * PHW; i += 256) {
+    const int pl = i / PHW, r = i - pl * PHW, hh = r / PW - 1, ww = r % PW - 1, d = 2 * s - 1 + pl;
+    float v = 0.f;
+    if ((unsigned)d < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) v = dl[((b * D + d) * H + hh) * W + ww];
+    dls[i] = v;
+  }
+  const int c4 = (threadIdx.x & 15) * 4;
+  f32x4 wq[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) wq[t] = *(const f32x4*)(w9 + t * 64 + c4);
+  __syncthreads();
+  for (int it = threadIdx.x >> 4; it < HW; it += 16) {
+    const int hh = it / W, ww = it - hh * W;
+    f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = ga;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int o = (hh + 2 - kh) * PW + (ww + 2 - kw);
+          const float da = dls[(2 - kd) * PHW + o], db = dls[(3 - kd) * PHW + o];
+          const f32x4 w = wq[(kd * 3 + kh) * 3 + kw];
+          ga += da * w; gb += db * w;
+        }
+    const long pixA = (b * D + 2 * s) * HW + it, pixB = pixA + HW, pr = (b * Ds + s) * HW + it;
+    const f32x4 ha = *(const f32x4*)(h3 + pixA * 64 + c4), hb = *(const f32x4*)(h3 + pixB * 64 + c4);
+    const f32x4 oa = rd_pn_lrelu_bwd_row<16>(ga, ha, rinv[pixA]);
+    const f32x4 ob = rd_pn_lrelu_bwd_row<16>(gb, hb, rinv[pixB]);
+    *(f32x4*)(dy + pixA * 64 + c4) = oa;
+    *(f32x4*)(dy + pixB * 64 + c4) = ob;
+    if (gS) *(f32x4*)(gS + pr * 64 + c4) = oa + ob;
+    if (dy16) {
+      rd_store_bf16x4(dy16 + pixA * 64 + c4, oa);
+      rd_store_bf16x4(dy16 + pixB * 64 + c4, ob);
+      rd_store_bf16x4(gS16 + pr * 64 + c4, oa + ob);
+    }
+  }
+}
+// Weight gradient of the same conv without the im2col matrix: dW9[tap][c] = sum_u dl[u - off(tap)] * h3[u][c].
+// Same decomposition; each thread accumulates its channel quad over its pixels, the 16 pixel slots of the workgroup are
+// folded by shuffles and LDS, and partial[blockIdx][27][64] is folded by k_reduce_partials (deterministic).
+__global__ void __launch_bounds__(256)
+k_g9_wgrad_pairs(const float* __restrict__ dl, const float* __restrict__ h3, float* __restrict__ partial, int D, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float dls[];     // [4][H+2][W+2], reused for the fold
+  const int Ds = D / 2, PW = W + 2, PHW = (H + 2) * PW, HW = H * W;
+  const long b = blockIdx.x / Ds;
+  const int s = blockIdx.x % Ds;
+  for (int i = threadIdx.x; i < 4 * PHW; i += 256) {
+    const int pl = i / PHW, r = i - pl * PHW, hh = r / PW - 1, ww = r % PW - 1, d = 2 * s - 1 + pl;
+    float v = 0.f;
+    if ((unsigned)d < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) v = dl[((b * D + d) * H + hh) * W + ww];
+    dls[i] = v;
+  }
+  const int c4 = (threadIdx.x & 15) * 4;
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int it = threadIdx.x >> 4; it < HW; it += 16) {
+    const int hh = it / W, ww = it - hh * W;
+    const long pixA = (b * D + 2 * s) * HW + it;
+    const f32x4 ha = *(const f32x4*)(h3 + pixA * 64 + c4), hb = *(const f32x4*)(h3 + (pixA + HW) * 64 + c4);
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int o = (hh + 2 - kh) * PW + (ww + 2 - kw);
+          acc[(kd * 3 + kh) * 3 + kw] += dls[(2 - kd) * PHW + o] * ha + dls[(3 - kd) * PHW + o] * hb;
+        }
+  }
+  // fold the 4 pixel slots of a wave (lanes l, l^16, l^32 share a channel quad), then the 4 waves through LDS
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[t][e];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      acc[t][e] = v;
+    }
+  __syncthreads();                                       // dl planes no longer needed
+  f32x4* red = (f32x4*)dls;                               // [4 waves][27][16 quads]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 16)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) red[(wave * 27 + t) * 16 + lane] = acc[t];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * 16; i += 256) {
+    f32x4 v = red[i] + red[27 * 16 + i] + red[2 * 27 * 16 + i] + red[3 * 27 * 16 + i];
+    *(f32x4*)(partial + (long)blockIdx.x * 1728 + (long)i * 4) = v;
+  }
+}
+
 // gradient wrt the Dense pre-activation (T:326-328): sum the 8 children of the first block's
 // upsampled-grid gradient and apply LeakyReLU' from the stored output h0.  C = 256.
 __global__ void k_pool_lrelu_bwd(const float* __restrict__ gup, const float* __restrict__ h0, float* __restrict__ out,

@@ -136,6 +136,7 @@ def test_gen_step_grads_parity(eng16, B, seed, collapse, ws, fast):
     eng16.set_option("wave_specialized", ws)
     eng16.set_option("fast_bwd", fast)          # shared-centre form of the blocks' weight / input gradients (48 vs 64 tap products)
     eng16.set_option("fast_fwd", (fast + B) % 2)   # every forward/backward combination occurs
+    eng16.set_option("g9_direct", (B + ws) % 2)    # last conv's backward: direct from the dlogits / im2col + column GEMMs
     g, d = _params(16, 14)
 
     def run_case(data_seed):
