@@ -161,3 +161,30 @@ def test_train_mirror_resume_is_bit_identical(tmp_path, monkeypatch, n_channel):
     finally:
         T.configure(n_disc=5, n_channel=1)
         T.use_arrays(data, idx)
+
+
+def test_train_mirror_in_mixed_bf16_mode(tmp_path, monkeypatch):
+    """T.train with the engine's "mfma_bf16" option (bf16 MFMA operands, fp32 state): a few iterations stay finite and
+    the losses track the fp32 run of the same batches to bf16 accuracy."""
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(3)
+    data = (rng.gamma(0.3, 2.0, (4, 24, 32, 32)).astype(np.float32) + 1e-3)
+    idx = [(t, y, x) for t in range(4) for y in (0, 16) for x in (0, 16)]
+    T.configure(ndomain=16, n_disc=1)
+    T.use_arrays(data, idx)
+    runs = {}
+    try:
+        for mode in (0, 1):
+            T.build_networks(seed=21)
+            T.hist["d_loss"].clear(); T.hist["g_loss"].clear()
+            models.get_engine(16, 8).set_option("mfma_bf16", mode)
+            np.random.seed(5)
+            T.train(1, 8, max_batches_per_epoch=3, save_models=False)
+            runs[mode] = (list(T.hist["d_loss"]), list(T.hist["g_loss"]))
+            assert np.all(np.isfinite(runs[mode][0])) and np.all(np.isfinite(runs[mode][1]))
+        np.testing.assert_allclose(runs[1][0], runs[0][0], rtol=0.1, atol=0.02)
+        np.testing.assert_allclose(runs[1][1], runs[0][1], rtol=0.1, atol=0.02)
+        assert runs[1] != runs[0]
+    finally:
+        models.get_engine(16, 8).set_option("mfma_bf16", 0)
+        T.configure(n_disc=5)
