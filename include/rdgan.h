@@ -117,7 +117,7 @@ enum {
   RDGAN_TAG_GCONV_WGRAD = 2,
   RDGAN_TAG_CRITIC_GEMM = 3,
   RDGAN_TAG_ELEMENTWISE = 4,
-  RDGAN_TAG_GCONV3_FWD = 5,  /* the single dominant launch: 128->64 block at 24x16x16 */
+  RDGAN_TAG_GCONV3_FWD = 5,  /* the single dominant launch: forward of the 128->64 block at 24x16x16 (its difference part in the shared-centre form) */
   RDGAN_NUM_TAGS = 8
 };
 int rdgan_profile(rdgan_handle* h, unsigned tag_mask);
