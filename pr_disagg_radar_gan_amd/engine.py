@@ -147,7 +147,8 @@ class Engine:
                                        float(grad_scale), self._stream()), self._h, "rdgan_adam")
 
     def set_option(self, name, value):
-        """"collapse": 1 (default) = 8-tap collapsed generator blocks, 0 = the reference's direct 27-tap form"""
+        """rdgan_set_option (include/rdgan.h): "collapse", "fast_fwd", "fast_bwd" (exact algebraic forms), "mfma_bf16" (mixed
+        mode), "wave_specialized", "ws_ksplit", "tapgather", "g9_direct" (kernel variants)."""
         _lib.check(self.lib.rdgan_set_option(self._h, name.encode(), int(value)), self._h, "rdgan_set_option")
 
     def profile(self, tag_mask):

@@ -370,3 +370,34 @@ def test_mfma_bf16_odd_batch_and_domain64():
                     off += k
         finally:
             eng.close()
+
+
+def test_error_paths(eng16):
+    """Argument errors come back as exceptions / -2 with a message, never as a launch: batch above max_batch, wrong shapes
+    and dtypes, unknown option; the C ABI reports them through rdgan_last_error."""
+    import ctypes
+    from pr_disagg_radar_gan_amd import _lib
+    g, d = _params(16, 71)
+    gs, ds = eng16.to_slab(g), eng16.to_slab(d)
+    x, cond, z = ot.synthetic_batch(9, 16, 1)                     # engine created with max_batch = 8
+    with pytest.raises(ValueError):
+        eng16.gen_forward(gs, dev(z), dev(cond))
+    x, cond, z = ot.synthetic_batch(2, 16, 1)
+    with pytest.raises(ValueError):
+        eng16.gen_forward(gs, dev(z[:, :50]), dev(cond))                   # latent width
+    with pytest.raises(ValueError):
+        eng16.gen_forward(gs, dev(z).double(), dev(cond))                   # dtype
+    with pytest.raises(ValueError):
+        eng16.critic_grad(ds, gs, dev(x)[:, :12], dev(cond), dev(z), 1)      # hours
+    with pytest.raises(_lib.RdganError) as ei:
+        eng16.set_option("no_such_option", 1)
+    assert "unknown option" in str(ei.value)
+    lib = _lib.load()
+    out = torch.empty((9, 24, 16, 16, 1), device="cuda")
+    z9 = torch.zeros((9, 100), device="cuda"); c9 = torch.zeros((9, 16, 16, 1), device="cuda")
+    rc = lib.rdgan_gen_forward(eng16._h, ctypes.c_void_p(gs.data_ptr()), ctypes.c_void_p(z9.data_ptr()),
+                               ctypes.c_void_p(c9.data_ptr()), ctypes.c_void_p(out.data_ptr()), 9, ctypes.c_void_p(0))
+    assert rc == -2 and b"max_batch" in lib.rdgan_last_error(eng16._h)
+    rc = lib.rdgan_gen_forward(eng16._h, ctypes.c_void_p(0), ctypes.c_void_p(z9.data_ptr()), ctypes.c_void_p(c9.data_ptr()),
+                               ctypes.c_void_p(out.data_ptr()), 2, ctypes.c_void_p(0))
+    assert rc == -2 and b"null" in lib.rdgan_last_error(eng16._h)
