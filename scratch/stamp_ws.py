@@ -8,6 +8,8 @@ import numpy as np, torch
 from pr_disagg_radar_gan_amd import Engine, weights as W
 from pr_disagg_radar_gan_amd.trainer import synthetic_batch_device
 eng = Engine(16, 256)
+for kv in sys.argv[2:]:
+    k, v = kv.split("="); eng.set_option(k, int(v))
 rng = np.random.default_rng(0)
 gs = eng.to_slab(W.init_generator(rng, 16))
 x, c, z = synthetic_batch_device(256, 16, 1, eng.device)
