@@ -194,8 +194,9 @@ def main():
                                    + (" (BASELINE configs[1])" if (ND, B, args.n_critic) == (16, 256, 1) else ""),
                        "global_batch": world * B, "n_critic": args.n_critic, "parallelism": f"dp{world}",
                        "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_ws<256,64,4,1>, generator block 3 forward, difference part (E x U over 8 parity "
-                                                    "phases x 4 taps + shared part T + bias + PixelNorm + LeakyReLU in the epilogue)",
+            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_ws<256, 64, 4, 1, 4, false, 1> (own symbol: this launch only), generator block 3 forward, "
+                                                    "difference part (E x U over 8 parity phases x 4 taps + shared part T + bias + "
+                                                    "PixelNorm + LeakyReLU in the epilogue)",
                          "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
                          "traffic": DOMINANT_TRAFFIC_BYTES if (ND, B, taps, bf16) == (16, 256, 4, False) else None,

@@ -28,7 +28,9 @@ __device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float*
 // the fp32 kernel, and B uses A's row image.  Plans need SC % 64 == 0.  Everything else (tile decode, row tables, tap
 // masks, epilogue) is shared.
 typedef __bf16 rd_bf16x8 __attribute__((ext_vector_type(8)));
-template <int BM, int BN, int WM, int WN, int TG, bool BF = false>
+// NAMETAG only gives a launch its own kernel symbol (the dominant launch, so that per-name profiler statistics
+// describe exactly that launch); it does not change the code.
+template <int BM, int BN, int WM, int WN, int TG, bool BF = false, int NAMETAG = 0>
 __global__ void __launch_bounds__(512, 4)
 k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
                const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {

@@ -77,6 +77,7 @@ struct RdEpi {
   int gw, ghw, gq;             // RD_EPI_TAPGATHER: plane width W, plane size H*W, sums per row (3 or 9)
   // shared-centre forward (second GEMM): before the mode's own work add T[b][plane >> 1][...] to the row, where
   // plane = (offset of the row inside its sample) / addt_plane is the output hour plane; T holds one plane per PAIR
+  int nametag;                 // 1: launch under the dominant launch's own kernel symbol (profiling only)
   const float* addt;
   int addt_plane;              // floats per output hour plane (2H * 2W * Cout)
 };
