@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """Benchmark of the cWGAN-GP training iteration on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
-A "step" is one training iteration of the reference's loop body
-(gan_train_cwgangp_pixelnorm.py:468-482) on synthetic 24x16x16 tiles: n_critic critic
-updates + 1 generator update, fp32, batch 256 per GPU (BASELINE.json configs[1]: "ndomain=16,
-24h, bs=256 fp32, 1 critic step + 1 gen step, single MI355X").  For N > 1 (one process per GPU,
-launched by torch.distributed.run) the minibatch dimension is sharded: every rank processes its
-own 256 samples and the gradient slabs are summed by RCCL (weak scaling).  Inputs are resident in
-HBM before the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one training iteration of the reference's loop body (gan_train_cwgangp_pixelnorm.py:468-482) on synthetic
+24 x nd x nd tiles: n_critic critic updates + 1 generator update.  Configurations (SURVEY 8d numbering = BASELINE.json
+configs[] index + 1):
+
+    --config 2 (default)  ndomain 16, bs 256 per GPU, fp32, 1 critic + 1 generator update      (the BASELINE metric; weak scaling)
+    --config 3            ndomain 16, bs 2048, bf16 storage, n_critic 5, one GPU               (GP double-backward stress)
+    --config 4            ndomain 16, GLOBAL bs 8192 sharded over the GPUs, bf16, n_critic 5   (strong scaling)
+    --config 5            ndomain 64, GLOBAL bs 512 sharded over the GPUs, bf16, n_critic 5    (large domain; strong scaling)
+
+For N > 1 there is one process per GPU.  Either the launcher creates them (`python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE come from the environment), or, when WORLD_SIZE
+is unset, this script starts N fresh child processes itself BEFORE it touches the GPU and relays rank 0's line.  The
+minibatch dimension is sharded; gradient slabs are summed by RCCL (torch.distributed backend "nccl"), one all-reduce per
+optimizer update, on a communication stream beside the next generator forward.  Inputs are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,14 +30,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-NDOMAIN = 16
-BATCH_PER_GPU = 256
-N_CRITIC = 1
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-BF16_MFMA_PEAK_TFLOPS = 2516.6     # dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles): 16x the fp32 rate; only with --opt mfma_bf16=1
+BF16_MFMA_PEAK_TFLOPS = 2516.6     # dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles): 16x the fp32 rate
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable with a float4 copy)
+
+CONFIGS = {
+    2: dict(nd=16, batch=256, n_critic=1, bf16=0, scaling="weak",
+            name="ndomain=16, 24h, bs=256 fp32, 1 critic step + 1 gen step (BASELINE configs[1])"),
+    3: dict(nd=16, batch=2048, n_critic=5, bf16=1, scaling="weak",
+            name="ndomain=16, 24h, bs=2048 bf16, n_critic=5 (BASELINE configs[2])"),
+    4: dict(nd=16, batch=8192, n_critic=5, bf16=1, scaling="strong",
+            name="ndomain=16, 24h, global bs=8192 bf16, n_critic=5, batch-sharded (BASELINE configs[3])"),
+    5: dict(nd=64, batch=512, n_critic=5, bf16=1, scaling="strong",
+            name="ndomain=64 (largedomain), 24h, global bs=512 bf16, n_critic=5, batch-sharded (BASELINE configs[4])"),
+}
 
 
-def gconv3_flops(batch, nd=NDOMAIN, taps=4):
+def gconv3_flops(batch, nd, taps=4):
     """Algorithmic (executed) FLOPs of ONE launch of the dominant kernel: the difference-part GEMM of the generator's
     third UpSampling3D+Conv3D block (128 -> 64 channels onto the 24 x nd x nd grid) in the shared-centre form
     (DESIGN.md 4.2): 8 output-parity phases x 4 taps on the un-upsampled grid, 2 * B * (24*nd*nd) * 4*128 * 64
@@ -36,78 +54,130 @@ def gconv3_flops(batch, nd=NDOMAIN, taps=4):
     return 2.0 * batch * 24 * nd * nd * taps * 128 * 64
 
 
-# HBM traffic of ONE launch of the dominant kernel at the default configuration, from separate rocprofv3 --pmc passes
+# HBM traffic of ONE launch of the dominant kernel at config 2, from separate rocprofv3 --pmc passes
 # (scripts/gpu_pmc_traffic.sh -> profiles/r01_e_pmc_hbm_traffic_gen_forward.json): FETCH_SIZE 241.6 MB x 2 (gfx950 counts
 # half the bytes of wide streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE 399.4 MB.  Algorithmic: E 109 MB + T 2 x 201 MB
 # read, 403 MB output + 6 MB 1/l2 written.  Not measurable inside this process, hence a recorded constant.
 DOMINANT_TRAFFIC_BYTES = 2 * 241.6e6 + 399.4e6
 
-# FLOPs of one iteration (n_critic critic steps + 1 generator step) per sample in the reference's direct
-# 27-tap form, nd = 16; used to price the measured iteration time as "direct-equivalent" TFLOP/s
-DIRECT_GF_PER_SAMPLE = {"critic_step": 5.41, "gen_step": 13.54}
+# FLOPs of one critic / generator step per sample in the reference's direct 27-tap form, by ndomain; prices
+# the measured iteration as "direct-equivalent" TFLOP/s
+DIRECT_GF_PER_SAMPLE = {16: {"critic_step": 5.41, "gen_step": 13.54}, 64: {"critic_step": 87.1, "gen_step": 217.9}}
 
 
-def cpu_baseline(iters=3, batch=32):
-    """The oracle's torch-CPU restatement of the same iteration (kind "port": the reference's own
-    runtime, TensorFlow 2.1, is not installed and no reference code travels to the GPU box),
-    timed on the host cores on a bounded sample."""
+def _host_cores():
+    # the GPU box gives one GPU's job a 16-core share; oversubscribing it (torch defaults to every visible core) makes the
+    # baseline 20x slower, so use at most 16 threads
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(16, avail))
+
+
+def cpu_baseline(nd=16, n_critic=1, batch=256, reps=3, small_batch=32):
+    """The oracle's torch-CPU restatement of the same arithmetic (kind "port": the reference's own runtime, TensorFlow
+    2.1, is not installed and no reference code travels to the GPU box), timed on the host cores on a bounded sample:
+    BASELINE configs[0] (generate_scenarios, 10 scenarios for one condition: generator forward only), and the training
+    iteration at the reference's default batch (32, T:70) and at the GPU line's batch.  Medians."""
+    import numpy as np
     import torch
     from oracle import rdgan_torch as ot
-    # the GPU box gives one GPU's job a 16-core share; oversubscribing it (torch defaults to every visible
-    # core) makes the baseline 20x slower, so use at most 16 threads
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(16, avail))
+    cores = _host_cores()
     torch.set_num_threads(cores)
-    tr = ot.Trainer(ndomain=NDOMAIN, seed=0)
-    batches = []
-    for i in range(N_CRITIC + 1):
-        x, c, z = ot.synthetic_batch(batch, NDOMAIN, 50 + i)
-        batches.append((torch.from_numpy(x), torch.from_numpy(c), torch.from_numpy(z)))
+    tr = ot.Trainer(ndomain=nd, seed=0)
 
-    def iteration(k):
-        for j in range(N_CRITIC):
-            x, c, z = batches[j]
-            tr.critic_step(x, c, z, seed=1000 + k * 7 + j)
-        x, c, z = batches[N_CRITIC]
-        tr.gen_step(z, c, seed=2000 + k)
+    def median_time(fn, n, warm=1):
+        for _ in range(warm):
+            fn(0)
+        ts = []
+        for k in range(n):
+            t0 = time.perf_counter()
+            fn(k + 1)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
 
-    iteration(0)                                   # warm-up
-    t0 = time.perf_counter()
-    for k in range(iters):
-        iteration(k + 1)
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * iters / dt, 3), "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"{iters} iterations (n_critic={N_CRITIC} critic + 1 generator update) at bs={batch}, "
-                      f"torch-CPU fp32 restatement of the reference arithmetic, after 1 warm-up iteration"}
+    # configs[0]: example.py -- cond = 10 mm/day everywhere, 10 scenarios
+    cond = torch.full((10, nd, nd, 1), 10.0 / 127.4)
+    z = torch.randn((10, 100))
+    with torch.no_grad():
+        t_fwd = median_time(lambda k: ot.generator_forward(tr.gp, z, cond), 5)
+
+    def iteration_at(bs):
+        batches = []
+        for i in range(n_critic + 1):
+            x, c, zz = ot.synthetic_batch(bs, nd, 50 + i)
+            batches.append((torch.from_numpy(x), torch.from_numpy(c), torch.from_numpy(zz)))
+
+        def it(k):
+            for j in range(n_critic):
+                x, c, zz = batches[j]
+                tr.critic_step(x, c, zz, seed=1000 + k * 7 + j)
+            x, c, zz = batches[n_critic]
+            tr.gen_step(zz, c, seed=2000 + k)
+        return it
+
+    t_small = median_time(iteration_at(small_batch), reps)
+    t_big = median_time(iteration_at(batch), reps) if batch != small_batch else t_small
+    return {"value": round(batch / t_big, 3), "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"median of {reps} iterations (n_critic={n_critic} critic + 1 generator update) at bs={batch} after 1 "
+                      f"warm-up, torch-CPU fp32 restatement of the reference arithmetic (oracle/rdgan_torch.py)",
+            "bs32_samples_per_s": round(small_batch / t_small, 3),
+            "config0_generate_scenarios_n10": {"value": round(10 / t_fwd, 2), "unit": "scenarios/s",
+                                               "sample": "generator forward, 10 scenarios of one 16x16 condition "
+                                                         "(example.py), median of 5 after 1 warm-up"}}
+
+
+def launch_children(args, argv):
+    """--gpus N without a launcher: N fresh processes, one per GPU, started before this process makes any GPU call (it
+    never does); rank 0's JSON line is relayed, the others' output goes to stderr."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="samples per GPU per iteration")
-    ap.add_argument("--n-critic", type=int, default=N_CRITIC)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="SURVEY 8d configuration number")
+    ap.add_argument("--batch", type=int, default=None, help="override: samples per GPU per iteration")
+    ap.add_argument("--n-critic", type=int, default=None)
+    ap.add_argument("--ndomain", type=int, default=None)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak: --batch per GPU; strong: the configuration's global batch divided over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ndomain", type=int, default=NDOMAIN, help="16 = BASELINE metric; 64 = large-domain variant (extra data point)")
+    ap.add_argument("--no-overlap", action="store_true", help="exchange + Adam on the compute stream (A/B)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="rdgan_set_option override for A/B runs (e.g. --opt fast_bwd=0); the default run sets none")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_children(args, sys.argv[1:]))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from pr_disagg_radar_gan_amd import Engine, weights as W, _lib
     from pr_disagg_radar_gan_amd.trainer import WGANGPTrainer, synthetic_batch_device
-    import numpy as np
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     if args.single_device:
@@ -115,6 +185,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -122,23 +193,41 @@ def main():
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                          # every rank really takes part in the collective
+        ranks_seen = int(ones.item())
 
-    B = args.batch
-    ND = args.ndomain
+    cfg = dict(CONFIGS[args.config])
+    ND = args.ndomain or cfg["nd"]
+    n_critic = args.n_critic or cfg["n_critic"]
+    scaling = args.scaling or cfg["scaling"]
+    if args.batch is not None:
+        B, scaling = args.batch, "weak"
+    elif scaling == "strong":
+        if cfg["batch"] % world:
+            raise SystemExit(f"global batch {cfg['batch']} is not divisible by {world} GPUs")
+        B = cfg["batch"] // world
+    else:
+        B = cfg["batch"]
+    opts = dict(kv.split("=") for kv in args.opt)
+    bf16 = int(opts.get("bf16_storage", opts.get("mfma_bf16", cfg["bf16"]))) != 0
+
     eng = Engine(ndomain=ND, max_batch=B, device=dev)
-    for kv in args.opt:
-        name, value = kv.split("=")
+    if cfg["bf16"] and "bf16_storage" not in opts and "mfma_bf16" not in opts:
+        eng.set_option("mfma_bf16", 1)
+    for name, value in opts.items():
         eng.set_option(name, int(value))
     rng = np.random.default_rng(0)                  # identical initial weights on every rank
-    trainer = WGANGPTrainer(eng, W.init_generator(rng, ND), W.init_critic(rng, ND), n_disc=args.n_critic,
-                            process_group=pg, world_size=world, rank=rank, base_seed=1234 + 1000 * 2)
+    trainer = WGANGPTrainer(eng, W.init_generator(rng, ND), W.init_critic(rng, ND), n_disc=n_critic,
+                            process_group=pg, world_size=world, rank=rank, base_seed=1234 + 1000 * args.config,
+                            overlap=False if args.no_overlap else None)
     # synthetic inputs resident in HBM; per-rank seeds 1234 + 1000*config + rank
-    nbuf = 4
+    nbuf = 4 if B * ND * ND <= 256 * 16 * 16 * 8 else 2
     data = []
+    base = 1234 + 1000 * args.config + rank
     for i in range(nbuf):
-        crit = [synthetic_batch_device(B, ND, 1234 + 2000 + rank + 97 * (i * (args.n_critic + 1) + j), dev)
-                for j in range(args.n_critic)]
-        _, c, z = synthetic_batch_device(B, ND, 1234 + 2000 + rank + 97 * (i * (args.n_critic + 1) + args.n_critic) + 13, dev)
+        crit = [synthetic_batch_device(B, ND, base + 97 * (i * (n_critic + 1) + j), dev) for j in range(n_critic)]
+        _, c, z = synthetic_batch_device(B, ND, base + 97 * (i * (n_critic + 1) + n_critic) + 13, dev)
         data.append((crit, (z, c)))
 
     def sync():
@@ -152,16 +241,22 @@ def main():
         trainer.iteration(crit, gen)
     sync()
     eng.profile(1 << _lib.TAG_GCONV3_FWD)            # HIP events around the dominant kernel, on the launch stream
+    eng.flop_count(reset=True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         crit, gen = data[k % nbuf]
+        ev[k][0].record()
         d_loss, g_loss, bad = trainer.iteration(crit, gen)
+        ev[k][1].record()
         flags.append(bad)
     sync()
     dt = time.perf_counter() - t0
+    flops_iter = eng.flop_count() / max(args.steps, 1)
     kern_ms, kern_n = eng.profile_read(_lib.TAG_GCONV3_FWD)
     eng.profile(0)
+    it_ms = np.array([a.elapsed_time(b) for a, b in ev]) if args.steps else np.zeros(1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -171,43 +266,82 @@ def main():
     if nonfinite != 0 or not (np.isfinite(d_loss) and np.isfinite(g_loss)):
         raise SystemExit(f"non-finite loss encountered (d_loss={d_loss}, g_loss={g_loss})")   # reference :487-488
 
+    # time per kernel class over a few extra iterations (HIP events around every launch of the class; outside the timed
+    # region because the extra events perturb it)
+    classes = None
+    if rank == 0:
+        names = {_lib.TAG_GCONV_FWD: "gen_conv_fwd", _lib.TAG_GCONV_DGRAD: "gen_conv_dgrad", _lib.TAG_GCONV_WGRAD: "gen_conv_wgrad",
+                 _lib.TAG_CRITIC_GEMM: "critic_gemm", _lib.TAG_ELEMENTWISE: "elementwise"}
+    sync()
+    nprof = 3
+    eng.profile(sum(1 << t for t in (_lib.TAG_GCONV_FWD, _lib.TAG_GCONV_DGRAD, _lib.TAG_GCONV_WGRAD, _lib.TAG_CRITIC_GEMM,
+                                     _lib.TAG_ELEMENTWISE)))
+    for k in range(nprof):
+        crit, gen = data[k % nbuf]
+        trainer.iteration(crit, gen)
+    sync()
+    if rank == 0:
+        classes = {}
+        for t, nm in names.items():
+            ms, n = eng.profile_read(t)
+            classes[nm] = {"ms_per_iteration": round(ms / nprof, 4), "launches_per_iteration": n // nprof}
+    eng.profile(0)
+
     if rank == 0:
         value = world * B * args.steps / dt
         avg_ms = kern_ms / max(kern_n, 1)
-        opts = dict(kv.split("=") for kv in args.opt)     # A/B runs: the tagged launch is the whole block in the other forms
         taps = 27 if opts.get("collapse") == "0" else (8 if opts.get("fast_fwd") == "0" else 4)
-        bf16 = opts.get("mfma_bf16") == "1" and taps == 4     # mixed mode
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         achieved = gconv3_flops(B, ND, taps) / (avg_ms * 1e-3) / 1e12 if kern_n else None
+        med = float(np.median(it_ms))
         direct_equiv = None
-        if ND == 16:
-            gf = args.n_critic * DIRECT_GF_PER_SAMPLE["critic_step"] + DIRECT_GF_PER_SAMPLE["gen_step"]
-            direct_equiv = gf * 1e9 * B * args.steps / dt / 1e12          # per GPU
+        if ND in DIRECT_GF_PER_SAMPLE:
+            gf = n_critic * DIRECT_GF_PER_SAMPLE[ND]["critic_step"] + DIRECT_GF_PER_SAMPLE[ND]["gen_step"]
+            direct_equiv = gf * 1e9 * B / (med * 1e-3) / 1e12          # per GPU
+        it_tflops = flops_iter / (med * 1e-3) / 1e12
+        is_metric = (args.config, ND, B, n_critic, bf16) == (2, 16, 256, 1, False)
+        dtype = ("bf16 activations / gradients in HBM and bf16 MFMA operands, f32 accumulation, f32 master weights, "
+                 "PixelNorm / softmax / penalty / Adam in f32") if bf16 else "f32"
         out = {
-            "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256" if (ND, B) == (16, 256)
-                      else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles, bs={B} (extra data point)",
+            "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256" if is_metric
+                      else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles, bs={B} per GPU (config {args.config})",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16 MFMA operands in every heavy GEMM, f32 accumulation / tensors / optimizer (mixed mode)" if bf16 else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"ndomain={ND}, 24h, bs={B} fp32 per GPU, {args.n_critic} critic step + 1 gen step"
-                                   + (" (BASELINE configs[1])" if (ND, B, args.n_critic) == (16, 256, 1) else ""),
-                       "global_batch": world * B, "n_critic": args.n_critic, "parallelism": f"dp{world}",
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": cfg["name"] if (ND, n_critic) == (cfg["nd"], cfg["n_critic"]) and args.batch is None
+                                   else f"ndomain={ND}, 24h, bs={B} per GPU, n_critic={n_critic}",
+                       "batch_per_gpu": B, "global_batch": world * B, "n_critic": n_critic, "parallelism": f"dp{world}",
+                       "world": world, "rccl_ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
+                       "exchange": None if world == 1 else ("one all-reduce of the flat gradient slab per optimizer update"
+                                                            + (", on a side stream beside the next generator forward"
+                                                               if trainer.overlap else ", on the compute stream")),
                        "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm_ws<256, 64, 4, 1, 4, false, 1> (own symbol: this launch only), generator block 3 forward, "
+            "iteration_ms": {"median": round(med, 4), "p10": round(float(np.percentile(it_ms, 10)), 4),
+                             "p90": round(float(np.percentile(it_ms, 90)), 4), "n": int(args.steps),
+                             "clock": "HIP events on the compute stream around each iteration"},
+            "roofline": {"bound": "mfma", "kernel": ("k_conv_gemm_ws<256, 64, 4, 1, 4, %s, 1>" % ("true" if bf16 else "false"))
+                                                    + " (own symbol: this launch only), generator block 3 forward, "
                                                     "difference part (E x U over 8 parity phases x 4 taps + shared part T + bias + "
                                                     "PixelNorm + LeakyReLU in the epilogue)",
                          "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
-                         "traffic": DOMINANT_TRAFFIC_BYTES if (ND, B, taps, bf16) == (16, 256, 4, False) else None,
+                         "traffic": DOMINANT_TRAFFIC_BYTES if is_metric and taps == 4 else None,
                          "traffic_source": "profiles/r01_e_pmc_hbm_traffic_gen_forward.json (separate --pmc passes, bytes per launch)",
                          "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": gconv3_flops(B, ND, taps),
-                         "iteration_direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2)},
+                         "iteration": {"executed_gflop": round(flops_iter / 1e9, 2), "tflops": round(it_tflops, 2),
+                                       "frac": round(it_tflops / peak, 4),
+                                       "note": "algorithmic FLOPs of every GEMM of one iteration in the forms actually run "
+                                               "(rdgan_flop_count) / median iteration time / the same MFMA peak; includes all "
+                                               "elementwise kernels' time"},
+                         "iteration_direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2),
+                         "kernel_classes": classes},
             "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},
         }
         if world == 1 and not args.no_cpu_baseline and ND == 16:
-            out["cpu_baseline"] = cpu_baseline()
+            # bounded sample: the default configuration's iteration at the GPU line's batch (~6 s per CPU iteration);
+            # n_critic = 5 configurations at bs 64 so that the default run still ends within minutes
+            out["cpu_baseline"] = cpu_baseline(ND, n_critic, batch=256 if n_critic == 1 else 64)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -45,6 +45,12 @@ long rdgan_workspace_bytes(const rdgan_handle* h);
 int rdgan_gen_forward(rdgan_handle* h, const float* gen_params, const float* z, const float* cond,
                       float* out, int B, void* stream);
 
+/* tf.debugging.check_numerics(..., 'generator has nans or infs') behind the generator's softmax (T:349-350): waits for
+ * `stream`, then returns -1 (and sets rdgan_last_error) if the generator output of the calls issued since the last
+ * rdgan_gen_forward / rdgan_critic_grad / rdgan_gen_grad began contained NaN or Inf, else 0.  The gradient entries also
+ * fold the same flag into slot 4 (nonfinite_flag) of their loss tail, so a training loop needs no extra sync (T:487-488). */
+int rdgan_check_numerics(rdgan_handle* h, void* stream);
+
 /* critic.predict([sample, cond]) (graph T:272-309).  seed == 0: dropout off (inference);
  * seed != 0: dropout masks of a train_on_batch pass (streams D1..D4 of rdgan_rng.h). out [B,1]. */
 int rdgan_critic_forward(rdgan_handle* h, const float* critic_params, const float* sample,
@@ -60,12 +66,26 @@ int rdgan_critic_grad(rdgan_handle* h, const float* critic_params, const float* 
                       const float* x_real, const float* cond, const float* z, uint64_t seed,
                       float* grad_out, int B, void* stream);
 
+/* The same, for callers that update the critic on another stream (data-parallel training: gradient all-reduce + Adam
+ * on a communication stream).  The frozen generator's forward reads no critic weight, so it is issued first; `stream`
+ * then waits for `critic_ready_event` (a hipEvent_t the caller recorded behind its last write of critic_params; NULL =
+ * no wait) before the first kernel that reads critic_params.  The previous update thus overlaps the generator forward. */
+int rdgan_critic_grad_after(rdgan_handle* h, const float* critic_params, const float* gen_params,
+                            const float* x_real, const float* cond, const float* z, uint64_t seed,
+                            float* grad_out, int B, void* critic_ready_event, void* stream);
+
 /* Gradient half of generator_model.train_on_batch([latent, cond], valid) (T:482; graph T:395-408):
  * loss = mean(-D(G(z,c))), critic frozen, its dropout active.
  * grad_out[0:n_gen_params], grad_out[n .. n+8) = {loss, 0, 0, 0, nonfinite_flag, 0, 0, 0}. */
 int rdgan_gen_grad(rdgan_handle* h, const float* critic_params, const float* gen_params,
                    const float* z, const float* cond, uint64_t seed, float* grad_out, int B,
                    void* stream);
+
+/* rdgan_gen_grad with the same late wait for the critic weights (see rdgan_critic_grad_after): the generator forward
+ * runs in front of it. */
+int rdgan_gen_grad_after(rdgan_handle* h, const float* critic_params, const float* gen_params,
+                         const float* z, const float* cond, uint64_t seed, float* grad_out, int B,
+                         void* critic_ready_event, void* stream);
 
 /* tf.optimizers.Adam(lr, beta_1=0, beta_2) apply step (T:385): v = b2 v + (1-b2) g^2,
  * p -= lr*sqrt(1-b2^t) * g / (sqrt(v)+eps), g = grad*grad_scale (1/world after the all-reduce sum).
@@ -103,6 +123,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * neighbouring hour planes in LDS: weight gradient without the [rows][27] im2col matrix, input gradient fused with
  * block 3's PixelNorm+LeakyReLU backward (no intermediate gradient tensor).  Needs 4 (nd+2)^2 floats of LDS (nd <= 72);
  * 0 (and larger domains) = im2col + column GEMMs + separate PixelNorm backward.
+ * "sample_offset" (default 0): global index of this rank's first sample.  RandomWeightedAverage's alpha (T:222-223) of
+ * local sample k is uniform(key(seed, ALPHA), sample_offset + k), so ranks that share a seed draw the alphas of the
+ * global batch (used by the data-parallel equivalence tests; the dropout masks stay keyed by the local element index).
  * "tapgather" (default 1): the last generator conv (64 -> 1, T:345) runs as a column GEMM over its 27 taps whose
  * epilogue already sums the taps that fall inside the 256-row tile (ndomain 8/16: whole planes, 32/64/128: whole
  * rows), writing 3 or 9 floats per grid point instead of 32; 0 (and every other ndomain) = full column matrix +
@@ -121,6 +144,9 @@ enum {
   RDGAN_NUM_TAGS = 8
 };
 int rdgan_profile(rdgan_handle* h, unsigned tag_mask);
+/* Algorithmic FLOPs (2 * rows * taps * K * N, of the algebraic forms actually run: collapsed / shared-centre) of every GEMM
+ * this handle has launched since the last reset -- the numerator of bench.py's whole-iteration roofline fraction. */
+int rdgan_flop_count(rdgan_handle* h, double* flops, int reset);
 int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, long* launches);
 
 /* Input pipeline either side of the step (device-resident radar array data[n_days][24][ny][nx], fp32).

@@ -99,12 +99,13 @@ def critic_masks(seed, batch, ndomain, dtype=torch.float32):
     return out
 
 
-def critic_step_grads(dp, gp, x_real, cond, z, seed):
+def critic_step_grads(dp, gp, x_real, cond, z, seed, alpha_offset=0):
     """One critic ``train_on_batch`` graph (T:363-392,472) up to the gradients.
 
     The three critic passes of the reference (T:372,373,379) are evaluated as ONE batch
     [real; fake; interpolated] of 3B samples so that dropout-mask element indices match the
-    HIP path; alpha comes from stream ALPHA.  Returns (losses[4] = total, valid, fake, gp
+    HIP path; alpha of sample k comes from stream ALPHA at index alpha_offset + k (alpha_offset = the global index of
+    this shard's first sample, the HIP option "sample_offset").  Returns (losses[4] = total, valid, fake, gp
     as Keras reports them, grads list in critic weight order)."""
     B = x_real.shape[0]
     nd = cond.shape[1]
@@ -112,7 +113,7 @@ def critic_step_grads(dp, gp, x_real, cond, z, seed):
     dp = [t.detach().clone().requires_grad_(True) for t in dp]
     with torch.no_grad():
         fake = generator_forward(gp, z, cond)                        # generator frozen, T:363
-    alpha = torch.from_numpy(orng.uniform(seed, orng.STREAM_ALPHA, B)).to(dt).reshape(B, 1, 1, 1, 1)
+    alpha = torch.from_numpy(orng.uniform(seed, orng.STREAM_ALPHA, B, start=alpha_offset)).to(dt).reshape(B, 1, 1, 1, 1)
     xhat = (alpha * x_real + (1 - alpha) * fake).detach().requires_grad_(True)   # T:221-224
     masks = critic_masks(seed, 3 * B, nd, dt)
     v = critic_forward(dp, torch.cat([x_real, fake, xhat], 0), torch.cat([cond, cond, cond], 0), masks)

@@ -21,18 +21,24 @@ SIGNATURES = {
     "rdgan_critic_param_count": (ctypes.c_long, [ctypes.c_void_p]),
     "rdgan_workspace_bytes": (ctypes.c_long, [ctypes.c_void_p]),
     "rdgan_gen_forward": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int, c_stream]),
+    "rdgan_check_numerics": (ctypes.c_int, [ctypes.c_void_p, c_stream]),
     "rdgan_critic_forward": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int,
                                             ctypes.c_uint64, c_stream]),
     "rdgan_critic_grad": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_uint64,
                                          c_f32p, ctypes.c_int, c_stream]),
     "rdgan_gen_grad": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_uint64, c_f32p,
                                       ctypes.c_int, c_stream]),
+    "rdgan_critic_grad_after": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_uint64,
+                                               c_f32p, ctypes.c_int, ctypes.c_void_p, c_stream]),
+    "rdgan_gen_grad_after": (ctypes.c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_uint64, c_f32p,
+                                            ctypes.c_int, ctypes.c_void_p, c_stream]),
     "rdgan_adam": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_float, c_stream]),
     "rdgan_gen_param_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "rdgan_critic_param_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "rdgan_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),
     "rdgan_profile": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
+    "rdgan_flop_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "rdgan_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_long)]),
     "rdgan_data_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
@@ -58,6 +64,10 @@ _lib = None
 
 class RdganError(RuntimeError):
     pass
+
+
+class NumericsError(RdganError, ArithmeticError):
+    """tf.debugging.check_numerics behind the generator's softmax (reference T:349-350) fired: NaN/Inf in the output."""
 
 
 def load():

@@ -384,8 +384,10 @@ struct rdgan_handle {
   int tapgather = 1;              // 1: last generator conv sums its in-tile taps in the GEMM epilogue; 0: full column matrix + gather kernel
   int ws_ksplit = 1;              // 1: split K of mid-size producer/consumer launches to fill whole rounds of workgroups; 0: off; >1: force (tests)
   int wave_spec = 1;              // 1: producer/consumer (wave-specialised, LDS-DMA) kernel for the big clean GEMMs
+  int sample_offset = 0;          // global index of this rank's first sample: RandomWeightedAverage's alpha of sample k is uniform(key, sample_offset + k)
   int* d_flag;
   // profiling
+  double flops_acc = 0;           // algorithmic FLOPs (2 * rows * taps * K * N of the forms actually run) of every GEMM launched so far
   unsigned prof_mask = 0;
   std::vector<hipEvent_t> ev_start[RDGAN_NUM_TAGS], ev_stop[RDGAN_NUM_TAGS];
   size_t ev_used[RDGAN_NUM_TAGS] = {0};
@@ -428,6 +430,13 @@ struct ProfScope {
 // ------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------
+// algorithmic FLOPs of one pass over a plan: 2 * sum over phases of (rows * taps) * K per tap * N
+static double plan_flops(const RdPlan& p, int B) {
+  double rt = 0;
+  for (int i = 0; i < p.nphases; ++i) rt += (double)B * p.ph[i].L * p.ph[i].ntaps;
+  return 2.0 * rt * p.SC * p.N;
+}
+
 static long plan_tiles(const RdPlan& p, int B, int BM) {
   long t = 0;
   for (int i = 0; i < p.nphases; ++i) t += ((long)B * p.ph[i].L + BM - 1) / BM;
@@ -552,6 +561,7 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
 static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* W,
                        int ldw, float* dst, const RdEpi& epi, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
+  if (h) h->flops_acc += plan_flops(hp, B);
   const bool partial = (hp.SC & 3) != 0, shift = hp.s_shift != 0;
   if (partial && shift) return bad_arg(h, "conv: SC % 4 != 0 with a folded upsample is not supported");
   if (hp.SC < 32 && hp.SC != 27) {   // small-K taps (D1): BK = 8
@@ -611,6 +621,7 @@ static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>(
 static int launch_conv16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* w16,
                          float* dst, const RdEpi& epi, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
+  if (h) h->flops_acc += plan_flops(hp, B);
   if (hp.s_shift || hp.SC % 64 || hp.N % 64) return bad_arg(h, "conv16: needs SC % 64 == 0, N % 64 == 0, no folded upsample");
   const float* s = (const float*)src16; const float* w = (const float*)w16;
   if (hp.N % 128 == 0) return launch_conv_ws_cfg<128, 128, 2, 2, true>(h, hp, dp, B, s, w, 0, dst, epi, st);
@@ -710,6 +721,7 @@ static int launch_wgrad_ws_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, i
 static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* dy,
                         float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
+  if (h) h->flops_acc += plan_flops(hp, B);
   if (hp.N % 64) return bad_arg(h, "wgrad: N % 64 != 0");
   for (int i = 1; i < hp.nphases; ++i)
     if (hp.ph[i].ntaps != hp.ph[0].ntaps || hp.ph[i].L != hp.ph[0].L) return bad_arg(h, "wgrad: phases must be congruent");
@@ -779,6 +791,7 @@ static bool wgrad16_ok(const RdPlan& hp, int B) {
 static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* dy16,
                           float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
+  if (h) h->flops_acc += plan_flops(hp, B);
   if (!wgrad16_ok(hp, B)) return bad_arg(h, "wgrad16: needs SC % 64 == 0, N % 64 == 0, a 128- or 256-row tile, no folded upsample");
   for (int i = 1; i < hp.nphases; ++i)
     if (hp.ph[i].ntaps != hp.ph[0].ntaps || hp.ph[i].L != hp.ph[0].L) return bad_arg(h, "wgrad: phases must be congruent");
@@ -1112,6 +1125,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "fast_fwd")) { h->fast_fwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "sample_offset")) { if (value < 0) return bad_arg(h, "set_option: sample_offset < 0"); h->sample_offset = value; return 0; }
   if (!strcmp(name, "ws_ksplit")) { h->ws_ksplit = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }   // > 1 = force (tests)
   return bad_arg(h, "set_option: unknown option");
 }
@@ -1129,6 +1143,12 @@ extern "C" int rdgan_profile(rdgan_handle* h, unsigned tag_mask) {
       }
     }
   }
+  return 0;
+}
+extern "C" int rdgan_flop_count(rdgan_handle* h, double* flops, int reset) {
+  if (!h) return -2;
+  if (flops) *flops = h->flops_acc;
+  if (reset) h->flops_acc = 0;
   return 0;
 }
 extern "C" int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, long* launches) {
@@ -1268,7 +1288,20 @@ extern "C" int rdgan_gen_forward(rdgan_handle* h, const float* gen_params, const
                                  float* out, int B, void* stream) {
   if (!h || !gen_params || !z || !cond || !out) return bad_arg(h, "gen_forward: null pointer");
   if (B < 1 || B > h->MB) return bad_arg(h, "gen_forward: B outside [1, max_batch]");
+  RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), (hipStream_t)stream));
   return gen_forward_impl(h, gen_params, z, cond, out, B, (hipStream_t)stream);
+}
+
+// tf.debugging.check_numerics behind the generator's softmax (T:349-350): the softmax kernels raise a device flag on
+// NaN/Inf; this waits for `stream` and reports the flag of the calls issued since the last reset (every public
+// generator-forward / gradient entry resets it first).
+extern "C" int rdgan_check_numerics(rdgan_handle* h, void* stream) {
+  if (!h) return -2;
+  RD_CHECK(h, hipStreamSynchronize((hipStream_t)stream));
+  int flag = 0;
+  RD_CHECK(h, hipMemcpy(&flag, h->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) { h->err = "check_numerics: the generator output contains NaN or Inf"; return -1; }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1378,7 +1411,7 @@ extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params,
   else if (h->CP != h->Cin)
     hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, critic_params + h->doff[0], h->W1P, h->Cin, h->CP);
   hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, sample,
-                     (const float*)nullptr, cond, h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 2, 0u);
+                     (const float*)nullptr, cond, h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 2, 0u, 0u);
   RD_TRY(critic_forward_impl(h, critic_params, B, seed, st));
   RD_CHECK(h, hipMemcpyAsync(out, h->v, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
   return 0;
@@ -1386,20 +1419,29 @@ extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params,
 
 extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* gp, const float* x_real,
                                  const float* cond, const float* z, uint64_t seed, float* grad, int B, void* stream) {
+  return rdgan_critic_grad_after(h, dp, gp, x_real, cond, z, seed, grad, B, nullptr, stream);
+}
+
+extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const float* gp, const float* x_real,
+                                       const float* cond, const float* z, uint64_t seed, float* grad, int B,
+                                       void* critic_ready_event, void* stream) {
   if (!h || !dp || !gp || !x_real || !cond || !z || !grad) return bad_arg(h, "critic_grad: null pointer");
   if (B < 1 || B > h->MB) return bad_arg(h, "critic_grad: B outside [1, max_batch]");
   hipStream_t st = (hipStream_t)stream;
   const int NBt = 3 * B;
   const int use_drop = seed != 0;
   RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
-  RD_TRY(prep_critic_weights(h, dp, st));
-  // fake = G(z, cond), generator frozen (T:363,370)
+  // fake = G(z, cond), generator frozen (T:363,370): reads no critic weight, so it is issued in front of the wait for
+  // them -- the previous critic update's all-reduce + Adam (on the caller's other stream) hide behind it
   RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st));
+  if (critic_ready_event) RD_CHECK(h, hipStreamWaitEvent(st, (hipEvent_t)critic_ready_event, 0));
+  RD_TRY(prep_critic_weights(h, dp, st));
   // [real; fake; alpha*real + (1-alpha)*fake] with the condition as 2nd channel (T:275-282, T:376)
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, x_real, h->fake, cond,
-                       h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 0, rd_make_key(seed, RD_STREAM_ALPHA));
+                       h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 0, rd_make_key(seed, RD_STREAM_ALPHA),
+                       (uint32_t)h->sample_offset);
   }
   RD_TRY(critic_forward_impl(h, dp, NBt, seed, st));           // T:372,373,379 as one batch
   RD_TRY(critic_dgrad_chain(h, dp, NBt, B, 0, seed, st));       // dL/dh for real|fake, dD/dh for x_hat
@@ -1448,7 +1490,7 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
                        h->F, B);
     RD_CHECK(h, hipMemsetAsync(grad + h->doff[9], 0, sizeof(float), st));   // sum of dv over real|fake = 0
     RD_CHECK(h, hipMemsetAsync(grad + h->n_critic, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));
-    hipLaunchKernelGGL(k_critic_losses, dim3(1), dim3(256), 0, st, h->v, h->gpv, grad + h->n_critic, B, RD_GP_WEIGHT);
+    hipLaunchKernelGGL(k_critic_losses, dim3(1), dim3(256), 0, st, h->v, h->gpv, grad + h->n_critic, B, RD_GP_WEIGHT, h->d_flag);
   }
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -1459,20 +1501,28 @@ extern "C" int rdgan_critic_grad(rdgan_handle* h, const float* dp, const float* 
 // ------------------------------------------------------------------------------------
 extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp, const float* z, const float* cond,
                               uint64_t seed, float* grad, int B, void* stream) {
+  return rdgan_gen_grad_after(h, dp, gp, z, cond, seed, grad, B, nullptr, stream);
+}
+
+extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const float* gp, const float* z, const float* cond,
+                                    uint64_t seed, float* grad, int B, void* critic_ready_event, void* stream) {
   if (!h || !dp || !gp || !z || !cond || !grad) return bad_arg(h, "gen_grad: null pointer");
   if (B < 1 || B > h->MB) return bad_arg(h, "gen_grad: B outside [1, max_batch]");
   hipStream_t st = (hipStream_t)stream;
   const int nd = h->nd;
   RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
-  RD_TRY(prep_critic_weights(h, dp, st));
   if (!h->collapse)
     for (int l = 1; l <= 3; ++l)
       RD_TRY(launch_transpose(h, gp + h->goff[2 * l], h->GWT[l], 27, h->gch[l - 1], h->gch[l], h->gch[l - 1], st));
+  // the generator forward reads no critic weight: the last critic update (all-reduce + Adam on the caller's other
+  // stream) hides behind it; everything below the wait reads them
   RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st));
+  if (critic_ready_event) RD_CHECK(h, hipStreamWaitEvent(st, (hipEvent_t)critic_ready_event, 0));
+  RD_TRY(prep_critic_weights(h, dp, st));
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, (const float*)nullptr,
-                       h->fake, cond, h->cin, B, h->ddim[0][0], nd * nd, h->nc, h->CP, 1, 0u);
+                       h->fake, cond, h->cin, B, h->ddim[0][0], nd * nd, h->nc, h->CP, 1, 0u, 0u);
   }
   RD_TRY(critic_forward_impl(h, dp, B, seed, st));              // critic frozen, dropout active (T:395,405)
   RD_TRY(critic_dgrad_chain(h, dp, B, B, 1, seed, st));
@@ -1666,7 +1716,7 @@ extern "C" int rdgan_gen_grad(rdgan_handle* h, const float* dp, const float* gp,
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     RD_CHECK(h, hipMemsetAsync(grad + h->n_gen, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));
-    hipLaunchKernelGGL(k_gen_loss, dim3(1), dim3(256), 0, st, h->v, grad + h->n_gen, B);
+    hipLaunchKernelGGL(k_gen_loss, dim3(1), dim3(256), 0, st, h->v, grad + h->n_gen, B, h->d_flag);
   }
   RD_CHECK(h, hipGetLastError());
   return 0;

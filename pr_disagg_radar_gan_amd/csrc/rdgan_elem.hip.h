@@ -436,11 +436,12 @@ __global__ void k_dl_im2col(const float* __restrict__ dl, float* __restrict__ co
 
 // D0 + X1 (T:275-282, T:221-224): critic input with CP floats per voxel = (sample | nc condition channels repeated
 // over the 24 hours | zero padding): CP = 2 for nc = 1, CP = 4 for nc = 2 or 3 (revision1/additional_inputs variants).
-// mode 0: out[0:B] = real, out[B:2B] = fake, out[2B:3B] = alpha*real + (1-alpha)*fake, alpha = uniform(key, b)
+// mode 0: out[0:B] = real, out[B:2B] = fake, out[2B:3B] = alpha*real + (1-alpha)*fake, alpha = uniform(key, alpha_base + b)
+// (alpha_base = global index of this rank's first sample, option "sample_offset")
 // mode 1: out[0:B] = fake only (generator step);  mode 2: out[0:B] = real only (critic.predict).
 __global__ void k_build_critic_input(const float* __restrict__ real, const float* __restrict__ fake,
                                      const float* __restrict__ cond, float* __restrict__ out, int B, int D, int HW,
-                                     int nc, int CP, int mode, uint32_t alpha_key) {
+                                     int nc, int CP, int mode, uint32_t alpha_key, uint32_t alpha_base) {
   const long per = (long)D * HW;
   const long total = (long)B * per;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
@@ -456,7 +457,7 @@ __global__ void k_build_critic_input(const float* __restrict__ real, const float
     };
     if (mode == 0) {
       float rl = real[f], fk = fake[f];
-      float a = rd_uniform(alpha_key, (uint32_t)b);
+      float a = rd_uniform(alpha_key, alpha_base + (uint32_t)b);
       put(f, rl); put(total + f, fk); put(2 * total + f, a * rl + (1.0f - a) * fk);
     } else if (mode == 1) {
       put(f, fake[f]);
@@ -638,8 +639,9 @@ __global__ void k_gp_norm_r0(const float* __restrict__ g0, float* __restrict__ c
 
 // X3 (T:215-216, T:388-392): losses of the critic step as Keras reports them:
 // out[0] = total, out[1] = mean(-v_real), out[2] = mean(v_fake), out[3] = mean(gp^2); out[4] = non-finite flag
+// (the flag also carries the generator's check_numerics, T:349-350: *gflag != 0 when its softmax produced NaN/Inf)
 __global__ void k_critic_losses(const float* __restrict__ v, const float* __restrict__ gp, float* __restrict__ out,
-                                int B, float gp_weight) {
+                                int B, float gp_weight, const int* __restrict__ gflag) {
   __shared__ float red[4];
   float a = 0.f, f = 0.f, g = 0.f;
   for (int i = threadIdx.x; i < B; i += blockDim.x) { a -= v[i]; f += v[B + i]; g += gp[i] * gp[i]; }
@@ -648,11 +650,11 @@ __global__ void k_critic_losses(const float* __restrict__ v, const float* __rest
     a /= B; f /= B; g /= B;
     float tot = a + f + gp_weight * g;
     out[0] = tot; out[1] = a; out[2] = f; out[3] = g;
-    out[4] = (fabsf(tot) <= 3.0e38f) ? 0.f : 1.f;
+    out[4] = (fabsf(tot) <= 3.0e38f && *gflag == 0) ? 0.f : 1.f;
   }
 }
 // generator step loss (T:408): out[0] = mean(-v); out[4] = non-finite flag
-__global__ void k_gen_loss(const float* __restrict__ v, float* __restrict__ out, int B) {
+__global__ void k_gen_loss(const float* __restrict__ v, float* __restrict__ out, int B, const int* __restrict__ gflag) {
   __shared__ float red[4];
   float a = 0.f;
   for (int i = threadIdx.x; i < B; i += blockDim.x) a -= v[i];
@@ -660,7 +662,7 @@ __global__ void k_gen_loss(const float* __restrict__ v, float* __restrict__ out,
   if (threadIdx.x == 0) {
     a /= B;
     out[0] = a; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f;
-    out[4] = (fabsf(a) <= 3.0e38f) ? 0.f : 1.f;
+    out[4] = (fabsf(a) <= 3.0e38f && *gflag == 0) ? 0.f : 1.f;
   }
 }
 

@@ -91,6 +91,14 @@ class Engine:
                    self._h, "rdgan_gen_forward")
         return out
 
+    def check_numerics(self):
+        """The reference's ``tf.debugging.check_numerics(x, 'found nan in output of per_gridpoint_softmax')`` (T:349-350):
+        waits for the current stream and raises NumericsError if the generator output of the last call held NaN/Inf."""
+        rc = self.lib.rdgan_check_numerics(self._h, self._stream())
+        if rc == -1:
+            raise _lib.NumericsError("found nan in output of per_gridpoint_softmax")
+        _lib.check(rc, self._h, "rdgan_check_numerics")
+
     def critic_forward(self, critic_params, sample, cond, seed=0):
         B = sample.shape[0]
         nd = self.ndomain
@@ -103,7 +111,14 @@ class Engine:
                                                  ctypes.c_uint64(seed), self._stream()), self._h, "rdgan_critic_forward")
         return out
 
-    def critic_grad(self, critic_params, gen_params, x_real, cond, z, seed, grad_out=None):
+    @staticmethod
+    def _event_handle(ev):
+        """hipEvent_t of a recorded torch.cuda.Event (None -> NULL)"""
+        return ctypes.c_void_p(ev.cuda_event if ev is not None else 0)
+
+    def critic_grad(self, critic_params, gen_params, x_real, cond, z, seed, grad_out=None, critic_ready=None):
+        """critic_ready: torch.cuda.Event recorded (on another stream) behind the last update of critic_params; the
+        current stream waits for it after the generator forward (rdgan_critic_grad_after)."""
         B = x_real.shape[0]
         nd = self.ndomain
         self._check_batch(B, self.max_batch)
@@ -115,12 +130,13 @@ class Engine:
         if grad_out is None:
             grad_out = torch.empty(self.n_critic + LOSS_SLOTS, dtype=torch.float32, device=self.device)
         _chk_tensor(grad_out, (self.n_critic + LOSS_SLOTS,), "grad_out")
-        _lib.check(self.lib.rdgan_critic_grad(self._h, _ptr(critic_params), _ptr(gen_params), _ptr(x_real), _ptr(cond),
-                                              _ptr(z), ctypes.c_uint64(seed), _ptr(grad_out), B, self._stream()),
+        _lib.check(self.lib.rdgan_critic_grad_after(self._h, _ptr(critic_params), _ptr(gen_params), _ptr(x_real), _ptr(cond),
+                                                    _ptr(z), ctypes.c_uint64(seed), _ptr(grad_out), B,
+                                                    self._event_handle(critic_ready), self._stream()),
                    self._h, "rdgan_critic_grad")
         return grad_out
 
-    def gen_grad(self, critic_params, gen_params, z, cond, seed, grad_out=None):
+    def gen_grad(self, critic_params, gen_params, z, cond, seed, grad_out=None, critic_ready=None):
         B = z.shape[0]
         nd = self.ndomain
         self._check_batch(B, self.max_batch)
@@ -131,8 +147,9 @@ class Engine:
         if grad_out is None:
             grad_out = torch.empty(self.n_gen + LOSS_SLOTS, dtype=torch.float32, device=self.device)
         _chk_tensor(grad_out, (self.n_gen + LOSS_SLOTS,), "grad_out")
-        _lib.check(self.lib.rdgan_gen_grad(self._h, _ptr(critic_params), _ptr(gen_params), _ptr(z), _ptr(cond),
-                                           ctypes.c_uint64(seed), _ptr(grad_out), B, self._stream()),
+        _lib.check(self.lib.rdgan_gen_grad_after(self._h, _ptr(critic_params), _ptr(gen_params), _ptr(z), _ptr(cond),
+                                                 ctypes.c_uint64(seed), _ptr(grad_out), B,
+                                                 self._event_handle(critic_ready), self._stream()),
                    self._h, "rdgan_gen_grad")
         return grad_out
 
@@ -148,11 +165,18 @@ class Engine:
 
     def set_option(self, name, value):
         """rdgan_set_option (include/rdgan.h): "collapse", "fast_fwd", "fast_bwd" (exact algebraic forms), "mfma_bf16" (mixed
-        mode), "wave_specialized", "ws_ksplit", "tapgather", "g9_direct" (kernel variants)."""
+        mode), "wave_specialized", "ws_ksplit", "tapgather", "g9_direct" (kernel variants), "sample_offset" (data-parallel
+        tests)."""
         _lib.check(self.lib.rdgan_set_option(self._h, name.encode(), int(value)), self._h, "rdgan_set_option")
 
     def profile(self, tag_mask):
         _lib.check(self.lib.rdgan_profile(self._h, int(tag_mask)), self._h, "rdgan_profile")
+
+    def flop_count(self, reset=False):
+        """algorithmic FLOPs of every GEMM launched since the last reset (rdgan_flop_count)"""
+        f = ctypes.c_double()
+        _lib.check(self.lib.rdgan_flop_count(self._h, ctypes.byref(f), int(bool(reset))), self._h, "rdgan_flop_count")
+        return f.value
 
     def profile_read(self, tag):
         ms, n = ctypes.c_double(), ctypes.c_long()

@@ -47,6 +47,7 @@ def generate_ensemble_device(gen, cond_norm, n_members, chunk=1024, seed=None):
         else:
             z = torch.randn((m, W.LATENT_DIM), generator=g, device=eng.device)
         eng.gen_forward(slab, z, cond_t.expand(m, nd, nd, 1).contiguous(), out=out[i:i + m])
+        eng.check_numerics()                     # reference T:349-350
     return out.view(n_members, W.NHOURS, nd, nd)
 
 

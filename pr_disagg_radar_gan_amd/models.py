@@ -102,7 +102,9 @@ class Generator(_Model):
         for i in range(0, n, chunk):
             z = torch.from_numpy(latent[i:i + chunk]).to(eng.device)
             c = torch.from_numpy(cond[i:i + chunk]).to(eng.device)
-            out[i:i + chunk] = eng.gen_forward(slab, z, c).cpu().numpy()
+            res = eng.gen_forward(slab, z, c)
+            eng.check_numerics()                 # tf.debugging.check_numerics in the generator graph (reference T:349-350)
+            out[i:i + chunk] = res.cpu().numpy()
         return out
 
 

@@ -16,8 +16,16 @@ LOSS_SLOTS = 8
 
 
 class WGANGPTrainer:
+    """overlap (default: world_size > 1 on a GPU engine): the gradient all-reduce and the Adam update of an optimizer step
+    run on a separate communication stream.  The next gradient call starts right away on the compute stream: its generator
+    forward reads no critic weight, so it runs beside the critic's exchange + update, and the compute stream only waits for
+    the `critic ready` event in front of the first kernel that reads critic weights (rdgan_*_grad_after).  Per iteration the
+    n_disc critic exchanges hide behind generator forwards; the generator's own exchange is exposed (the next critic step's
+    first kernel needs the new generator weights).  comm_hook(slab): called on the communication stream in place of / in
+    front of the all-reduce (tests: a delay kernel that would expose a missing dependency)."""
+
     def __init__(self, engine, gen_arrays, critic_arrays, n_disc=5, lr=1e-4, beta2=0.9, eps=1e-7,
-                 process_group=None, world_size=1, rank=0, base_seed=1234):
+                 process_group=None, world_size=1, rank=0, base_seed=1234, overlap=None, comm_hook=None):
         self.eng = engine
         self.n_disc = int(n_disc)
         self.lr, self.beta2, self.eps = lr, beta2, eps
@@ -31,6 +39,12 @@ class WGANGPTrainer:
         self.t = 0                      # shared optimizer.iterations
         self.base_seed = int(base_seed)
         self.calls = 0
+        on_gpu = self.gparams.is_cuda
+        self.overlap = bool(on_gpu and (self.world > 1 if overlap is None else overlap))
+        self.comm_hook = comm_hook
+        self.comm = torch.cuda.Stream(device=self.gparams.device) if self.overlap else None
+        self.d_ready = None             # events recorded on the communication stream behind the last critic / generator update
+        self.g_ready = None
 
     # every stochastic draw inside a step (dropout masks, alpha) is keyed by (base_seed, call index, rank)
     def _next_seed(self):
@@ -40,28 +54,67 @@ class WGANGPTrainer:
         return s or 1
 
     def _allreduce(self, slab):
+        if self.comm_hook is not None:
+            self.comm_hook(slab)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _update(self, params, grad, v):
+        """exchange + optimizer half of a train_on_batch call: ONE all-reduce of the flat gradient slab (losses in its
+        tail), then the fused Adam kernel with 1/world folded in.  Returns [total, valid, fake, gp, nonfinite] averaged
+        over ranks.  Runs on the current stream."""
+        self._allreduce(grad)
+        self.t += 1
+        self.eng.adam(params, grad, v, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
+        return grad[-LOSS_SLOTS:-LOSS_SLOTS + 5] / self.world
+
+    def _update_overlapped(self, params, grad, v, which):
+        cur = torch.cuda.current_stream(params.device)
+        done = torch.cuda.Event()
+        done.record(cur)                               # the gradient slab is complete
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(done)
+            losses = self._update(params, grad, v)
+            ready = torch.cuda.Event()
+            ready.record(self.comm)
+        losses.record_stream(cur)
+        setattr(self, which, ready)
+        return losses
 
     def critic_step(self, x_real, cond, z, seed=None):
         """critic_model.train_on_batch([X_real, cond_real, latent], [valid, fake, dummy]) (reference :472).
         Returns the device tensor [total, valid, fake, gp, nonfinite] averaged over ranks."""
         seed = self._next_seed() if seed is None else seed
-        self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self.dgrad)
-        self._allreduce(self.dgrad)
-        self.t += 1
-        self.eng.adam(self.dparams, self.dgrad, self.dv, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
-        return self.dgrad[-LOSS_SLOTS:-LOSS_SLOTS + 5] / self.world
+        if not self.overlap:
+            self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self.dgrad)
+            return self._update(self.dparams, self.dgrad, self.dv)
+        cur = torch.cuda.current_stream(self.dparams.device)
+        if self.g_ready is not None:
+            cur.wait_event(self.g_ready)               # the generator forward reads the generator weights at once
+        # critic weights, their Adam state and the gradient slab are touched only behind the wait for d_ready
+        self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self.dgrad, critic_ready=self.d_ready)
+        return self._update_overlapped(self.dparams, self.dgrad, self.dv, "d_ready")
 
     def gen_step(self, z, cond, seed=None):
         """generator_model.train_on_batch([latent, cond], valid) (reference :482)."""
         seed = self._next_seed() if seed is None else seed
-        self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self.ggrad)
-        self._allreduce(self.ggrad)
-        self.t += 1
-        self.eng.adam(self.gparams, self.ggrad, self.gv, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
-        return self.ggrad[-LOSS_SLOTS:-LOSS_SLOTS + 5] / self.world
+        if not self.overlap:
+            self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self.ggrad)
+            return self._update(self.gparams, self.ggrad, self.gv)
+        cur = torch.cuda.current_stream(self.gparams.device)
+        if self.g_ready is not None:
+            cur.wait_event(self.g_ready)
+        self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self.ggrad, critic_ready=self.d_ready)
+        return self._update_overlapped(self.gparams, self.ggrad, self.gv, "g_ready")
+
+    def join(self):
+        """Make the current stream wait for the updates still running on the communication stream (no host sync)."""
+        if self.overlap:
+            cur = torch.cuda.current_stream(self.gparams.device)
+            for ev in (self.d_ready, self.g_ready):
+                if ev is not None:
+                    cur.wait_event(ev)
 
     def iteration(self, critic_batches, gen_batch):
         """critic_batches: n_disc tuples (x_real, cond, z); gen_batch: (z, cond).  Returns (d_loss, g_loss)
@@ -71,11 +124,14 @@ class WGANGPTrainer:
         for (x, c, z) in critic_batches:
             dl = self.critic_step(x, c, z)
         gl = self.gen_step(*gen_batch)
+        self.join()         # the returned scalars (and the weights) are safe to read on the current stream; the next
+        #                     iteration's first kernel needs the new generator weights anyway
         return 0.5 * (dl[1] + dl[2]), gl[0], torch.maximum(dl[4], gl[4])
 
     def state_arrays(self):
         """(generator arrays, critic arrays) in Keras weight order, as numpy."""
         from . import weights as W
+        self.join()
         return (W.unflatten(self.gparams.cpu().numpy(), self.eng.gen_shapes),
                 W.unflatten(self.dparams.cpu().numpy(), self.eng.critic_shapes))
 
@@ -86,6 +142,7 @@ class WGANGPTrainer:
         shared Adam iteration counter, the step-RNG position (base_seed, calls) and numpy's global RNG state (the
         reference draws batches and latents from it, T:150,179).  One .npz; rank 0 writes (replicas are identical)."""
         st = np.random.get_state()
+        self.join()
         np.savez(path, format=np.array("rdgan-checkpoint-1"), ndomain=self.eng.ndomain,
                  n_cond_channels=getattr(self.eng, "n_cond_channels", 1),
                  gparams=self.gparams.cpu().numpy(), dparams=self.dparams.cpu().numpy(),
@@ -98,6 +155,7 @@ class WGANGPTrainer:
     def load_checkpoint(self, path, restore_numpy_rng=True):
         """Inverse of save_checkpoint, in place (device slabs keep their addresses, so models that adopted them
         keep tracking).  Raises ValueError when the file belongs to another configuration."""
+        self.join()
         with np.load(path, allow_pickle=False) as f:
             if str(f["format"]) != "rdgan-checkpoint-1":
                 raise ValueError(f"{path}: not an rdgan checkpoint")

@@ -55,6 +55,49 @@ def test_two_ranks_identical_shards_equal_single_process(tmp_path):
     assert not torch.equal(gp, torch.from_numpy(np.zeros(1, np.float32)).expand_as(gp))
 
 
+def _worker_shards(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import dp_case
+    from tests.fake_engine import FakeEngine
+    torch.set_num_threads(3)
+    res = dp_case.run_iteration(FakeEngine(dp_case.NDOMAIN, dtype=torch.float64), world, rank, dist.group.WORLD)
+    torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_different_shards_equal_the_global_batch(tmp_path):
+    """every loss term is a per-sample quantity followed by a batch mean, so the all-reduced (sum) gradient
+    slab of two DIFFERENT shards of 2 samples times 1/world equals the gradient of the global batch of 4 -- gradients,
+    the four reported losses and the updated weights.  The oracle behind the fp32 slabs runs in float64 here, so the only
+    differences are the fp32 roundings of the slabs (1e-6)."""
+    from tests import dp_case
+    from tests.fake_engine import FakeEngine
+    from pr_disagg_radar_gan_amd import weights as W
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_shards, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    for k in ("dgrad", "ggrad", "dl", "gl", "dparams", "gparams"):
+        assert torch.equal(r0[k], r1[k]), k        # replicas bit-identical after the exchange
+    torch.set_num_threads(6)
+    one = dp_case.run_iteration(FakeEngine(dp_case.NDOMAIN, dtype=torch.float64), 1, 0, None)
+    nd_, ng_ = one["dparams"].numel(), one["gparams"].numel()
+    errs = dp_case.grad_errors(r0["dgrad"][:nd_], one["dgrad"][:nd_], W.critic_param_shapes(dp_case.NDOMAIN))
+    assert max(errs.values()) < 1e-6, errs
+    errs = dp_case.grad_errors(r0["ggrad"][:ng_], one["ggrad"][:ng_], W.gen_param_shapes(dp_case.NDOMAIN))
+    assert max(errs.values()) < 1e-6, errs
+    assert torch.allclose(r0["dl"][:4], one["dl"][:4], rtol=1e-6, atol=1e-7)      # total, valid, fake, gp
+    assert torch.allclose(r0["gl"][:1], one["gl"][:1], rtol=1e-6, atol=1e-7)
+    # Adam's first step is lr * g / (|g| + eps'): equal wherever the gradient is not within rounding of zero
+    assert float((r0["dparams"] - one["dparams"]).abs().max()) <= 2.1e-4
+    assert float((r0["dparams"] - one["dparams"]).abs().mean()) < 1e-8
+    assert float((r0["gparams"] - one["gparams"]).abs().mean()) < 1e-8
+
+
 def test_shard_slice():
     from pr_disagg_radar_gan_amd.trainer import shard_slice
     assert [shard_slice(8, 4, r) for r in range(4)] == [slice(0, 2), slice(2, 4), slice(4, 6), slice(6, 8)]
