@@ -140,7 +140,8 @@ def launch_children(args, argv):
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
     out0 = procs[0].communicate()[0].decode()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    for line in out0.splitlines():             # (the gloo rehearsal backend prints a connection banner on stdout)
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 

@@ -202,6 +202,11 @@ int rdgan_op_conv3d_wgrad_bf16(const float* x, const float* gy, float* dw, int B
 int rdgan_op_pixelnorm_lrelu(const float* y, float* h, float* rinv, long npix, int C, void* stream);
 int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* rinv, float* dy,
                                  long npix, int C, void* stream);
+/* Test hook: copies the first n floats of an activation tensor the last forward pass left in the workspace into `out`
+ * (device, fp32): which = 0..3 generator h0..h3 [B, D, H, W, C] after LeakyReLU; 4..7 critic layers 1..4 after LeakyReLU
+ * and dropout.  The gradient parity tests take the LeakyReLU slope pattern of the fp32 run from here, so that the fp64
+ * oracle differentiates the same piecewise-linear branch. */
+int rdgan_debug_activation(rdgan_handle* h, int which, float* out, long n, void* stream);
 /* dropout keep-scale mask (0 or 1/0.75) and uniforms of the counter RNG, for pinning it to oracle/rng.py */
 int rdgan_op_rng(uint64_t seed, uint32_t stream_id, float* mask_out, float* uniform_out, long n,
                  void* stream);

@@ -43,20 +43,31 @@ def upsample3d(x):
     return x.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
 
 
-def generator_forward(p, z, cond, return_intermediates=False):
-    """T:312-357."""
+def _lrelu(x, gate=None):
+    """LeakyReLU(0.2) (T:327,333,288).  gate (bool tensor, True = slope 1): differentiate the piecewise-linear branch an
+    external run took instead of deciding by the sign of x -- the loss is only piecewise smooth, and an fp32 run and this
+    oracle legitimately pick different slopes for an input within rounding of zero (see kink_margin); with the fp32 run's
+    own pattern both sides evaluate the same smooth function."""
+    if gate is None:
+        return F.leaky_relu(x, LRELU)
+    return x * torch.where(gate, torch.ones((), dtype=x.dtype), torch.full((), LRELU, dtype=x.dtype))
+
+
+def generator_forward(p, z, cond, return_intermediates=False, gates=None):
+    """T:312-357.  gates: optional [h0, h1, h2, h3] slope patterns for _lrelu."""
     Wd, bd, W1, b1, W2, b2, W3, b3, W4, b4 = p
     B = z.shape[0]
     nd = cond.shape[1]
     s = nd // 8
     x = torch.cat([z, cond.reshape(B, -1)], dim=1)
-    h0 = F.leaky_relu(x @ Wd + bd, LRELU).reshape(B, 3, s, s, 256)
+    gt = gates if gates is not None else [None] * 4
+    h0 = _lrelu((x @ Wd + bd).reshape(B, 3, s, s, 256), gt[0])
     hs = [h0]
     h = h0
-    for W, b in ((W1, b1), (W2, b2), (W3, b3)):
+    for li, (W, b) in enumerate(((W1, b1), (W2, b2), (W3, b3))):
         u = upsample3d(h)
         y = _conv3d_tf(u, W, b, 1, (1, 1, 1), u.shape[1:4])
-        h = F.leaky_relu(pixel_norm(y), LRELU)
+        h = _lrelu(pixel_norm(y), gt[li + 1])
         hs.append(h)
     logits = _conv3d_tf(h, W4, b4, 1, (1, 1, 1), h.shape[1:4])
     out = torch.softmax(logits, dim=1)
@@ -65,8 +76,8 @@ def generator_forward(p, z, cond, return_intermediates=False):
     return out
 
 
-def critic_forward(p, sample, cond, masks=None, return_intermediates=False):
-    """T:272-309.  masks: list of 4 tensors (0 or 1/0.75) or None."""
+def critic_forward(p, sample, cond, masks=None, return_intermediates=False, gates=None):
+    """T:272-309.  masks: list of 4 tensors (0 or 1/0.75) or None.  gates: optional 4 slope patterns for _lrelu."""
     nd = cond.shape[1]
     geo = onp.critic_geometry(nd)
     cond_rep = cond[:, None].expand(-1, onp.NHOURS, -1, -1, -1)
@@ -75,7 +86,7 @@ def critic_forward(p, sample, cond, masks=None, return_intermediates=False):
     for li in range(4):
         _, out_dims, pad = geo[li]
         a = _conv3d_tf(x, p[2 * li], p[2 * li + 1], 2, pad, out_dims)
-        x = F.leaky_relu(a, LRELU)
+        x = _lrelu(a, None if gates is None else gates[li])
         if masks is not None:
             x = x * masks[li]
         hs.append(x)
@@ -130,15 +141,15 @@ def critic_step_grads(dp, gp, x_real, cond, z, seed, alpha_offset=0):
     return losses, [gg.detach() for gg in grads]
 
 
-def gen_step_grads(dp, gp, z, cond, seed):
+def gen_step_grads(dp, gp, z, cond, seed, gates=None):
     """One generator ``train_on_batch`` graph (T:395-408,482): loss = mean(-D(G(z,c))),
-    critic frozen but dropout active."""
+    critic frozen but dropout active.  gates: optional (generator [h0..h3], critic [4 layers]) slope patterns."""
     B = z.shape[0]
     nd = cond.shape[1]
     gp = [t.detach().clone().requires_grad_(True) for t in gp]
-    img = generator_forward(gp, z, cond)
+    img = generator_forward(gp, z, cond, gates=None if gates is None else gates[0])
     masks = critic_masks(seed, B, nd, z.dtype)
-    v = critic_forward(dp, img, cond, masks)
+    v = critic_forward(dp, img, cond, masks, gates=None if gates is None else gates[1])
     loss = torch.mean(-1.0 * v)
     grads = torch.autograd.grad(loss, gp)
     return loss.detach(), [gg.detach() for gg in grads]

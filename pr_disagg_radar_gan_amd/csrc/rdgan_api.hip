@@ -1899,6 +1899,23 @@ extern "C" int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* hh, co
   return (int)hipStreamSynchronize((hipStream_t)stream);
 }
 
+// test hook: the activations the last forward left in the workspace (generator h0..h3: which = 0..3, critic layers 1..4
+// after LeakyReLU and dropout: which = 4..7), first n floats, as fp32
+extern "C" int rdgan_debug_activation(rdgan_handle* h, int which, float* out, long n, void* stream) {
+  if (!h || !out || which < 0 || which > 7 || n < 1) return bad_arg(h, "debug_activation: bad argument");
+  const float* src; long cap;
+  if (which < 4) {
+    float* hs[4] = {h->h0, h->h1, h->h2, h->h3};
+    src = hs[which]; cap = (long)h->MB * h->gpix[which] * h->gch[which];
+  } else {
+    const int l = which - 3;
+    src = h->dh[l]; cap = (long)h->NB * h->dL[l] * h->dch[l];
+  }
+  if (n > cap) return bad_arg(h, "debug_activation: n exceeds the tensor");
+  RD_CHECK(h, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
 __global__ void k_rng_probe(uint32_t key, float* mask, float* uni, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     if (mask) mask[i] = rd_drop_scale(key, (uint32_t)i);

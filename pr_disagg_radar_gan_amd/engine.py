@@ -172,6 +172,14 @@ class Engine:
     def profile(self, tag_mask):
         _lib.check(self.lib.rdgan_profile(self._h, int(tag_mask)), self._h, "rdgan_profile")
 
+    def debug_activation(self, which, shape):
+        """test hook (rdgan_debug_activation): activation tensor `which` of the last forward (0..3 generator h0..h3,
+        4..7 critic layers 1..4) as a float32 CUDA tensor of `shape`"""
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.rdgan_debug_activation(self._h, int(which), _ptr(out), out.numel(), self._stream()), self._h,
+                   "rdgan_debug_activation")
+        return out
+
     def flop_count(self, reset=False):
         """algorithmic FLOPs of every GEMM launched since the last reset (rdgan_flop_count)"""
         f = ctypes.c_double()

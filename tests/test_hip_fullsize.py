@@ -17,7 +17,7 @@ from oracle import rdgan_torch as ot
 from pr_disagg_radar_gan_amd import Engine
 from pr_disagg_radar_gan_amd import weights as W
 from pr_disagg_radar_gan_amd.trainer import WGANGPTrainer
-from tests.hip_util import dev, rel_err
+from tests.hip_util import dev, rel_err, hip_gates
 from tests.test_hip_step import _params, _t64, _grad_errors, TIGHT, LOOSE
 
 pytestmark = pytest.mark.gpu
@@ -34,56 +34,53 @@ def test_b96_default_options_step_gradients_vs_oracle():
         out = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
         np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-7)          # north_star tolerance
         assert rel_err(out, ref) < 2e-5
-        # a flipped LeakyReLU slope (see test_hip_step._parity_over_batches) moves a batch-mean gradient by ~1e-3 / B,
-        # so at this batch the first data seed is expected to reach the tight tolerance; two seeds are allowed
-        for step in ("critic", "gen"):
-            history = []
-            for data_seed in (300, 301):
-                x, cond, z = ot.synthetic_batch(B, 16, data_seed)
-                if step == "critic":
-                    losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
-                                                         torch.from_numpy(cond).double(), torch.from_numpy(z).double(), 4711)
-                    slab = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 4711).cpu().numpy()
-                    n = eng.n_critic
-                    np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
-                    assert slab[n + 4] == 0.0
-                    errs = _grad_errors(slab[:n], grads, eng.critic_shapes)
-                else:
-                    loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(),
-                                                    torch.from_numpy(cond).double(), 4712)
-                    slab = eng.gen_grad(ds, gs, dev(z), dev(cond), 4712).cpu().numpy()
-                    n = eng.n_gen
-                    np.testing.assert_allclose(slab[n], loss.item(), rtol=2e-4, atol=1e-6)
-                    errs = _grad_errors(slab[:n], grads, eng.gen_shapes)
-                worst = max(errs.values())
-                history.append(float(f"{worst:.2e}"))
-                assert worst < LOOSE, (step, data_seed, errs)
-                if worst < TIGHT:
-                    print(step, "grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
-                    break
-            else:
-                raise AssertionError(f"{step}: no batch reached the tight tolerance: {history}")
+        # critic step: compared directly (observed 1e-7...8e-7).  Generator step: at this batch some of the ~2e8 LeakyReLU
+        # inputs always sit within fp32 rounding of zero and take the other slope in fp64, which moves gradients by ~1e-3
+        # whatever the batch (the number of flips and the gradient norm both scale as sqrt(B)); the oracle therefore
+        # differentiates the branch the fp32 run took (its slope pattern, read back from the workspace) -- the same smooth
+        # function on both sides, so the comparison is tight at any size.
+        x, cond, z = ot.synthetic_batch(B, 16, 300)
+        losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
+                                             torch.from_numpy(cond).double(), torch.from_numpy(z).double(), 4711)
+        slab = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 4711).cpu().numpy()
+        n = eng.n_critic
+        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+        assert slab[n + 4] == 0.0
+        errs = _grad_errors(slab[:n], grads, eng.critic_shapes)
+        print("critic grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
+        assert max(errs.values()) < TIGHT, errs
+        slab = eng.gen_grad(ds, gs, dev(z), dev(cond), 4712).cpu().numpy()
+        gates = hip_gates(eng, B)
+        loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 4712,
+                                        gates=gates)
+        n = eng.n_gen
+        np.testing.assert_allclose(slab[n], loss.item(), rtol=2e-4, atol=1e-6)
+        errs = _grad_errors(slab[:n], grads, eng.gen_shapes)
+        print("gen grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
+        assert max(errs.values()) < TIGHT, errs
     finally:
         eng.close()
 
 
 def test_nd64_gen_step_gradients_vs_oracle():
     """largedomain variant (L:59,325,335), B = 1: generator-step gradients incl. the Dense kernel (4196 x 49152) and the
-    shared-centre backward at ndomain 64.  fp32 torch oracle (the fp64 one needs > 3 GB per weight copy), hence 1e-3."""
+    shared-centre backward at ndomain 64, against the fp64 oracle differentiating the fp32 run's LeakyReLU branch (see the
+    B = 96 test)."""
     eng = Engine(ndomain=64, max_batch=1)
     try:
         g, d = _params(64, 15)
-        x, cond, z = ot.synthetic_batch(1, 64, 8)
         gs, ds = eng.to_slab(g), eng.to_slab(d)
-        loss, grads = ot.gen_step_grads([torch.from_numpy(a) for a in d], [torch.from_numpy(a) for a in g],
-                                        torch.from_numpy(z), torch.from_numpy(cond), 6)
+        x, cond, z = ot.synthetic_batch(1, 64, 8)
         slab = eng.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
+        gates = hip_gates(eng, 1)
+        loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 6,
+                                        gates=gates)
         n = eng.n_gen
-        np.testing.assert_allclose(slab[n], loss.item(), rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(slab[n], loss.item(), rtol=2e-4, atol=1e-6)
         assert slab[n + 4] == 0.0
         errs = _grad_errors(slab[:n], grads, eng.gen_shapes)
         print("nd64 gen-step grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
-        assert max(errs.values()) < 1e-3, errs
+        assert max(errs.values()) < TIGHT, errs
     finally:
         eng.close()
 

@@ -82,6 +82,12 @@ def _grad_errors(got, ref_list, shapes):
             assert abs(float(got[off])) < 1e-6, got[off]
             off += n
             continue
+        if name == "dense_1/bias:0" and float(np.abs(r.numpy()).max()) < 1e-12:
+            # critic step: d/d(last bias) = mean(-1) + mean(+1) = 0 analytically (the penalty does not see it); the HIP
+            # path writes the exact zero, the oracle's sum of +-1/B is rounding noise when 1/B is not a binary fraction
+            assert abs(float(got[off])) < 1e-6, got[off]
+            off += n
+            continue
         errs[name] = rel_err(got[off:off + n].reshape(s), r.numpy())
         off += n
     return errs

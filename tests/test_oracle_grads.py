@@ -91,3 +91,28 @@ def test_gen_step_grads_vs_finite_differences():
         fd = (L(plus) - L(minus)) / (2 * eps)
         an = float((grads[i].numpy() * d).sum())
         assert abs(fd - an) <= 1e-4 * max(1e-4, abs(an)) + 1e-9, (i, fd, an)
+
+
+def test_slope_pattern_of_the_run_itself_changes_nothing():
+    """gen_step_grads(gates=...) differentiates the LeakyReLU branch given by an external slope pattern (the GPU tests pass
+    the fp32 run's); with the oracle's own pattern it must reproduce the plain call exactly."""
+    import torch
+    from oracle import rdgan_np as onp
+    from oracle import rdgan_torch as ot
+    rng = np.random.default_rng(5)
+    g = [torch.from_numpy(a) for a in onp.init_generator(rng, 8, dtype=np.float64)]
+    d = [torch.from_numpy(a) for a in onp.init_critic(rng, 8, dtype=np.float64)]
+    x, cond, z = (torch.from_numpy(a) for a in ot.synthetic_batch(2, 8, 3, dtype=np.float64))
+    with torch.no_grad():
+        img, gi = ot.generator_forward(g, z, cond, True)
+        _, di = ot.critic_forward(d, img, cond, ot.critic_masks(7, 2, 8, torch.float64), True)
+    gates = ([gi[k] > 0 for k in ("h0", "h1", "h2", "h3")], [h > 0 for h in di["h"]])
+    l0, g0 = ot.gen_step_grads(d, g, z, cond, 7)
+    l1, g1 = ot.gen_step_grads(d, g, z, cond, 7, gates=gates)
+    assert abs(float(l0) - float(l1)) < 1e-14
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 1e-13 * float(a.abs().max() + 1e-30)
+    # and a different pattern really is a different function
+    flipped = ([~t for t in gates[0]], gates[1])
+    _, g2 = ot.gen_step_grads(d, g, z, cond, 7, gates=flipped)
+    assert float((g2[2] - g0[2]).abs().max()) > 1e-3 * float(g0[2].abs().max())
