@@ -211,11 +211,11 @@ def main():
     else:
         B = cfg["batch"]
     opts = dict(kv.split("=") for kv in args.opt)
-    bf16 = int(opts.get("bf16_storage", opts.get("mfma_bf16", cfg["bf16"]))) != 0
+    bf16 = int(opts.get("bf16", cfg["bf16"])) != 0
 
     eng = Engine(ndomain=ND, max_batch=B, device=dev)
-    if cfg["bf16"] and "bf16_storage" not in opts and "mfma_bf16" not in opts:
-        eng.set_option("mfma_bf16", 1)
+    if cfg["bf16"] and "bf16" not in opts:
+        eng.set_option("bf16", 1)
     for name, value in opts.items():
         eng.set_option(name, int(value))
     rng = np.random.default_rng(0)                  # identical initial weights on every rank

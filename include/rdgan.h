@@ -175,11 +175,13 @@ int rdgan_crps_ensemble(const float* ens, const float* obs, const float* scale, 
 int rdgan_op_conv3d(const float* x, const float* w, const float* bias, float* y, int B, int D, int H,
                     int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d,
                     int pad_h, int pad_w, int upsample, void* stream);
-/* the same contraction with bf16 operands (x and w rounded to nearest-even bf16 on the device, fp32 accumulation and
- * output; v_mfma_f32_32x32x16_bf16): the GEMM of the "mfma_bf16" option.  No folded upsample; Cin, Cout % 64 == 0. */
+/* the same contraction with bf16 operands (x and w rounded to nearest-even bf16 on the device, fp32 accumulation;
+ * v_mfma_f32_32x32x16_bf16): the GEMM of the "bf16" storage mode.  out_bf16 = 0: y is fp32 (the arithmetic, checked at
+ * 1e-5 against the oracle on bf16-rounded operands); 1: y is bf16 (2 bytes per element), the accumulator rounded once
+ * after the epilogue, as the storage mode writes it.  No folded upsample; Cin, Cout % 64 == 0. */
 int rdgan_op_conv3d_bf16(const float* x, const float* w, const float* bias, float* y, int B, int D, int H,
                          int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d,
-                         int pad_h, int pad_w, void* stream);
+                         int pad_h, int pad_w, int out_bf16, void* stream);
 /* input gradient of the above for stride 2 (parity-phase plan) or stride 1: gy -> gx (same dims as x,
  * on the upsampled grid when the forward had upsample=1: D,H,W are the conv's input extents). */
 int rdgan_op_conv3d_dgrad(const float* gy, const float* w, float* gx, int B, int D, int H, int W,
@@ -198,6 +200,13 @@ int rdgan_op_conv3d_wgrad(const float* x, const float* gy, float* dw, int B, int
 int rdgan_op_conv3d_wgrad_bf16(const float* x, const float* gy, float* dw, int B, int D, int H, int W,
                                int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h,
                                int pad_w, void* stream);
+/* Weight gradient of one tap group (g = 0, 1, 2) of the shared-centre form of a generator block through the production
+ * plan (4 parity phases x 4 taps: the even tap count that selects the 256-row tile at B*D*H*W >= 65536).  g = 0: src = E
+ * [B,D+1,H,W,Cin], dy [B,2D,2H,2W,Cout] (even planes used); g = 1: src = x [B,D,H,W,Cin], dy = plane-pair sums
+ * [B,D,2H,2W,Cout]; g = 2: E at j = s+1 against the odd planes.  dU [48][Cin][Cout], forms g*16 .. g*16+15 written.
+ * bf16 = 1: operands rounded to bf16 on the device, fp32 accumulation (Cin % 128 == 0). */
+int rdgan_op_fastd_wgrad(const float* src, const float* dy, float* dU, int B, int D, int H, int W, int Cin, int Cout,
+                         int g, int bf16, void* stream);
 /* PixelNormalization + LeakyReLU(0.2) forward (T:255-266, T:333) and its backward. C in {64,128,256}. */
 int rdgan_op_pixelnorm_lrelu(const float* y, float* h, float* rinv, long npix, int C, void* stream);
 int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* rinv, float* dy,

@@ -368,14 +368,15 @@ struct rdgan_handle {
   // shared-centre form: per block the hour differences E of its input and the 48 weight forms U (written by the forward,
   // reused by the backward); T / plane sums gS, the gradient wrt E, weight-form gradients and transposes (scratch)
   float *fE[4], *fU[4], *fgS, *fdE, *fdU, *fUT;
-  // "mfma_bf16": bf16 copies of the operands of the shared-centre GEMMs (block input x, differences E, plane sums gS,
-  // output gradient dy, weight forms in [N][K] layout)
-  void *bX[4], *bE[4], *bU[4], *bUT, *bgS, *bdy;
-  void *bScr, *bScr2;             // bf16 copies of the current GEMM's operands (critic layers, generator block 1)
-  size_t bScr_elems = 0;
-  void *bWF[5], *bWB[5];          // critic layers 2-4: bf16 kernels [27][Cout][Cin] (forward) and [27][Cin][Cout] (input gradient)
-  void *bG1F, *bG1B;              // generator block 1: collapsed forms [64][Cout][Cin] and, re-ordered by tap, [64][Cin][Cout]
-  int mfma_bf16 = 0;              // 1: shared-centre forward / input-gradient GEMMs of blocks 2, 3 on bf16 operands (fp32 accumulate, fp32 tensors everywhere else)
+  // "bf16" storage mode: activations and activation gradients live in the workspace as bf16 (the same float* fields then
+  // point at bf16 data; act_off() does their pointer arithmetic); bf16 weight images of every bf16-MFMA GEMM, rebuilt from
+  // the fp32 master weights inside each call: shared-centre forms [48][N][K] and their tap-reordered input-gradient
+  // stack, critic layers 2-4 forward [27][Cout][Cin] / input gradient [27][Cin][Cout], generator block 1 collapsed forms
+  // [64][Cout][Cin] and (re-ordered by tap) [64][Cin][Cout], the first critic kernel [ldp1][64]
+  void *bU[4], *bUT;
+  void *bWF[5], *bWB[5];
+  void *bG1F, *bG1B, *bW1B;
+  int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
   int g9_direct = 1;              // 1: backward of the 64 -> 1 conv straight from the dlogits (no im2col matrix), fused with block 3's PixelNorm backward
   int fast_fwd = 1;               // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products)
   int fast_bwd = 1;               // 1: generator blocks' weight/input gradients in the shared-centre form along d (48 instead of 64 tap products)
@@ -443,7 +444,7 @@ static long plan_tiles(const RdPlan& p, int B, int BM) {
   return t;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool PARTIAL, bool SHIFT>
+template <int BM, int BN, int WM, int WN, int BK, bool PARTIAL, bool SHIFT, bool SRC16 = false, bool OUT16 = false>
 static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src,
                            const float* W, int ldw, float* dst, const RdEpi& epi, hipStream_t st) {
   constexpr int AST = BK == 32 ? BK : BK + 4, BST = BN;
@@ -456,7 +457,7 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
 #endif
   static bool attr_done = false;
-  auto kern = k_conv_gemm<BM, BN, WM, WN, BK, PARTIAL, SHIFT>;
+  auto kern = k_conv_gemm<BM, BN, WM, WN, BK, PARTIAL, SHIFT, SRC16, OUT16>;
   if (!attr_done) {
     RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -476,7 +477,7 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   const long nch = (long)hp.ph[0].ntaps * ((hp.SC + BK - 1) / BK);
   const long total = (long)B * hp.dst_sample;
   if (epi.addt && BK != 32) return bad_arg(h, "conv: the shared-centre epilogue needs the BK = 32 kernels");
-  if (h && blocks < 256 && nch >= 16 && hp.d_cstride == hp.N && hp.N % 4 == 0 && epi.mode != RD_EPI_BIAS_PN_LRELU && !epi.addt) {
+  if (h && !OUT16 && blocks < 256 && nch >= 16 && hp.d_cstride == hp.N && hp.N % 4 == 0 && epi.mode != RD_EPI_BIAS_PN_LRELU && !epi.addt) {
     long ks = std::min<long>(std::min<long>(8, 640 / blocks), nch / 4);
     for (int i = 1; i < hp.nphases; ++i) ks = std::min<long>(ks, (long)hp.ph[i].ntaps * ((hp.SC + BK - 1) / BK) / 2);
     if (ks >= 2 && (size_t)(ks * total) <= h->kpartial_cap) { e2.ksplit = (int)ks; e2.kpart = h->kpartial; e2.kstride = total; }
@@ -484,7 +485,7 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   dim3 grid((unsigned)blocks, (unsigned)e2.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, W, ldw, dst, e2);
   if (e2.ksplit > 1)
-    hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)std::min<long>((total / 4 + 255) / 256, 2048)), dim3(256), 0, st, dst,
+    hipLaunchKernelGGL(k_splitk_finish<false>, dim3((unsigned)std::min<long>((total / 4 + 255) / 256, 2048)), dim3(256), 0, st, dst,
                        total, hp.N, e2);
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -550,10 +551,13 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
     if (h->ws_ksplit > 1) best = std::min<long>(h->ws_ksplit, std::max<long>(1, nch / 4));   // tests: force a split
     if (best > 1 && (size_t)(best * total) <= h->kpartial_cap) { e2.ksplit = (int)best; e2.kpart = h->kpartial; e2.kstride = total; }
   }
+  if (!BF) e2.out16 = 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)e2.ksplit), dim3(512), lds, st, dp, B, src, W, ldw, dst, e2);
-  if (e2.ksplit > 1)
-    hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)std::min<long>((total / 4 + 255) / 256, 2048)), dim3(256), 0, st, dst,
-                       total, hp.N, e2);
+  if (e2.ksplit > 1) {
+    const dim3 fg((unsigned)std::min<long>((total / 4 + 255) / 256, 2048));
+    if (e2.out16) hipLaunchKernelGGL(k_splitk_finish<true>, fg, dim3(256), 0, st, dst, total, hp.N, e2);
+    else hipLaunchKernelGGL(k_splitk_finish<false>, fg, dim3(256), 0, st, dst, total, hp.N, e2);
+  }
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -615,6 +619,30 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
   return bad_arg(h, "conv: unsupported N");
 }
 
+// bf16 storage mode: the few GEMMs that stay on the fp32 matrix pipe (the generator's Dense layer and the first critic
+// layer read fp32 inputs and write bf16; the 64 -> 1 conv reads bf16 and writes its fp32 tap sums)
+static int launch_conv_a16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* W,
+                           int ldw, float* dst, const RdEpi& epi, hipStream_t st, int tag, bool src16, bool out16) {
+  ProfScope ps(h, tag, st);
+  if (h) h->flops_acc += plan_flops(hp, B);
+  const bool partial = (hp.SC & 3) != 0;
+  if (hp.s_shift) return bad_arg(h, "conv (bf16 storage): folded upsample is not supported");
+  if (!src16 && out16) {
+    if (hp.SC < 32 && hp.SC != 27) {      // first critic layer: BK = 8
+      if (hp.N % 64) return bad_arg(h, "conv (bf16 storage): unsupported BK=8 case");
+      if (partial) return launch_conv_cfg<128, 64, 2, 2, 8, true, false, false, true>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+      return launch_conv_cfg<128, 64, 2, 2, 8, false, false, false, true>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    }
+    if (!partial && hp.N % 64 == 0)        // Dense
+      return launch_conv_cfg<64, 64, 2, 2, 32, false, false, false, true>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  }
+  if (src16 && !out16 && hp.N == 32 && !partial) {     // last generator conv as a column GEMM
+    if (epi.mode == RD_EPI_TAPGATHER) return launch_conv_cfg<256, 32, 4, 1, 32, false, false, true, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+    return launch_conv_cfg<128, 32, 4, 1, 32, false, false, true, false>(h, hp, dp, B, src, W, ldw, dst, epi, st);
+  }
+  return bad_arg(h, "conv (bf16 storage): unsupported fp32-pipe GEMM");
+}
+
 static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>((n + per - 1) / per, 8192); }
 
 // bf16-operand conv GEMM (fp32 accumulate / output): src16 = bf16 NDHWC activations, w16 = bf16 weights [tap block][N][K]
@@ -640,10 +668,6 @@ static int launch_weights_to_bf16_t(rdgan_handle* h, const float* in, void* out,
   return 0;
 }
 
-// mixed mode: the GEMM reads a bf16 copy of its gathered operand made just before it (n_src floats of src) and bf16 weights
-static int conv_mixed(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, size_t n_src, const void* w16,
-                      float* dst, const RdEpi& epi, hipStream_t st, int tag);
-
 // true when launch_conv will pick a tile whose BN equals the plan's N, i.e. a workgroup owns whole output rows
 static bool conv_rows_owned(const RdPlan& hp, int B) {
   if (hp.s_shift || (hp.SC & 3) || hp.SC < 32) return false;
@@ -651,6 +675,9 @@ static bool conv_rows_owned(const RdPlan& hp, int B) {
   if (hp.N == 64) return plan_tiles(hp, B, 256) >= 1024 || plan_tiles(hp, B, 128) >= 200;
   return false;
 }
+
+// the same for launch_conv16 (bf16 storage mode): tiles 128x128 (N % 128 == 0), 256x64 / 128x64 (N == 64)
+static bool conv16_rows_owned(const RdPlan& hp) { return hp.N == 128 || hp.N == 64; }
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
@@ -683,12 +710,12 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   return T;
 }
 
-template <int BR, int BN, bool PARTIAL, bool SHIFT>
+template <int BR, int BN, bool PARTIAL, bool SHIFT, bool DY16 = false>
 static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int B, const float* src, const float* dy,
                             float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(32 * BR + 32 * BN) * sizeof(float);
   static bool attr_done = false;
-  auto kern = k_wgrad_gemm<BR, BN, PARTIAL, SHIFT>;
+  auto kern = k_wgrad_gemm<BR, BN, PARTIAL, SHIFT, DY16>;
   if (!attr_done) {
     RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -719,7 +746,7 @@ static int launch_wgrad_ws_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, i
 
 // dW (rows tap_w*wrpt + c, leading dimension ldw = N) from src (gathered through the plan) and dy
 static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* dy,
-                        float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
+                        float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag, bool dy16 = false) {
   ProfScope ps(h, tag, st);
   if (h) h->flops_acc += plan_flops(hp, B);
   if (hp.N % 64) return bad_arg(h, "wgrad: N % 64 != 0");
@@ -741,8 +768,13 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   } while (0)
   float* partial_buf = partial_ws;
   const long wrows = (long)B * hp.ph[0].L;
-  const bool ws = h && h->wave_spec && !partial && !shift && (h->wave_spec == 2 || wrows * hp.nphases >= 1024);
-  if (ws && BR == 256) RD_TRY((launch_wgrad_ws_cfg<256, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  const bool ws = h && h->wave_spec && !partial && !shift && !dy16 && (h->wave_spec == 2 || wrows * hp.nphases >= 1024);
+  if (dy16) {       // bf16 storage mode, first critic layer: fp32 gathered input against the bf16 output gradient
+    if (shift || BR != 64 || BN != 64) return bad_arg(h, "wgrad: bf16 output gradient only with the 64x64 tile");
+    if (partial) RD_TRY((launch_wgrad_cfg<64, 64, true, false, true>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+    else RD_TRY((launch_wgrad_cfg<64, 64, false, false, true>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
+  }
+  else if (ws && BR == 256) RD_TRY((launch_wgrad_ws_cfg<256, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
   else if (ws && BR == 128 && BN == 128) RD_TRY((launch_wgrad_ws_cfg<128, 128>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
   else if (ws && BR == 128) RD_TRY((launch_wgrad_ws_cfg<128, 64>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
   else if (ws && BN == 128) RD_TRY((launch_wgrad_ws_cfg<64, 128>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
@@ -821,15 +853,20 @@ static size_t wgrad_partial_need(const RdPlan& hp, int B) {
 }
 
 // out[c] = sum over rows of src[rows][C]
-static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, float* out, hipStream_t st) {
+static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, float* out, hipStream_t st, bool src16 = false) {
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
   const bool any = C != 64 && C != 128 && C != 256;
+  if (src16 && any) return bad_arg(h, "colsum: bf16 input only for 64 / 128 / 256 columns");
   long nblk = std::min<long>(1024, std::max<long>(1, rows / (any ? 8 : 32)));
   if ((size_t)nblk * C > h->cpartial_cap) nblk = std::max<long>(1, (long)(h->cpartial_cap / C));
   long rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
   dim3 grid((unsigned)nblk);
-  if (C == 64) hipLaunchKernelGGL(k_colsum_partial<16>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
+  const rd_bf16_t* s16 = (const rd_bf16_t*)src;
+  if (src16 && C == 64) hipLaunchKernelGGL((k_colsum_partial<16, rd_bf16_t>), grid, dim3(256), 0, st, s16, rows, h->cpartial, rpb);
+  else if (src16 && C == 128) hipLaunchKernelGGL((k_colsum_partial<32, rd_bf16_t>), grid, dim3(256), 0, st, s16, rows, h->cpartial, rpb);
+  else if (src16) hipLaunchKernelGGL((k_colsum_partial<64, rd_bf16_t>), grid, dim3(256), 0, st, s16, rows, h->cpartial, rpb);
+  else if (C == 64) hipLaunchKernelGGL(k_colsum_partial<16>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
   else if (C == 128) hipLaunchKernelGGL(k_colsum_partial<32>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
   else if (C == 256) hipLaunchKernelGGL(k_colsum_partial<64>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
   else {
@@ -848,10 +885,17 @@ static int launch_transpose(rdgan_handle* h, const float* in, float* out, int T,
   return 0;
 }
 
-static int launch_pn_fwd(rdgan_handle* h, const float* y, float* hout, float* rinv, long npix, int C, hipStream_t st) {
+static int launch_pn_fwd(rdgan_handle* h, const float* y, float* hout, float* rinv, long npix, int C, hipStream_t st, bool a16 = false) {
   long threads = npix * (C / 4);
   dim3 grid((unsigned)((threads + 255) / 256));
-  if (C == 256) hipLaunchKernelGGL(k_pixelnorm_lrelu_fwd<64>, grid, dim3(256), 0, st, y, hout, rinv, npix);
+  const rd_bf16_t* y16 = (const rd_bf16_t*)y; rd_bf16_t* h16 = (rd_bf16_t*)hout;
+  if (a16) {
+    if (C == 256) hipLaunchKernelGGL((k_pixelnorm_lrelu_fwd<64, rd_bf16_t>), grid, dim3(256), 0, st, y16, h16, rinv, npix);
+    else if (C == 128) hipLaunchKernelGGL((k_pixelnorm_lrelu_fwd<32, rd_bf16_t>), grid, dim3(256), 0, st, y16, h16, rinv, npix);
+    else if (C == 64) hipLaunchKernelGGL((k_pixelnorm_lrelu_fwd<16, rd_bf16_t>), grid, dim3(256), 0, st, y16, h16, rinv, npix);
+    else return bad_arg(h, "pixelnorm: C must be 64/128/256");
+  }
+  else if (C == 256) hipLaunchKernelGGL(k_pixelnorm_lrelu_fwd<64>, grid, dim3(256), 0, st, y, hout, rinv, npix);
   else if (C == 128) hipLaunchKernelGGL(k_pixelnorm_lrelu_fwd<32>, grid, dim3(256), 0, st, y, hout, rinv, npix);
   else if (C == 64) hipLaunchKernelGGL(k_pixelnorm_lrelu_fwd<16>, grid, dim3(256), 0, st, y, hout, rinv, npix);
   else return bad_arg(h, "pixelnorm: C must be 64/128/256");
@@ -859,29 +903,43 @@ static int launch_pn_fwd(rdgan_handle* h, const float* y, float* hout, float* ri
   return 0;
 }
 static int launch_pn_bwd(rdgan_handle* h, const float* g, const float* hh, const float* rinv, float* dy, long npix, int C,
-                         int pool, int D, int H, int W, hipStream_t st) {
+                         int pool, int D, int H, int W, hipStream_t st, bool a16 = false) {
   long threads = npix * (C / 4);
   dim3 grid((unsigned)((threads + 255) / 256));
 #define RD_PNB(LP, PO) hipLaunchKernelGGL((k_pn_lrelu_bwd<LP, PO>), grid, dim3(256), 0, st, g, hh, rinv, dy, npix, D, H, W)
-  if (C == 256) { if (pool) RD_PNB(64, 1); else RD_PNB(64, 0); }
+#define RD_PNB16(LP) hipLaunchKernelGGL((k_pn_lrelu_bwd<LP, 0, rd_bf16_t>), grid, dim3(256), 0, st, (const rd_bf16_t*)g, \
+                                        (const rd_bf16_t*)hh, rinv, (rd_bf16_t*)dy, npix, D, H, W)
+  if (a16) {
+    if (pool) return bad_arg(h, "pixelnorm bwd: the bf16 storage mode needs the collapsed form");
+    if (C == 256) RD_PNB16(64); else if (C == 128) RD_PNB16(32); else if (C == 64) RD_PNB16(16);
+    else return bad_arg(h, "pixelnorm bwd: C must be 64/128/256");
+  }
+  else if (C == 256) { if (pool) RD_PNB(64, 1); else RD_PNB(64, 0); }
   else if (C == 128) { if (pool) RD_PNB(32, 1); else RD_PNB(32, 0); }
   else if (C == 64) { if (pool) RD_PNB(16, 1); else RD_PNB(16, 0); }
   else return bad_arg(h, "pixelnorm bwd: C must be 64/128/256");
 #undef RD_PNB
+#undef RD_PNB16
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
 
 // PixelNorm+LeakyReLU backward over hour-plane pairs, also writing the pair sums gS (shared-centre backward)
 static int launch_pn_bwd_pairs(rdgan_handle* h, const float* g, const float* hh, const float* rinv, float* dy, float* gS,
-                               long npair, long HW, int C, void* dy16v, void* gS16v, hipStream_t st) {
+                               long npair, long HW, int C, hipStream_t st, bool a16 = false) {
   long threads = npair * (C / 4);
   dim3 grid((unsigned)((threads + 255) / 256));
-  unsigned short* dy16 = (unsigned short*)dy16v; unsigned short* gS16 = (unsigned short*)gS16v;
-  if (C == 256) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<64>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW, dy16, gS16);
-  else if (C == 128) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<32>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW, dy16, gS16);
-  else if (C == 64) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<16>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW, dy16, gS16);
+#define RD_PNP16(LP) hipLaunchKernelGGL((k_pn_lrelu_bwd_pairs<LP, rd_bf16_t>), grid, dim3(256), 0, st, (const rd_bf16_t*)g, \
+                                        (const rd_bf16_t*)hh, rinv, (rd_bf16_t*)dy, (rd_bf16_t*)gS, npair, HW)
+  if (a16) {
+    if (C == 256) RD_PNP16(64); else if (C == 128) RD_PNP16(32); else if (C == 64) RD_PNP16(16);
+    else return bad_arg(h, "pixelnorm bwd: C must be 64/128/256");
+  }
+  else if (C == 256) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<64>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
+  else if (C == 128) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<32>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
+  else if (C == 64) hipLaunchKernelGGL(k_pn_lrelu_bwd_pairs<16>, grid, dim3(256), 0, st, g, hh, rinv, dy, gS, npair, HW);
   else return bad_arg(h, "pixelnorm bwd: C must be 64/128/256");
+#undef RD_PNP16
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -986,6 +1044,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     for (int id : wg) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)MB));
     const int wd[] = {PL_D1F, PL_D2F, PL_D3F, PL_D4F};
     for (int id : wd) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)NB));
+    wneed = std::max(wneed, (size_t)MB * (RDGAN_NHOURS / 2) * 1728);      // k_g9_wgrad_pairs: [27][64] per (sample, plane pair)
   }
   h->wpartial_cap = wneed;
   h->cpartial_cap = (size_t)1024 * std::max(h->n_nodes, 256);
@@ -1051,22 +1110,11 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(h->fU[l], 48L * gch[l - 1] * gch[l]);
       }
       carve(h->fdE, MB * ne); carve(h->fgS, MB * ns);
-      {   // bf16 operand copies (2 bytes per element: half the floats)
+      {   // bf16 weight images (2 bytes per element: half the floats)
         float* p = nullptr;
-        h->bX[0] = h->bE[0] = h->bU[0] = nullptr;
-        for (int l = 1; l <= 3; ++l) {
-          const int* sd = h->gdim[l - 1];
-          const size_t nx = MB * (size_t)(sd[0] + 1) * sd[1] * sd[2] * gch[l - 1];
-          carve(p, nx / 2 + 8); h->bX[l] = p;
-          carve(p, nx / 2 + 8); h->bE[l] = p;
-          carve(p, 24L * gch[l - 1] * gch[l] + 8); h->bU[l] = p;
-        }
+        h->bU[0] = nullptr;
+        for (int l = 1; l <= 3; ++l) { carve(p, 24L * gch[l - 1] * gch[l] + 8); h->bU[l] = p; }
         carve(p, 24L * 256 * 256 + 8); h->bUT = p;
-        carve(p, MB * ns / 2 + 8); h->bgS = p;
-        carve(p, MB * ns + 8); h->bdy = p;
-        h->bScr_elems = std::max<size_t>((size_t)NB * h->dL[1] * 64, (size_t)MB * h->gpix[1] * 256);
-        carve(p, h->bScr_elems / 2 + 8); h->bScr = p;
-        carve(p, h->bScr_elems / 2 + 8); h->bScr2 = p;
         h->bWF[0] = h->bWF[1] = h->bWB[0] = h->bWB[1] = nullptr;
         for (int l = 2; l <= 4; ++l) {
           carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->bWF[l] = p;
@@ -1074,6 +1122,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         }
         carve(p, 32L * 256 * 256 + 8); h->bG1F = p;
         carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
+        carve(p, 32L * h->ldp1 + 8); h->bW1B = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
     }
@@ -1120,7 +1169,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!h || !name) return -2;
   if (!strcmp(name, "collapse")) { h->collapse = value ? 1 : 0; return 0; }
   if (!strcmp(name, "wave_specialized")) { h->wave_spec = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }   // 2 = also for small problems (tests)
-  if (!strcmp(name, "mfma_bf16")) { h->mfma_bf16 = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "bf16") || !strcmp(name, "mfma_bf16")) { h->a16 = value ? 1 : 0; return 0; }   // ("mfma_bf16": round-1 name)
   if (!strcmp(name, "g9_direct")) { h->g9_direct = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fast_fwd")) { h->fast_fwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value ? 1 : 0; return 0; }
@@ -1172,8 +1221,20 @@ static RdEpi epi_make(int mode, const float* bias = nullptr, const float* aux = 
                       uint32_t key = 0, uint32_t idx_base = 0) {
   RdEpi e; e.mode = mode; e.use_drop = use_drop; e.key = key; e.idx_base = idx_base; e.bias = bias; e.aux = aux;
   e.ksplit = 1; e.kpart = nullptr; e.kstride = 0; e.rinv = nullptr; e.gw = e.ghw = e.gq = 0;
-  e.addt = nullptr; e.addt_plane = 0; e.nametag = 0;
+  e.addt = nullptr; e.addt_plane = 0; e.nametag = 0; e.out16 = 0;
   return e;
+}
+// pointer arithmetic on an activation tensor of the workspace: bf16 elements in the storage mode, floats otherwise
+static inline float* act_off(const rdgan_handle* h, float* p, long elems) {
+  return (float*)((char*)p + elems * (h->a16 ? 2 : 4));
+}
+// bf16 storage mode needs the forms whose GEMMs all exist as bf16 kernels
+static int a16_check(rdgan_handle* h) {
+  if (!h->a16) return 0;
+  if (!h->collapse || !h->fast_fwd || !h->fast_bwd || !h->g9_direct)
+    return bad_arg(h, "bf16 storage mode needs the options collapse, fast_fwd, fast_bwd and g9_direct at 1");
+  if (4 * (size_t)(h->nd + 2) * (h->nd + 2) * sizeof(float) > 96 * 1024) return bad_arg(h, "bf16 storage mode: ndomain too large");
+  return 0;
 }
 
 // the shared-centre form pays where the hour axis of the block input is long enough for its (D+1)/D boundary plane
@@ -1184,6 +1245,8 @@ static bool gen_block_fast(const rdgan_handle* h, int l, int enabled) {
 static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, const float* cond, float* out, int B,
                             hipStream_t st) {
   const int nd = h->nd;
+  const bool a16 = h->a16 != 0;
+  RD_TRY(a16_check(h));
   // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
   RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, st));
   {
@@ -1192,6 +1255,9 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
                        RDGAN_LATENT_DIM, nd * nd * h->nc);
   }
   // Dense + LeakyReLU (T:326-327); the Reshape (T:328) is a view
+  if (a16) RD_TRY(launch_conv_a16(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, gp + h->goff[0], h->n_nodes, h->h0,
+                                  epi_make(RD_EPI_BIAS_LRELU, gp + h->goff[1]), st, -1, false, true));
+  else
   RD_TRY(launch_conv(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, gp + h->goff[0], h->n_nodes, h->h0,
                      epi_make(RD_EPI_BIAS_LRELU, gp + h->goff[1]), st, -1));
   float* hs[4] = {h->h0, h->h1, h->h2, h->h3};
@@ -1209,57 +1275,56 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       fastd_weight_map(wm);
       {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-        const bool bf16 = h->mfma_bf16 && h->gch[l - 1] % 64 == 0;
-        hipLaunchKernelGGL(k_diff_d, dim3(ew_blocks((long)B * (sd[0] + 1) * P / 4)), dim3(256), 0, st, hs[l - 1], h->fE[l], B, sd[0], P,
-                           bf16 ? (unsigned short*)h->bX[l] : nullptr, bf16 ? (unsigned short*)h->bE[l] : nullptr);
+        const dim3 dg(ew_blocks((long)B * (sd[0] + 1) * P / 4));
+        if (a16) hipLaunchKernelGGL(k_diff_d<rd_bf16_t>, dg, dim3(256), 0, st, (const rd_bf16_t*)hs[l - 1], (rd_bf16_t*)h->fE[l], B, sd[0], P);
+        else hipLaunchKernelGGL(k_diff_d<float>, dg, dim3(256), 0, st, (const float*)hs[l - 1], h->fE[l], B, sd[0], P);
         hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, Wl, h->fU[l], (int)cc, 48, wm);
+        if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->fU[l], h->bU[l], 48, h->gch[l - 1], h->gch[l], st));
       }
       const int pls = PL_F1WS + l - 1, ple = PL_F1FE + l - 1;
-      const bool bf = h->mfma_bf16 && h->gch[l - 1] % 64 == 0;
-      if (bf) {
-        ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-        RD_TRY(launch_weights_to_bf16_t(h, h->fU[l], h->bU[l], 48, h->gch[l - 1], h->gch[l], st));
-      }
-      if (bf) RD_TRY(launch_conv16(h, h->plans[pls], h->d_plans + pls, B, h->bX[l], h->bU[l], h->fgS, epi_make(RD_EPI_PLAIN), st,
-                                   RDGAN_TAG_GCONV_FWD));
+      RdEpi et = epi_make(RD_EPI_PLAIN);
+      et.out16 = a16;
+      if (a16) RD_TRY(launch_conv16(h, h->plans[pls], h->d_plans + pls, B, hs[l - 1], h->bU[l], h->fgS, et, st, RDGAN_TAG_GCONV_FWD));
       else
-      RD_TRY(launch_conv(h, h->plans[pls], h->d_plans + pls, B, hs[l - 1], h->fU[l], h->gch[l], h->fgS, epi_make(RD_EPI_PLAIN), st,
+      RD_TRY(launch_conv(h, h->plans[pls], h->d_plans + pls, B, hs[l - 1], h->fU[l], h->gch[l], h->fgS, et, st,
                          RDGAN_TAG_GCONV_FWD));
-      const bool fuse = conv_rows_owned(h->plans[ple], B);
+      const bool fuse = a16 ? conv16_rows_owned(h->plans[ple]) : conv_rows_owned(h->plans[ple], B);
       RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
       ep.rinv = rs[l];
       ep.addt = h->fgS; ep.addt_plane = 4 * sd[1] * sd[2] * h->gch[l];
       ep.nametag = l == 3;
-      if (bf) RD_TRY(launch_conv16(h, h->plans[ple], h->d_plans + ple, B, h->bE[l], h->bU[l], hs[l], ep, st,
-                                   l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
+      ep.out16 = a16;
+      if (a16) RD_TRY(launch_conv16(h, h->plans[ple], h->d_plans + ple, B, h->fE[l], h->bU[l], hs[l], ep, st,
+                                    l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
       else
       RD_TRY(launch_conv(h, h->plans[ple], h->d_plans + ple, B, h->fE[l], h->fU[l], h->gch[l], hs[l], ep, st,
                          l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
       if (!fuse) {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-        RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st));
+        RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st, a16));
       }
       continue;
     }
+    if (a16 && l != 1) return bad_arg(h, "bf16 storage mode: generator blocks 2 and 3 need the shared-centre form");
     if (h->collapse) {
       hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * h->gch[l - 1] * h->gch[l])), dim3(256), 0, st, Wl,
                          h->GWC[l], h->gch[l - 1] * h->gch[l]);
       Wl = h->GWC[l];
       pl = PL_G1FC + l - 1;
     }
-    const bool fuse = conv_rows_owned(h->plans[pl], B);       // PixelNorm+LeakyReLU in the GEMM epilogue
+    const bool fuse = a16 ? conv16_rows_owned(h->plans[pl]) : conv_rows_owned(h->plans[pl], B);       // PixelNorm+LeakyReLU in the GEMM epilogue
     RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
     ep.rinv = rs[l];
-    if (h->collapse && h->mfma_bf16 && l == 1) {     // mixed mode: block 1 (collapsed form) on bf16 operands
+    ep.out16 = a16;
+    if (a16) {     // block 1 (collapsed form, 64 taps) on the bf16 matrix pipe
       RD_TRY(launch_weights_to_bf16_t(h, h->GWC[1], h->bG1F, 64, h->gch[0], h->gch[1], st));
-      RD_TRY(conv_mixed(h, h->plans[pl], h->d_plans + pl, B, hs[0], (size_t)B * h->gpix[0] * h->gch[0], h->bG1F, hs[1], ep, st,
-                        RDGAN_TAG_GCONV_FWD));
+      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, hs[0], h->bG1F, hs[1], ep, st, RDGAN_TAG_GCONV_FWD));
     } else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], Wl, h->gch[l], hs[l], ep, st,
                        l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
     if (!fuse) {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-      RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st));
+      RD_TRY(launch_pn_fwd(h, hs[l], hs[l], rs[l], (long)B * h->gpix[l], h->gch[l], st, a16));
     }
   }
   // Conv3D 64->1 (T:345) as column GEMM + gather, bias, Softmax(axis=1) (T:347), check_numerics (T:349-350).
@@ -1270,11 +1335,16 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   if (gq && h->tapgather) {
     RdEpi e = epi_make(RD_EPI_TAPGATHER);
     e.gw = nd; e.ghw = nd * nd; e.gq = gq;
+    if (a16) RD_TRY(launch_conv_a16(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, e, st, -1, true, false));
+    else
     RD_TRY(launch_conv(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, e, st, -1));
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_tapsum_softmax<RDGAN_NHOURS>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->P9,
                        gp + h->goff[9], out, B, nd, nd, gq, h->d_flag);
   } else {
+    if (a16) RD_TRY(launch_conv_a16(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, epi_make(RD_EPI_PLAIN), st, -1,
+                                    true, false));
+    else
     RD_TRY(launch_conv(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, epi_make(RD_EPI_PLAIN), st, -1));
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_colgather_softmax, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->P9, gp + h->goff[9],
@@ -1313,34 +1383,16 @@ static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st)
   // W1 [27*Cin][64] -> W1T [64][ldp1] (columns (tap,ci), zero padded)
   RD_TRY(launch_transpose(h, dp + h->doff[0], h->W1T, 1, 27 * h->Cin, 64, h->ldp1, st));
   if (h->CP != h->Cin) hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, dp + h->doff[0], h->W1P, h->Cin, h->CP);
-  if (h->mfma_bf16)
+  if (h->a16) {
     for (int l = 2; l <= 4; ++l) {
       const float* w = dp + h->doff[2 * (l - 1)];
       RD_TRY(launch_weights_to_bf16_t(h, w, h->bWF[l], 27, h->dch[l - 1], h->dch[l], st));
       RD_TRY(launch_to_bf16(h, w, h->bWB[l], 27L * h->dch[l - 1] * h->dch[l], st));
     }
+    hipLaunchKernelGGL(k_w1_to_bf16, dim3(ew_blocks(64L * h->ldp1)), dim3(256), 0, st, dp + h->doff[0], (rd_bf16_t*)h->bW1B,
+                       27 * h->Cin, h->ldp1);
+  }
   return 0;
-}
-
-static int conv_mixed(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, size_t n_src, const void* w16,
-                      float* dst, const RdEpi& epi, hipStream_t st, int tag) {
-  if (n_src > h->bScr_elems) return bad_arg(h, "conv_mixed: bf16 scratch too small");
-  {
-    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    RD_TRY(launch_to_bf16(h, src, h->bScr, (long)n_src, st));
-  }
-  return launch_conv16(h, hp, dp, B, h->bScr, w16, dst, epi, st, tag);
-}
-// mixed mode weight gradient on bf16 copies made on the fly
-static int wgrad_mixed(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, size_t n_src, const float* dy,
-                       size_t n_dy, float* dW, hipStream_t st, int tag) {
-  if (n_src > h->bScr_elems || n_dy > h->bScr_elems) return bad_arg(h, "wgrad_mixed: bf16 scratch too small");
-  {
-    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    RD_TRY(launch_to_bf16(h, src, h->bScr, (long)n_src, st));
-    RD_TRY(launch_to_bf16(h, dy, h->bScr2, (long)n_dy, st));
-  }
-  return launch_wgrad16(h, hp, dp, B, h->bScr, h->bScr2, dW, h->wpartial, h->wpartial_cap, st, tag);
 }
 
 // D1's forward weights: the caller's [27][Cin][64] kernel, or its zero-padded [27][CP][64] copy when CP > Cin
@@ -1351,21 +1403,28 @@ static inline const float* d1_weights(const rdgan_handle* h, const float* dp) {
 // forward over NBt samples already laid out in h->cin; writes h->dh[1..4], h->v
 static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64_t seed, hipStream_t st) {
   const int use_drop = seed != 0;
+  const bool a16 = h->a16 != 0;
   const float* in = h->cin;
   for (int l = 1; l <= 4; ++l) {
     int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
-    const RdEpi ep = epi_make(RD_EPI_BIAS_LRELU_DROP, dp + h->doff[2 * (l - 1) + 1], nullptr, use_drop,
-                              rd_make_key(seed, RD_STREAM_D1 + l - 1), 0);
-    if (l >= 2 && h->mfma_bf16)
-      RD_TRY(conv_mixed(h, h->plans[pl], h->d_plans + pl, NBt, in, (size_t)NBt * h->dL[l - 1] * h->dch[l - 1], h->bWF[l], h->dh[l], ep,
-                        st, RDGAN_TAG_CRITIC_GEMM));
+    RdEpi ep = epi_make(RD_EPI_BIAS_LRELU_DROP, dp + h->doff[2 * (l - 1) + 1], nullptr, use_drop,
+                        rd_make_key(seed, RD_STREAM_D1 + l - 1), 0);
+    ep.out16 = a16;
+    if (a16 && l == 1)
+      RD_TRY(launch_conv_a16(h, h->plans[pl], h->d_plans + pl, NBt, in, d1_weights(h, dp), h->dch[l], h->dh[l], ep, st,
+                             RDGAN_TAG_CRITIC_GEMM, false, true));
+    else if (a16)
+      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->bWF[l], h->dh[l], ep, st, RDGAN_TAG_CRITIC_GEMM));
     else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
                        h->dch[l], h->dh[l], ep, st, RDGAN_TAG_CRITIC_GEMM));
     in = h->dh[l];
   }
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-  hipLaunchKernelGGL(k_critic_dense_fwd, dim3(NBt), dim3(256), 0, st, h->dh[4], dp + h->doff[8], dp + h->doff[9], h->v, h->F);
+  if (a16) hipLaunchKernelGGL(k_critic_dense_fwd<rd_bf16_t>, dim3(NBt), dim3(256), 0, st, (const rd_bf16_t*)h->dh[4], dp + h->doff[8],
+                              dp + h->doff[9], h->v, h->F);
+  else hipLaunchKernelGGL(k_critic_dense_fwd<float>, dim3(NBt), dim3(256), 0, st, (const float*)h->dh[4], dp + h->doff[8],
+                          dp + h->doff[9], h->v, h->F);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -1373,17 +1432,21 @@ static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64
 // input-gradient chain u4 -> u1 over NBt samples (mode 0: critic step 3B batch, 1: generator step)
 static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, int mode, uint64_t seed, hipStream_t st) {
   const int use_drop = seed != 0;
+  const bool a16 = h->a16 != 0;
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_critic_top_bwd, dim3(ew_blocks((long)NBt * h->F)), dim3(256), 0, st, h->dh[4], dp + h->doff[8],
-                       h->du[4], NBt, h->F, B, mode, use_drop, rd_make_key(seed, RD_STREAM_D1 + 3));
+    const dim3 g(ew_blocks((long)NBt * h->F));
+    if (a16) hipLaunchKernelGGL(k_critic_top_bwd<rd_bf16_t>, g, dim3(256), 0, st, (const rd_bf16_t*)h->dh[4], dp + h->doff[8],
+                                (rd_bf16_t*)h->du[4], NBt, h->F, B, mode, use_drop, rd_make_key(seed, RD_STREAM_D1 + 3));
+    else hipLaunchKernelGGL(k_critic_top_bwd<float>, g, dim3(256), 0, st, (const float*)h->dh[4], dp + h->doff[8],
+                            h->du[4], NBt, h->F, B, mode, use_drop, rd_make_key(seed, RD_STREAM_D1 + 3));
   }
   for (int l = 4; l >= 2; --l) {
     int pl = PL_D2B + l - 2;
-    const RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, h->dh[l - 1], use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 2), 0);
-    if (h->mfma_bf16)
-      RD_TRY(conv_mixed(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], (size_t)NBt * h->dL[l] * h->dch[l], h->bWB[l], h->du[l - 1], ep,
-                        st, RDGAN_TAG_CRITIC_GEMM));
+    RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, h->dh[l - 1], use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 2), 0);
+    ep.out16 = a16;
+    if (a16)
+      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->bWB[l], h->du[l - 1], ep, st, RDGAN_TAG_CRITIC_GEMM));
     else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->DWT[l], h->dch[l - 1], h->du[l - 1], ep, st,
                        RDGAN_TAG_CRITIC_GEMM));
@@ -1393,6 +1456,10 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
 
 // dD/d(sample channel) for `B` samples whose u1 starts at u1: column GEMM + col2im -> h->g0
 static int critic_input_grad(rdgan_handle* h, const float* u1, int B, hipStream_t st) {
+  if (h->a16)     // bf16 u1 against the bf16 first kernel [ldp1][64], fp32 column matrix
+    RD_TRY(launch_conv16(h, h->plans[PL_D1B], h->d_plans + PL_D1B, B, u1, h->bW1B, h->P1, epi_make(RD_EPI_PLAIN), st,
+                         RDGAN_TAG_CRITIC_GEMM));
+  else
   RD_TRY(launch_conv(h, h->plans[PL_D1B], h->d_plans + PL_D1B, B, u1, h->W1T, h->ldp1, h->P1, epi_make(RD_EPI_PLAIN), st,
                      RDGAN_TAG_CRITIC_GEMM));
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
@@ -1407,7 +1474,8 @@ extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params,
   if (!h || !critic_params || !sample || !cond || !out) return bad_arg(h, "critic_forward: null pointer");
   if (B < 1 || B > h->NB) return bad_arg(h, "critic_forward: B outside [1, 3*max_batch]");
   hipStream_t st = (hipStream_t)stream;
-  if (h->mfma_bf16) RD_TRY(prep_critic_weights(h, critic_params, st));      // (also makes the bf16 kernels of layers 2-4)
+  RD_TRY(a16_check(h));
+  if (h->a16) RD_TRY(prep_critic_weights(h, critic_params, st));      // (also makes the bf16 kernels of layers 2-4)
   else if (h->CP != h->Cin)
     hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, critic_params + h->doff[0], h->W1P, h->Cin, h->CP);
   hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, sample,
@@ -1437,6 +1505,7 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   if (critic_ready_event) RD_CHECK(h, hipStreamWaitEvent(st, (hipEvent_t)critic_ready_event, 0));
   RD_TRY(prep_critic_weights(h, dp, st));
   // [real; fake; alpha*real + (1-alpha)*fake] with the condition as 2nd channel (T:275-282, T:376)
+  const bool a16 = h->a16 != 0;
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, x_real, h->fake, cond,
@@ -1446,7 +1515,7 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   RD_TRY(critic_forward_impl(h, dp, NBt, seed, st));           // T:372,373,379 as one batch
   RD_TRY(critic_dgrad_chain(h, dp, NBt, B, 0, seed, st));       // dL/dh for real|fake, dD/dh for x_hat
   // gradient penalty (T:238-241, T:382): g0 = dD/dx_hat, n = ||g0||, r0 = d(10 mean((n-1)^2))/dg0
-  RD_TRY(critic_input_grad(h, h->du[1] + (long)2 * B * h->dL[1] * 64, B, st));
+  RD_TRY(critic_input_grad(h, act_off(h, h->du[1], (long)2 * B * h->dL[1] * 64), B, st));
   float* cin_hat = h->cin + (long)2 * B * h->dL[0] * h->CP;
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
@@ -1458,11 +1527,14 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
     for (int l = 1; l <= 4; ++l) {
       int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
       long third = (long)2 * B * h->dL[l] * h->dch[l];
-      float* dst = h->dh[l] + third;
-      const RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, dst, use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 1), (uint32_t)third);
-      if (l >= 2 && h->mfma_bf16)
-        RD_TRY(conv_mixed(h, h->plans[pl], h->d_plans + pl, B, in, (size_t)B * h->dL[l - 1] * h->dch[l - 1], h->bWF[l], dst, ep, st,
-                          RDGAN_TAG_CRITIC_GEMM));
+      float* dst = act_off(h, h->dh[l], third);
+      RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, dst, use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 1), (uint32_t)third);
+      ep.out16 = a16;
+      if (a16 && l == 1)
+        RD_TRY(launch_conv_a16(h, h->plans[pl], h->d_plans + pl, B, in, d1_weights(h, dp), h->dch[l], dst, ep, st,
+                               RDGAN_TAG_CRITIC_GEMM, false, true));
+      else if (a16)
+        RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, in, h->bWF[l], dst, ep, st, RDGAN_TAG_CRITIC_GEMM));
       else
       RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
                          h->dch[l], dst, ep, st, RDGAN_TAG_CRITIC_GEMM));
@@ -1474,20 +1546,23 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
     int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
     const float* in = l == 1 ? h->cin : h->dh[l - 1];
     const bool padded = l == 1 && h->CP != h->Cin;   // D1 with padding channels: gradient of the padded kernel, then drop the pad rows
-    if (h->mfma_bf16 && l >= 2 && wgrad16_ok(h->plans[pl], NBt))     // layers 2-4 on bf16 operands
-      RD_TRY(wgrad_mixed(h, h->plans[pl], h->d_plans + pl, NBt, in, (size_t)NBt * h->dL[l - 1] * h->dch[l - 1], h->du[l],
-                         (size_t)NBt * h->dL[l] * h->dch[l], grad + h->doff[2 * (l - 1)], st, RDGAN_TAG_CRITIC_GEMM));
-    else
+    if (a16 && l >= 2) {      // layers 2-4: bf16 activations against bf16 output gradients
+      if (!wgrad16_ok(h->plans[pl], NBt)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this critic layer");
+      RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], grad + h->doff[2 * (l - 1)], h->wpartial,
+                            h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM));
+    } else
     RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], padded ? h->dW1P : grad + h->doff[2 * (l - 1)],
-                        h->wpartial, h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM));
+                        h->wpartial, h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM, a16));
     if (padded) hipLaunchKernelGGL(k_unpad_w1, dim3(27), dim3(256), 0, st, h->dW1P, grad + h->doff[0], h->Cin, h->CP);
     // bias gradient: only the real|fake passes reach the loss through the bias (the penalty term does not)
-    RD_TRY(launch_colsum(h, h->du[l], (long)2 * B * h->dL[l], h->dch[l], grad + h->doff[2 * (l - 1) + 1], st));
+    RD_TRY(launch_colsum(h, h->du[l], (long)2 * B * h->dL[l], h->dch[l], grad + h->doff[2 * (l - 1) + 1], st, a16));
   }
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_critic_dense_wgrad, dim3((h->F + 15) / 16), dim3(256), 0, st, h->dh[4], grad + h->doff[8], NBt,
-                       h->F, B);
+    if (a16) hipLaunchKernelGGL(k_critic_dense_wgrad<rd_bf16_t>, dim3((h->F + 15) / 16), dim3(256), 0, st, (const rd_bf16_t*)h->dh[4],
+                                grad + h->doff[8], NBt, h->F, B);
+    else hipLaunchKernelGGL(k_critic_dense_wgrad<float>, dim3((h->F + 15) / 16), dim3(256), 0, st, (const float*)h->dh[4],
+                            grad + h->doff[8], NBt, h->F, B);
     RD_CHECK(h, hipMemsetAsync(grad + h->doff[9], 0, sizeof(float), st));   // sum of dv over real|fake = 0
     RD_CHECK(h, hipMemsetAsync(grad + h->n_critic, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));
     hipLaunchKernelGGL(k_critic_losses, dim3(1), dim3(256), 0, st, h->v, h->gpv, grad + h->n_critic, B, RD_GP_WEIGHT, h->d_flag);
@@ -1527,6 +1602,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   RD_TRY(critic_forward_impl(h, dp, B, seed, st));              // critic frozen, dropout active (T:395,405)
   RD_TRY(critic_dgrad_chain(h, dp, B, B, 1, seed, st));
   RD_TRY(critic_input_grad(h, h->du[1], B, st));                 // g0 = dL/d fake
+  const bool a16 = h->a16 != 0;
   const long npix3 = (long)B * h->gpix[3];
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
@@ -1540,17 +1616,23 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   const size_t g9_lds = 4 * (size_t)(nd + 2) * (nd + 2) * sizeof(float);
   const bool g9_direct = h->g9_direct && g9_lds <= 96 * 1024 &&
                          (size_t)B * (RDGAN_NHOURS / 2) * 1728 <= h->wpartial_cap;
+  if (a16 && !g9_direct) return bad_arg(h, "bf16 storage mode needs the direct backward of the last conv (g9_direct)");
   if (g9_direct) {
     ProfScope ps(h, RDGAN_TAG_GCONV_WGRAD, st);
     const size_t lds = std::max<size_t>(g9_lds, 4 * 27 * 16 * sizeof(f32x4));
     static bool attr_done = false;
     if (!attr_done) {
-      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_wgrad_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_bwd_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_wgrad_pairs<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_bwd_pairs<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_wgrad_pairs<rd_bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_bwd_pairs<rd_bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       attr_done = true;
     }
     const int nwg = B * (RDGAN_NHOURS / 2);
-    hipLaunchKernelGGL(k_g9_wgrad_pairs, dim3(nwg), dim3(256), lds, st, h->dl, h->h3, h->wpartial, RDGAN_NHOURS, nd, nd);
+    if (a16) hipLaunchKernelGGL(k_g9_wgrad_pairs<rd_bf16_t>, dim3(nwg), dim3(256), lds, st, h->dl, (const rd_bf16_t*)h->h3, h->wpartial,
+                                RDGAN_NHOURS, nd, nd);
+    else hipLaunchKernelGGL(k_g9_wgrad_pairs<float>, dim3(nwg), dim3(256), lds, st, h->dl, (const float*)h->h3, h->wpartial,
+                            RDGAN_NHOURS, nd, nd);
     hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(256), 0, st, h->wpartial, nwg, 1728, grad + h->goff[8]);
   } else {
     {
@@ -1575,6 +1657,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
     collapsed_dgrad_slice_map(map.src);
     for (int l = 1; l <= 3; ++l) {   // Wd[q][Cout][Cin] <- Wc (written by gen_forward_impl above unless that block ran in the shared-centre form)
       if (gen_block_fast(h, l, h->fast_bwd)) continue;
+      if (a16) continue;              // (block 1 reads the bf16 image of Wc re-ordered by tap instead, below)
       if (gen_block_fast(h, l, h->fast_fwd))
         hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * h->gch[l - 1] * h->gch[l])), dim3(256), 0, st,
                            gp + h->goff[2 * l], h->GWC[l], h->gch[l - 1] * h->gch[l]);
@@ -1586,24 +1669,24 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
     // shared-centre backward only where the hour axis is long enough to pay for its (D+1)/D boundary plane
     const bool fast = gen_block_fast(h, l, h->fast_bwd);
     if (l == 3 && g9_direct) {
-      // input gradient of the 64 -> 1 conv + block 3's PixelNorm+LeakyReLU backward (+ plane-pair sums, bf16 copies)
+      // input gradient of the 64 -> 1 conv + block 3's PixelNorm+LeakyReLU backward (+ plane-pair sums)
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-      const bool bf = fast && h->mfma_bf16;
-      hipLaunchKernelGGL(k_g9_bwd_pairs, dim3(B * (RDGAN_NHOURS / 2)), dim3(256), g9_lds, st, h->dl, gp + h->goff[8], hs[3], rs[3],
-                         dys[3], fast ? h->fgS : (float*)nullptr, RDGAN_NHOURS, nd, nd,
-                         bf ? (unsigned short*)h->bdy : (unsigned short*)nullptr, bf ? (unsigned short*)h->bgS : (unsigned short*)nullptr);
+      if (a16) hipLaunchKernelGGL(k_g9_bwd_pairs<rd_bf16_t>, dim3(B * (RDGAN_NHOURS / 2)), dim3(256), g9_lds, st, h->dl, gp + h->goff[8],
+                                  (const rd_bf16_t*)hs[3], rs[3], (rd_bf16_t*)dys[3], fast ? (rd_bf16_t*)h->fgS : (rd_bf16_t*)nullptr,
+                                  RDGAN_NHOURS, nd, nd);
+      else hipLaunchKernelGGL(k_g9_bwd_pairs<float>, dim3(B * (RDGAN_NHOURS / 2)), dim3(256), g9_lds, st, h->dl, gp + h->goff[8],
+                              (const float*)hs[3], rs[3], dys[3], fast ? h->fgS : (float*)nullptr, RDGAN_NHOURS, nd, nd);
       RD_CHECK(h, hipGetLastError());
     } else if (fast) {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
       const long HW = (long)h->gdim[l][1] * h->gdim[l][2];
-      const bool bf = h->mfma_bf16 != 0;       // the mixed mode's GEMMs read the bf16 copies written here
       RD_TRY(launch_pn_bwd_pairs(h, l == 3 ? h->gh3 : gups[l + 1], hs[l], rs[l], dys[l], h->fgS, (long)B * h->gdim[l - 1][0] * HW,
-                                 HW, h->gch[l], bf ? h->bdy : nullptr, bf ? h->bgS : nullptr, st));
+                                 HW, h->gch[l], st, a16));
     } else {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-      if (l == 3) RD_TRY(launch_pn_bwd(h, h->gh3, hs[3], rs[3], dys[3], npix3, 64, 0, 0, 0, 0, st));
+      if (l == 3) RD_TRY(launch_pn_bwd(h, h->gh3, hs[3], rs[3], dys[3], npix3, 64, 0, 0, 0, 0, st, a16));
       else RD_TRY(launch_pn_bwd(h, gups[l + 1], hs[l], rs[l], dys[l], (long)B * h->gpix[l], h->gch[l], col ? 0 : 1,
-                                h->gdim[l][0], h->gdim[l][1], h->gdim[l][2], st));
+                                h->gdim[l][0], h->gdim[l][1], h->gdim[l][2], st, a16));
     }
     const long cc = (long)h->gch[l - 1] * h->gch[l];
     if (fast) {
@@ -1616,39 +1699,33 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
         if (!gen_block_fast(h, l, h->fast_fwd)) {      // (otherwise the forward pass above has left both)
-          hipLaunchKernelGGL(k_diff_d, dim3(ew_blocks((long)B * (D + 1) * P / 4)), dim3(256), 0, st, hs[l - 1], h->fE[l], B, D, P,
-                             (unsigned short*)nullptr, (unsigned short*)nullptr);
+          hipLaunchKernelGGL(k_diff_d<float>, dim3(ew_blocks((long)B * (D + 1) * P / 4)), dim3(256), 0, st, (const float*)hs[l - 1],
+                             h->fE[l], B, D, P);
           hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, gp + h->goff[2 * l], h->fU[l],
                              (int)cc, 48, wm);
         }
       }
-      const bool bf = h->mfma_bf16 && gen_block_fast(h, l, h->fast_fwd) && wgrad16_ok(h->plans[PL_F1WS + l - 1], B);
-      // (bf16 copies: plane sums and output gradient from k_pn_lrelu_bwd_pairs, x and E from the forward's k_diff_d)
+      // weight gradients of the three tap groups: E[s] x even planes, x x plane sums, E[s+1] x odd planes
       const float* wsrc[3] = {h->fE[l], hs[l - 1], h->fE[l]};
       const float* wdy[3] = {dys[l], h->fgS, dys[l]};
-      const void* wsrc16[3] = {h->bE[l], h->bX[l], h->bE[l]};
-      const void* wdy16[3] = {h->bdy, h->bgS, h->bdy};
       for (int g = 0; g < 3; ++g) {
         const int pl = PL_F1WA + 3 * g + l - 1;
-        if (bf) RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, B, wsrc16[g], wdy16[g], h->fdU, h->wpartial, h->wpartial_cap, st,
-                                      RDGAN_TAG_GCONV_WGRAD));
-        else
+        if (a16) {
+          if (!wgrad16_ok(h->plans[pl], B)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this block");
+          RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, B, wsrc[g], wdy[g], h->fdU, h->wpartial, h->wpartial_cap, st,
+                                RDGAN_TAG_GCONV_WGRAD));
+        } else
         RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, B, wsrc[g], wdy[g], h->fdU, h->wpartial, h->wpartial_cap, st,
                             RDGAN_TAG_GCONV_WGRAD));
       }
       hipLaunchKernelGGL(k_weight_transform_adj, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->fdU, grad + h->goff[2 * l],
                          (int)cc, 48, wm);
-      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
-      {
-        RdSliceMap map;
-        fastd_dgrad_slice_map(map.src);
-        hipLaunchKernelGGL(k_transpose_map, dim3((h->gch[l] + 31) / 32, (h->gch[l - 1] + 31) / 32, 48), dim3(256), 0, st, h->fU[l],
-                           h->fUT, h->gch[l - 1], h->gch[l], map);
-      }
+      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st, a16));
       const int pbs = PL_F1BS + l - 1, pbe = PL_F1BE + l - 1;
-      if (h->mfma_bf16 && h->gch[l] % 64 == 0) {
-        // bf16 operands: plane sums, output gradient, and the forward forms U re-ordered by tap ([Cin][Cout] is already the
-        // [N][K] layout of these GEMMs)
+      RdEpi eb = epi_make(RD_EPI_PLAIN);
+      eb.out16 = a16;
+      if (a16) {
+        // the forward forms U re-ordered by tap ([Cin][Cout] is already the [N][K] layout of these GEMMs)
         RdSliceMap map;
         fastd_dgrad_slice_map(map.src);
         {
@@ -1656,38 +1733,46 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
           hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 48), dim3(256), 0, st,
                              h->fU[l], (unsigned short*)h->bUT, cc, map);
         }
-        RD_TRY(launch_conv16(h, h->plans[pbs], h->d_plans + pbs, B, h->bgS, h->bUT, gups[l], epi_make(RD_EPI_PLAIN), st,
-                             RDGAN_TAG_GCONV_DGRAD));
-        RD_TRY(launch_conv16(h, h->plans[pbe], h->d_plans + pbe, B, h->bdy, h->bUT, h->fdE, epi_make(RD_EPI_PLAIN), st,
-                             RDGAN_TAG_GCONV_DGRAD));
+        RD_TRY(launch_conv16(h, h->plans[pbs], h->d_plans + pbs, B, h->fgS, h->bUT, gups[l], eb, st, RDGAN_TAG_GCONV_DGRAD));
+        RD_TRY(launch_conv16(h, h->plans[pbe], h->d_plans + pbe, B, dys[l], h->bUT, h->fdE, eb, st, RDGAN_TAG_GCONV_DGRAD));
       } else {
-      RD_TRY(launch_conv(h, h->plans[pbs], h->d_plans + pbs, B, h->fgS, h->fUT, h->gch[l - 1], gups[l], epi_make(RD_EPI_PLAIN), st,
-                         RDGAN_TAG_GCONV_DGRAD));
-      RD_TRY(launch_conv(h, h->plans[pbe], h->d_plans + pbe, B, dys[l], h->fUT, h->gch[l - 1], h->fdE, epi_make(RD_EPI_PLAIN), st,
-                         RDGAN_TAG_GCONV_DGRAD));
+        {
+          RdSliceMap map;
+          fastd_dgrad_slice_map(map.src);
+          hipLaunchKernelGGL(k_transpose_map, dim3((h->gch[l] + 31) / 32, (h->gch[l - 1] + 31) / 32, 48), dim3(256), 0, st, h->fU[l],
+                             h->fUT, h->gch[l - 1], h->gch[l], map);
+        }
+        RD_TRY(launch_conv(h, h->plans[pbs], h->d_plans + pbs, B, h->fgS, h->fUT, h->gch[l - 1], gups[l], eb, st,
+                           RDGAN_TAG_GCONV_DGRAD));
+        RD_TRY(launch_conv(h, h->plans[pbe], h->d_plans + pbe, B, dys[l], h->fUT, h->gch[l - 1], h->fdE, eb, st,
+                           RDGAN_TAG_GCONV_DGRAD));
       }
       {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-        hipLaunchKernelGGL(k_combine_dx, dim3(ew_blocks((long)B * D * P / 4)), dim3(256), 0, st, gups[l], h->fdE, B, D, P);
+        const dim3 cg(ew_blocks((long)B * D * P / 4));
+        if (a16) hipLaunchKernelGGL(k_combine_dx<rd_bf16_t>, cg, dim3(256), 0, st, (rd_bf16_t*)gups[l], (const rd_bf16_t*)h->fdE, B, D, P);
+        else hipLaunchKernelGGL(k_combine_dx<float>, cg, dim3(256), 0, st, gups[l], (const float*)h->fdE, B, D, P);
       }
     } else if (col) {
       int plf = PL_G1FC + l - 1, plb = PL_G1BC + l - 1;
-      if (h->mfma_bf16 && l == 1 && wgrad16_ok(h->plans[plf], B))
-        RD_TRY(wgrad_mixed(h, h->plans[plf], h->d_plans + plf, B, hs[0], (size_t)B * h->gpix[0] * h->gch[0], dys[1],
-                           (size_t)B * h->gpix[1] * h->gch[1], h->dWc, st, RDGAN_TAG_GCONV_WGRAD));
-      else
+      if (a16) {
+        if (l != 1 || !wgrad16_ok(h->plans[plf], B)) return bad_arg(h, "bf16 storage mode: unsupported collapsed block");
+        RD_TRY(launch_wgrad16(h, h->plans[plf], h->d_plans + plf, B, hs[0], dys[1], h->dWc, h->wpartial, h->wpartial_cap, st,
+                              RDGAN_TAG_GCONV_WGRAD));
+      } else
       RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap,
                           st, RDGAN_TAG_GCONV_WGRAD));
       hipLaunchKernelGGL(k_fold_collapsed_wgrad, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->dWc,
                          grad + h->goff[2 * l], (int)cc);
-      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
-      if (h->mfma_bf16 && l == 1) {      // mixed mode: the collapsed forms re-ordered by tap are already [N = Cin][K = Cout]
+      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st, a16));
+      if (a16) {      // the collapsed forms re-ordered by tap are already [N = Cin][K = Cout]
         RdSliceMap map;
         collapsed_dgrad_slice_map(map.src);
         hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 64), dim3(256), 0, st,
                            h->GWC[1], (unsigned short*)h->bG1B, cc, map);
-        RD_TRY(conv_mixed(h, h->plans[plb], h->d_plans + plb, B, dys[1], (size_t)B * h->gpix[1] * h->gch[1], h->bG1B, gups[1],
-                          epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
+        RdEpi eb = epi_make(RD_EPI_PLAIN);
+        eb.out16 = 1;
+        RD_TRY(launch_conv16(h, h->plans[plb], h->d_plans + plb, B, dys[1], h->bG1B, gups[1], eb, st, RDGAN_TAG_GCONV_DGRAD));
       } else
       RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWD[l], h->gch[l - 1], gups[l],
                          epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
@@ -1703,11 +1788,15 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   // Dense (T:326): (pool the upsample adjoint,) LeakyReLU', then dW = xcat^T ga0, db = colsum(ga0)
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    if (col)
-      hipLaunchKernelGGL(k_lrelu_bwd, dim3(ew_blocks((long)B * h->gpix[0] * 64)), dim3(256), 0, st, h->gup1, h->h0, h->ga0,
+    const dim3 lg(ew_blocks((long)B * h->gpix[0] * 64));
+    if (col && a16)
+      hipLaunchKernelGGL(k_lrelu_bwd<rd_bf16_t>, lg, dim3(256), 0, st, (const rd_bf16_t*)h->gup1, (const rd_bf16_t*)h->h0, h->ga0,
+                         (long)B * h->gpix[0] * 64);
+    else if (col)
+      hipLaunchKernelGGL(k_lrelu_bwd<float>, lg, dim3(256), 0, st, (const float*)h->gup1, (const float*)h->h0, h->ga0,
                          (long)B * h->gpix[0] * 64);
     else
-      hipLaunchKernelGGL(k_pool_lrelu_bwd, dim3(ew_blocks((long)B * h->gpix[0] * 64)), dim3(256), 0, st, h->gup1, h->h0,
+      hipLaunchKernelGGL(k_pool_lrelu_bwd, lg, dim3(256), 0, st, h->gup1, h->h0,
                          h->ga0, (long)B * h->gpix[0], h->gdim[0][0], h->gdim[0][1], h->gdim[0][2], 256);
   }
   RD_TRY(launch_wgrad(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, h->ga0, grad + h->goff[0], h->wpartial,
@@ -1795,7 +1884,7 @@ extern "C" int rdgan_op_conv3d_wgrad_bf16(const float* x, const float* gy, float
 // bf16 (nearest even) on the device, products accumulate in fp32.  Cin % 64 == 0, Cout % 64 == 0.
 extern "C" int rdgan_op_conv3d_bf16(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W,
                                     int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d, int pad_h, int pad_w,
-                                    void* stream) {
+                                    int out_bf16, void* stream) {
   if (!x || !w || !y || Cin % 64 || Cout % 64) return -2;
   hipStream_t st = (hipStream_t)stream;
   TmpPlan tp;
@@ -1808,7 +1897,9 @@ extern "C" int rdgan_op_conv3d_bf16(const float* x, const float* w, const float*
   int rc = (int)e;
   if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
   if (rc == 0) rc = launch_weights_to_bf16_t(nullptr, w, wb, 27, Cin, Cout, st);
-  if (rc == 0) rc = launch_conv16(nullptr, tp.host, tp.dev, B, xb, wb, y, epi_make(bias ? RD_EPI_BIAS : RD_EPI_PLAIN, bias), st, -1);
+  RdEpi ep = epi_make(bias ? RD_EPI_BIAS : RD_EPI_PLAIN, bias);
+  ep.out16 = out_bf16 ? 1 : 0;
+  if (rc == 0) rc = launch_conv16(nullptr, tp.host, tp.dev, B, xb, wb, y, ep, st, -1);
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   if (xb) (void)hipFree(xb);
   if (wb) (void)hipFree(wb);
@@ -1887,6 +1978,43 @@ extern "C" int rdgan_op_conv3d_wgrad(const float* x, const float* gy, float* dw,
   return rc;
 }
 
+// Weight gradient of one tap group of the shared-centre form through the production plan
+// (plan_fastd_wgrad: 4 output-parity phases x 4 taps, an EVEN tap count, which is what lets the launcher pick the 256-row
+// tile at B * D*H*W >= 65536): group g = 0: src = E [B,D+1,H,W,Cin] against the even planes of dy [B,2D,2H,2W,Cout];
+// g = 1: src = x [B,D,H,W,Cin] against the plane-pair sums gS [B,D,2H,2W,Cout]; g = 2: E at j = s+1 against the odd planes.
+// dU [48][Cin][Cout]: the 16 forms g*16 .. g*16+15 are written.  bf16 = 1: operands rounded to bf16 on the device
+// (k_wgrad_gemm_ws16), fp32 accumulation and output.
+extern "C" int rdgan_op_fastd_wgrad(const float* src, const float* dy, float* dU, int B, int D, int H, int W, int Cin, int Cout,
+                                    int g, int bf16, void* stream) {
+  if (!src || !dy || !dU || g < 0 || g > 2 || Cin % 4 || Cout % 64) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  TmpPlan tp;
+  tp.host = plan_fastd_wgrad(D, H, W, Cin, Cout, g);
+  RD_TRY(tp.upload());
+  size_t need = wgrad_partial_need(tp.host, B);
+  float* partial = nullptr;
+  void *xb = nullptr, *gb = nullptr;
+  hipError_t e = hipMalloc((void**)&partial, need * sizeof(float));
+  int rc = (int)e;
+  if (rc == 0 && bf16) {
+    if (!wgrad16_ok(tp.host, B)) rc = -2;
+    const long nx = (long)B * tp.host.src_sample, ng = (long)B * tp.host.dst_sample;
+    if (rc == 0) rc = (int)hipMalloc(&xb, nx * 2);
+    if (rc == 0) rc = (int)hipMalloc(&gb, ng * 2);
+    if (rc == 0) rc = launch_to_bf16(nullptr, src, xb, nx, st);
+    if (rc == 0) rc = launch_to_bf16(nullptr, dy, gb, ng, st);
+    if (rc == 0) rc = launch_wgrad16(nullptr, tp.host, tp.dev, B, xb, gb, dU, partial, need, st, -1);
+  } else if (rc == 0) {
+    rdgan_handle fake_h;                   // (wave_spec = 1: the producer/consumer kernel, as in production)
+    rc = launch_wgrad(&fake_h, tp.host, tp.dev, B, src, dy, dU, partial, need, st, -1);
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  if (partial) (void)hipFree(partial);
+  if (xb) (void)hipFree(xb);
+  if (gb) (void)hipFree(gb);
+  return rc;
+}
+
 extern "C" int rdgan_op_pixelnorm_lrelu(const float* y, float* hout, float* rinv, long npix, int C, void* stream) {
   if (!y || !hout) return -2;
   RD_TRY(launch_pn_fwd(nullptr, y, hout, rinv, npix, C, (hipStream_t)stream));
@@ -1912,6 +2040,10 @@ extern "C" int rdgan_debug_activation(rdgan_handle* h, int which, float* out, lo
     src = h->dh[l]; cap = (long)h->NB * h->dL[l] * h->dch[l];
   }
   if (n > cap) return bad_arg(h, "debug_activation: n exceeds the tensor");
+  if (h->a16) {
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const rd_bf16_t*)src, out, n);
+    RD_CHECK(h, hipGetLastError());
+  } else
   RD_CHECK(h, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }

@@ -17,17 +17,7 @@ __device__ __forceinline__ float rd_seg_sum(float v) {   // sum over aligned gro
   for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// two floats -> packed bf16 pair (round to nearest even; v_cvt_pk_bf16_f32), and a float4 -> 4 bf16 (8 bytes)
-typedef __bf16 rd_bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int rd_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned rd_pack_bf16(float a, float b) {
-  rd_bf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;
-  return __builtin_bit_cast(unsigned, r);
-}
-__device__ __forceinline__ void rd_store_bf16x4(unsigned short* p, f32x4 v) {
-  rd_u32x2 o = {rd_pack_bf16(v.x, v.y), rd_pack_bf16(v.z, v.w)};
-  *(rd_u32x2*)p = o;
-}
+__device__ __forceinline__ void rd_store_bf16x4(unsigned short* p, f32x4 v) { rd_st4(p, v); }
 // block-wide sum, result valid in thread 0 (256 threads)
 __device__ __forceinline__ float rd_block_sum(float v, float* red) {
   v = rd_wave_sum(v);
@@ -52,22 +42,21 @@ __global__ void k_concat(const float* __restrict__ z, const float* __restrict__ 
 
 // G7+G8 (T:255-266, T:333): h = LeakyReLU(y / sqrt(mean_c(y^2) + 1e-8)); rinv = 1/sqrt(..) kept for backward.
 // In place allowed (h == y).  LP = C/4 lanes per pixel.
-template <int LP>
-__global__ void k_pixelnorm_lrelu_fwd(const float* __restrict__ y, float* __restrict__ h, float* __restrict__ rinv,
-                                      long npix) {
+template <int LP, typename T = float>
+__global__ void k_pixelnorm_lrelu_fwd(const T* y, T* h, float* __restrict__ rinv, long npix) {
   constexpr int C = LP * 4;
   const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long pix = gid / LP;
   const int sub = (int)(gid % LP);
   const bool ok = pix < npix;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (ok) v = *(const f32x4*)(y + pix * C + sub * 4);
+  if (ok) v = rd_ld4(y + pix * C + sub * 4);
   float ss = rd_seg_sum<LP>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
   float l2 = sqrtf(ss * (1.0f / C) + RD_PIXELNORM_EPS);
   if (ok) {
     f32x4 o;
     o.x = rd_lrelu(v.x / l2); o.y = rd_lrelu(v.y / l2); o.z = rd_lrelu(v.z / l2); o.w = rd_lrelu(v.w / l2);
-    *(f32x4*)(h + pix * C + sub * 4) = o;
+    rd_st4(h + pix * C + sub * 4, o);
     if (rinv && sub == 0) rinv[pix] = 1.0f / l2;
   }
 }
@@ -94,9 +83,9 @@ __device__ __forceinline__ f32x4 rd_pn_lrelu_bwd_row(f32x4 gh, f32x4 hv, float r
   o.z = ri * (gn.z - n.z * dot); o.w = ri * (gn.w - n.w * dot);
   return o;
 }
-template <int LP, int POOL>
-__global__ void k_pn_lrelu_bwd(const float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ rinv,
-                               float* __restrict__ dy, long npix, int D, int H, int W) {
+template <int LP, int POOL, typename T = float>
+__global__ void k_pn_lrelu_bwd(const T* __restrict__ g, const T* __restrict__ h, const float* __restrict__ rinv,
+                               T* __restrict__ dy, long npix, int D, int H, int W) {
   constexpr int C = LP * 4;
   const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long pix = gid / LP;
@@ -105,7 +94,7 @@ __global__ void k_pn_lrelu_bwd(const float* __restrict__ g, const float* __restr
   f32x4 gh = {0.f, 0.f, 0.f, 0.f}, hv = {0.f, 0.f, 0.f, 0.f};
   float ri = 0.f;
   if (ok) {
-    hv = *(const f32x4*)(h + pix * C + sub * 4);
+    hv = rd_ld4(h + pix * C + sub * 4);
     ri = rinv[pix];
     if (POOL) {
       long t = pix;
@@ -116,23 +105,21 @@ __global__ void k_pn_lrelu_bwd(const float* __restrict__ g, const float* __restr
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         long up = (((b * (2 * D) + 2 * d + (e >> 2)) * (2 * H) + 2 * hh + ((e >> 1) & 1)) * (2 * W) + 2 * w + (e & 1));
-        gh += *(const f32x4*)(g + up * C + sub * 4);
+        gh += rd_ld4(g + up * C + sub * 4);
       }
     } else {
-      gh = *(const f32x4*)(g + pix * C + sub * 4);
+      gh = rd_ld4(g + pix * C + sub * 4);
     }
   }
   const f32x4 o = rd_pn_lrelu_bwd_row<LP>(gh, hv, ri);
-  if (ok) *(f32x4*)(dy + pix * C + sub * 4) = o;
+  if (ok) rd_st4(dy + pix * C + sub * 4, o);
 }
 // same (POOL = 0) over PAIRS of hour planes (2s, 2s+1) of a block output, additionally writing their sum
 // gS[b][s][h][w][:] = dy[b][2s][h][w][:] + dy[b][2s+1][h][w][:] for the shared-centre backward (k_presum_d fused in).
 // npair = B * Ds * HW pixel pairs, HW = pixels per hour plane.
-// dy16 / gS16 (optional): bf16 copies of both outputs for the mixed mode's GEMMs.
-template <int LP>
-__global__ void k_pn_lrelu_bwd_pairs(const float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ rinv,
-                                     float* __restrict__ dy, float* __restrict__ gS, long npair, long HW,
-                                     unsigned short* __restrict__ dy16, unsigned short* __restrict__ gS16) {
+template <int LP, typename T = float>
+__global__ void k_pn_lrelu_bwd_pairs(const T* __restrict__ g, const T* __restrict__ h, const float* __restrict__ rinv,
+                                     T* __restrict__ dy, T* __restrict__ gS, long npair, long HW) {
   constexpr int C = LP * 4;
   const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long pr = gid / LP;
@@ -143,20 +130,15 @@ __global__ void k_pn_lrelu_bwd_pairs(const float* __restrict__ g, const float* _
   f32x4 ga = {0.f, 0.f, 0.f, 0.f}, ha = ga, gb = ga, hb = ga;
   float ra = 0.f, rb = 0.f;
   if (ok) {
-    ga = *(const f32x4*)(g + pixA * C + sub * 4); ha = *(const f32x4*)(h + pixA * C + sub * 4); ra = rinv[pixA];
-    gb = *(const f32x4*)(g + pixB * C + sub * 4); hb = *(const f32x4*)(h + pixB * C + sub * 4); rb = rinv[pixB];
+    ga = rd_ld4(g + pixA * C + sub * 4); ha = rd_ld4(h + pixA * C + sub * 4); ra = rinv[pixA];
+    gb = rd_ld4(g + pixB * C + sub * 4); hb = rd_ld4(h + pixB * C + sub * 4); rb = rinv[pixB];
   }
   const f32x4 oa = rd_pn_lrelu_bwd_row<LP>(ga, ha, ra);
   const f32x4 ob = rd_pn_lrelu_bwd_row<LP>(gb, hb, rb);
   if (ok) {
-    *(f32x4*)(dy + pixA * C + sub * 4) = oa;
-    *(f32x4*)(dy + pixB * C + sub * 4) = ob;
-    *(f32x4*)(gS + pr * C + sub * 4) = oa + ob;
-    if (dy16) {
-      rd_store_bf16x4(dy16 + pixA * C + sub * 4, oa);
-      rd_store_bf16x4(dy16 + pixB * C + sub * 4, ob);
-      rd_store_bf16x4(gS16 + pr * C + sub * 4, oa + ob);
-    }
+    rd_st4(dy + pixA * C + sub * 4, oa);
+    rd_st4(dy + pixB * C + sub * 4, ob);
+    rd_st4(gS + pr * C + sub * 4, oa + ob);
   }
 }
 
@@ -165,11 +147,11 @@ __global__ void k_pn_lrelu_bwd_pairs(const float* __restrict__ g, const float* _
 //   gh3[u][c] = sum_tap dl[u - off(tap)] * w9[tap][c];   dy = pn_lrelu_bwd(gh3, h3, rinv);   gS = dy[2s] + dy[2s+1]
 // One workgroup per (sample, hour-plane pair s); the four dl planes 2s-1 .. 2s+2 sit in LDS with a zero halo, a thread
 // owns one channel quad (its 27 x 4 kernel weights in registers) and walks the plane's pixels 16 at a time.
-// gS / dy16 / gS16 are optional (shared-centre backward, mixed mode).  H*W % 16 == 0.
+// gS is optional (shared-centre backward).  H*W % 16 == 0.  T = element type of h3 / dy / gS (bf16 storage mode).
+template <typename T = float>
 __global__ void __launch_bounds__(256)
-k_g9_bwd_pairs(const float* __restrict__ dl, const float* __restrict__ w9, const float* __restrict__ h3,
-               const float* __restrict__ rinv, float* __restrict__ dy, float* __restrict__ gS, int D, int H, int W,
-               unsigned short* __restrict__ dy16, unsigned short* __restrict__ gS16) {
+k_g9_bwd_pairs(const float* __restrict__ dl, const float* __restrict__ w9, const T* __restrict__ h3,
+               const float* __restrict__ rinv, T* __restrict__ dy, T* __restrict__ gS, int D, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) float dls[];     // [4][H+2][W+2]
   const int Ds = D / 2, PW = W + 2, PHW = (H + 2) * PW, HW = H * W;
   const long b = blockIdx.x / Ds;
@@ -200,24 +182,20 @@ k_g9_bwd_pairs(const float* __restrict__ dl, const float* __restrict__ w9, const
           ga += da * w; gb += db * w;
         }
     const long pixA = (b * D + 2 * s) * HW + it, pixB = pixA + HW, pr = (b * Ds + s) * HW + it;
-    const f32x4 ha = *(const f32x4*)(h3 + pixA * 64 + c4), hb = *(const f32x4*)(h3 + pixB * 64 + c4);
+    const f32x4 ha = rd_ld4(h3 + pixA * 64 + c4), hb = rd_ld4(h3 + pixB * 64 + c4);
     const f32x4 oa = rd_pn_lrelu_bwd_row<16>(ga, ha, rinv[pixA]);
     const f32x4 ob = rd_pn_lrelu_bwd_row<16>(gb, hb, rinv[pixB]);
-    *(f32x4*)(dy + pixA * 64 + c4) = oa;
-    *(f32x4*)(dy + pixB * 64 + c4) = ob;
-    if (gS) *(f32x4*)(gS + pr * 64 + c4) = oa + ob;
-    if (dy16) {
-      rd_store_bf16x4(dy16 + pixA * 64 + c4, oa);
-      rd_store_bf16x4(dy16 + pixB * 64 + c4, ob);
-      rd_store_bf16x4(gS16 + pr * 64 + c4, oa + ob);
-    }
+    rd_st4(dy + pixA * 64 + c4, oa);
+    rd_st4(dy + pixB * 64 + c4, ob);
+    if (gS) rd_st4(gS + pr * 64 + c4, oa + ob);
   }
 }
 // Weight gradient of the same conv without the im2col matrix: dW9[tap][c] = sum_u dl[u - off(tap)] * h3[u][c].
 // Same decomposition; each thread accumulates its channel quad over its pixels, the 16 pixel slots of the workgroup are
 // folded by shuffles and LDS, and partial[blockIdx][27][64] is folded by k_reduce_partials (deterministic).
+template <typename T = float>
 __global__ void __launch_bounds__(256)
-k_g9_wgrad_pairs(const float* __restrict__ dl, const float* __restrict__ h3, float* __restrict__ partial, int D, int H, int W) {
+k_g9_wgrad_pairs(const float* __restrict__ dl, const T* __restrict__ h3, float* __restrict__ partial, int D, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) float dls[];     // [4][H+2][W+2], reused for the fold
   const int Ds = D / 2, PW = W + 2, PHW = (H + 2) * PW, HW = H * W;
   const long b = blockIdx.x / Ds;
@@ -236,7 +214,7 @@ k_g9_wgrad_pairs(const float* __restrict__ dl, const float* __restrict__ h3, flo
   for (int it = threadIdx.x >> 4; it < HW; it += 16) {
     const int hh = it / W, ww = it - hh * W;
     const long pixA = (b * D + 2 * s) * HW + it;
-    const f32x4 ha = *(const f32x4*)(h3 + pixA * 64 + c4), hb = *(const f32x4*)(h3 + (pixA + HW) * 64 + c4);
+    const f32x4 ha = rd_ld4(h3 + pixA * 64 + c4), hb = rd_ld4(h3 + (pixA + HW) * 64 + c4);
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
@@ -468,12 +446,13 @@ __global__ void k_build_critic_input(const float* __restrict__ real, const float
 }
 
 // D6 (T:303-304): v[b] = h4[b,:] . w + bias; one block per sample.
-__global__ void k_critic_dense_fwd(const float* __restrict__ h4, const float* __restrict__ w, const float* __restrict__ bias,
+template <typename T = float>
+__global__ void k_critic_dense_fwd(const T* __restrict__ h4, const float* __restrict__ w, const float* __restrict__ bias,
                                    float* __restrict__ v, int F) {
   __shared__ float red[4];
   const long b = blockIdx.x;
   float s = 0.f;
-  for (int i = threadIdx.x; i < F; i += blockDim.x) s += h4[b * F + i] * w[i];
+  for (int i = threadIdx.x; i < F; i += blockDim.x) s += rd_ld1(h4 + b * F + i) * w[i];
   s = rd_block_sum(s, red);
   if (threadIdx.x == 0) v[b] = s + bias[0];
 }
@@ -487,31 +466,33 @@ __device__ __forceinline__ float rd_dv(int b, int B, int mode) {
 }
 
 // top of the critic's input-gradient chain: u4 = gate(h4) * w6 * dv(sample)
-__global__ void k_critic_top_bwd(const float* __restrict__ h4, const float* __restrict__ w, float* __restrict__ u4,
+template <typename T = float>
+__global__ void k_critic_top_bwd(const T* __restrict__ h4, const float* __restrict__ w, T* __restrict__ u4,
                                  int NB, int F, int B, int mode, int use_drop, uint32_t key) {
   const long total = (long)NB * F;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     int b = (int)(f / F), i = (int)(f - (long)b * F);
-    float g = rd_lrelu_slope_from_out(h4[f]);
+    float g = rd_lrelu_slope_from_out(rd_ld1(h4 + f));
     if (use_drop) g *= rd_drop_scale(key, (uint32_t)f);
-    u4[f] = g * w[i] * rd_dv(b, B, mode);
+    rd_st1(u4 + f, g * w[i] * rd_dv(b, B, mode));
   }
 }
 
 // dW6[i] = sum_b buf[b][i] * dv(b) over the 3B batch whose last third holds r4;
 // block = 16 columns x 16 sample groups (F / 16 workgroups: the matrix is short and wide)
+template <typename T = float>
 __global__ void __launch_bounds__(256)
-k_critic_dense_wgrad(const float* __restrict__ buf, float* __restrict__ dw, int NB, int F, int B) {
+k_critic_dense_wgrad(const T* __restrict__ buf, float* __restrict__ dw, int NB, int F, int B) {
   __shared__ float red[256];
   const int i = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
   float s0 = 0.f, s1 = 0.f;
   if (i < F) {
     int b = g;
     for (; b + 16 < NB; b += 32) {
-      s0 += buf[(long)b * F + i] * rd_dv(b, B, 0);
-      s1 += buf[(long)(b + 16) * F + i] * rd_dv(b + 16, B, 0);
+      s0 += rd_ld1(buf + (long)b * F + i) * rd_dv(b, B, 0);
+      s1 += rd_ld1(buf + (long)(b + 16) * F + i) * rd_dv(b + 16, B, 0);
     }
-    if (b < NB) s0 += buf[(long)b * F + i] * rd_dv(b, B, 0);
+    if (b < NB) s0 += rd_ld1(buf + (long)b * F + i) * rd_dv(b, B, 0);
   }
   red[threadIdx.x] = s0 + s1;
   __syncthreads();
@@ -525,9 +506,9 @@ k_critic_dense_wgrad(const float* __restrict__ buf, float* __restrict__ dw, int 
 // column sums of rows [0,rows) of a [rows][C] matrix, two deterministic stages.
 // stage 1: CG = C/4 float4 column groups x RG = 256/CG row groups per block; each thread streams float4s
 // down its rows, the row groups are folded through LDS, and partial[blk][C] is written.
-template <int CG>
+template <int CG, typename T = float>
 __global__ void __launch_bounds__(256)
-k_colsum_partial(const float* __restrict__ src, long rows, float* __restrict__ partial, long rows_per_blk) {
+k_colsum_partial(const T* __restrict__ src, long rows, float* __restrict__ partial, long rows_per_blk) {
   constexpr int RG = 256 / CG, C = CG * 4;
   __shared__ f32x4 red[256];
   const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
@@ -535,10 +516,10 @@ k_colsum_partial(const float* __restrict__ src, long rows, float* __restrict__ p
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   long r = r0 + rg;
   for (; r + RG < r1; r += 2 * RG) {            // two independent chains to keep loads in flight
-    s0 += *(const f32x4*)(src + r * C + cg * 4);
-    s1 += *(const f32x4*)(src + (r + RG) * C + cg * 4);
+    s0 += rd_ld4(src + r * C + cg * 4);
+    s1 += rd_ld4(src + (r + RG) * C + cg * 4);
   }
-  if (r < r1) s0 += *(const f32x4*)(src + r * C + cg * 4);
+  if (r < r1) s0 += rd_ld4(src + r * C + cg * 4);
   red[threadIdx.x] = s0 + s1;
   __syncthreads();
   if (rg == 0) {
@@ -778,9 +759,10 @@ __global__ void k_transpose_map(const float* __restrict__ in, float* __restrict_
   }
 }
 // out = g * LeakyReLU'(h) (from the stored output h)
-__global__ void k_lrelu_bwd(const float* __restrict__ g, const float* __restrict__ h, float* __restrict__ out, long n4) {
+template <typename T = float>
+__global__ void k_lrelu_bwd(const T* __restrict__ g, const T* __restrict__ h, float* __restrict__ out, long n4) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    f32x4 gv = *(const f32x4*)(g + 4 * i), hv = *(const f32x4*)(h + 4 * i);
+    f32x4 gv = rd_ld4(g + 4 * i), hv = rd_ld4(h + 4 * i);
     gv.x *= rd_lrelu_slope_from_out(hv.x); gv.y *= rd_lrelu_slope_from_out(hv.y);
     gv.z *= rd_lrelu_slope_from_out(hv.z); gv.w *= rd_lrelu_slope_from_out(hv.w);
     *(f32x4*)(out + 4 * i) = gv;
@@ -840,34 +822,30 @@ __global__ void k_weight_transform_adj(const float* __restrict__ dU, float* __re
   }
 }
 // E[b][j][:] = x[b][j][:] - x[b][j-1][:], j = 0..D, x zero outside [0,D); P = floats per d-plane (multiple of 4)
-// x16 / E16 (optional): bf16 copies of the input (D planes per sample) and of E for the mixed mode's GEMMs.
-__global__ void k_diff_d(const float* __restrict__ x, float* __restrict__ E, int B, int D, long P,
-                         unsigned short* __restrict__ x16, unsigned short* __restrict__ E16) {
+template <typename T = float>
+__global__ void k_diff_d(const T* __restrict__ x, T* __restrict__ E, int B, int D, long P) {
   const long p4 = P / 4, total = (long)B * (D + 1) * p4;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     const long i = f % p4; const long bj = f / p4;
     const int j = (int)(bj % (D + 1)); const long b = bj / (D + 1);
-    const float* xb = x + (b * D) * P + i * 4;
+    const T* xb = x + (b * D) * P + i * 4;
     f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = hi;
-    if (j < D) hi = *(const f32x4*)(xb + (long)j * P);
-    if (j > 0) lo = *(const f32x4*)(xb + (long)(j - 1) * P);
-    *(f32x4*)(E + f * 4) = hi - lo;
-    if (E16) {
-      rd_store_bf16x4(E16 + f * 4, hi - lo);
-      if (j < D) rd_store_bf16x4(x16 + ((b * D + j) * P + i * 4), hi);
-    }
+    if (j < D) hi = rd_ld4(xb + (long)j * P);
+    if (j > 0) lo = rd_ld4(xb + (long)(j - 1) * P);
+    rd_st4(E + f * 4, hi - lo);
   }
 }
 // dx[b][d][:] += dE[b][d][:] - dE[b][d+1][:]   (adjoint of k_diff_d added to the shared-centre part already in dx)
-__global__ void k_combine_dx(float* __restrict__ dx, const float* __restrict__ dE, int B, int D, long P) {
+template <typename T = float>
+__global__ void k_combine_dx(T* __restrict__ dx, const T* __restrict__ dE, int B, int D, long P) {
   const long p4 = P / 4, total = (long)B * D * p4;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     const long i = f % p4; const long bd = f / p4;
     const int d = (int)(bd % D); const long b = bd / D;
-    const float* e = dE + ((b * (D + 1) + d) * P) + i * 4;
-    f32x4 v = *(const f32x4*)(dx + f * 4);
-    v += *(const f32x4*)e - *(const f32x4*)(e + P);
-    *(f32x4*)(dx + f * 4) = v;
+    const T* e = dE + ((b * (D + 1) + d) * P) + i * 4;
+    f32x4 v = rd_ld4(dx + f * 4);
+    v += rd_ld4(e) - rd_ld4(e + P);
+    rd_st4(dx + f * 4, v);
   }
 }
 
@@ -910,4 +888,16 @@ __global__ void k_blocks_to_bf16(const float* __restrict__ in, unsigned short* _
     u32x4_t o = {rd_pack_bf16(a.x, a.y), rd_pack_bf16(a.z, a.w), rd_pack_bf16(b.x, b.y), rd_pack_bf16(b.z, b.w)};
     *(u32x4_t*)(out + q * cc + 8 * i) = o;
   }
+}
+
+// bf16 -> fp32 (test hook rdgan_debug_activation in the bf16 storage mode)
+__global__ void k_bf16_to_f32(const rd_bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = rd_ld1(in + i);
+}
+// first critic kernel W1 [27*Cin][64] -> bf16 [ldp][64], rows 27*Cin.. zero: the [N][K] weight image of the column GEMM of
+// the critic's input gradient (P1[row][(tap,ci)] = u1[row][:] . W1[(tap,ci)][:]) in the bf16 storage mode
+__global__ void k_w1_to_bf16(const float* __restrict__ w, rd_bf16_t* __restrict__ out, int rows, int ldp) {
+  const int total = ldp * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+    rd_st1(out + i, i / 64 < rows ? w[i] : 0.f);
 }

@@ -28,6 +28,34 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #define RD_OOB 0x80000000u            // >= num_records of every descriptor below -> load returns 0
 #define RD_RSRC_BYTES 0x7FFFFFF0u
 
+// bf16 storage mode ("bf16" option): activations and activation gradients live in HBM as bf16 (rd_bf16_t), all
+// arithmetic on them is fp32.  Overloaded accessors so that the elementwise kernels are written once for both types.
+typedef unsigned short rd_bf16_t;
+typedef __bf16 rd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int rd_u32x2 __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair (round to nearest even, NaN stays NaN: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned rd_pack_bf16(float a, float b) {
+  rd_bf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ f32x4 rd_unpack_bf16x4(rd_u32x2 u) {
+  f32x4 v;
+  v.x = __builtin_bit_cast(float, u.x << 16); v.y = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
+  v.z = __builtin_bit_cast(float, u.y << 16); v.w = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
+  return v;
+}
+__device__ __forceinline__ f32x4 rd_ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 rd_ld4(const rd_bf16_t* p) { return rd_unpack_bf16x4(*(const rd_u32x2*)p); }
+__device__ __forceinline__ void rd_st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void rd_st4(rd_bf16_t* p, f32x4 v) {
+  rd_u32x2 o = {rd_pack_bf16(v.x, v.y), rd_pack_bf16(v.z, v.w)};
+  *(rd_u32x2*)p = o;
+}
+__device__ __forceinline__ float rd_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float rd_ld1(const rd_bf16_t* p) { return __builtin_bit_cast(float, (unsigned)*p << 16); }
+__device__ __forceinline__ void rd_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void rd_st1(rd_bf16_t* p, float v) { *p = __builtin_bit_cast(unsigned short, (__bf16)v); }
+
 __device__ __forceinline__ float rd_lrelu(float x) { return x > 0.f ? x : RD_LRELU_ALPHA * x; }
 // slope of LeakyReLU recovered from its (possibly dropout-scaled) output: TF's LeakyReluGrad
 // uses features > 0 ? 1 : alpha, and sign(output) == sign(features) for kept elements.
@@ -49,6 +77,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rd_make_rsrc(const float* base
 }
 __device__ __forceinline__ void rd_buf_store4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)voff, 0, 0);
+}
+// 4 bf16 (8 bytes) through a buffer descriptor, as fp32
+__device__ __forceinline__ f32x4 rd_buf_load4_bf16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff = 0) {
+  return rd_unpack_bf16x4(__builtin_bit_cast(rd_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, soff, 0)));
+}
+__device__ __forceinline__ void rd_buf_store4_bf16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, f32x4 v) {
+  rd_u32x2 o = {rd_pack_bf16(v.x, v.y), rd_pack_bf16(v.z, v.w)};
+  __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, (int)voff, 0, 0);
 }
 __device__ __forceinline__ void rd_buf_store1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, 0, 0);
@@ -108,13 +144,19 @@ __device__ __forceinline__ unsigned long long rd_stamp() {
 // ------------------------------------------------------------------------------------
 // C[m][n] = sum_{tap,c} A_gather[m][tap][c] * W[tap_w*wrpt + c][n]  (+ fused epilogue)
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK, bool PARTIAL, bool SHIFT>
+// SRC16 / OUT16 (bf16 storage mode, the few GEMMs that stay on the fp32 matrix pipe there): the gathered tensor is bf16
+// (converted to fp32 on its way into LDS) / the destination and the epi.aux / epi.addt tensors are bf16.  Arithmetic
+// unchanged.  OUT16 launches never split K.
+template <int BM, int BN, int WM, int WN, int BK, bool PARTIAL, bool SHIFT, bool SRC16 = false, bool OUT16 = false>
 __global__ void __launch_bounds__(256)
 k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
             const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {
   // PARTIAL: SC % 4 != 0 (the last float4 of a tap is masked element-wise); SHIFT: s_shift == 1 (direct
   // form of the folded nearest upsample).  Both are compile-time so the hot loop has no uniform branches.
   static_assert(WM * WN == 4, "4 waves");
+  static_assert(!(SRC16 && (SHIFT || PARTIAL)), "bf16 source: clean plans only");
+  constexpr int AESZ = SRC16 ? 2 : 4;         // bytes per gathered element
+  constexpr unsigned OSZ = OUT16 ? 2u : 4u;   // bytes per destination / aux / addt element
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
   // A image in LDS: BK = 32 -> unpadded 128-byte rows whose 16-byte chunk c sits at c ^ ((row >> 1) & 7), which
@@ -164,7 +206,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   const int ssample = (int)plan->src_sample;
   const int ntaps = P.ntaps;
   const RdRowTab tab = rd_row_tab(plan, P.tab);
-  const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)b0 * plan->src_sample);
+  const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc((const float*)((const char*)src + (long)b0 * plan->src_sample * AESZ));
   const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(W + P.w_off);
 
   // ---- per-thread A rows: byte offset relative to sample b0 (incl. this thread's channel group), validity bits
@@ -189,7 +231,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
     for (int i = 0; i < A_P; ++i) e[i] = rd_row(tab, rl[i]);
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      roff[i] = rok[i] ? (rb_[i] * ssample + e[i].x + a_c4) * 4 : 0;
+      roff[i] = rok[i] ? (rb_[i] * ssample + e[i].x + a_c4) * AESZ : 0;
       rbits[i] = rok[i] ? e[i].y : 0;
       rcode[i] = rok[i] ? e[i].w : 0;
     }
@@ -227,7 +269,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
       const int sd = ti.code & 255, sh_ = (ti.code >> 8) & 255, sw = ti.code >> 16;
 #pragma unroll
       for (int i = 0; i < A_P; ++i) {
-        int off = roff[i] + (SHIFT ? rd_shift_delta(rcode[i], sd, sh_, sw, SH, SW, cstride) * 4 : ti.delta);
+        int off = roff[i] + (SHIFT ? rd_shift_delta(rcode[i], sd, sh_, sw, SH, SW, cstride) * 4 : (SRC16 ? ti.delta >> 1 : ti.delta));
         voffs[i][t] = ((rbits[i] & ti.mask) == ti.mask) ? (unsigned)off : RD_OOB;
       }
     }
@@ -247,14 +289,16 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
   f32x4 ra[A_P], rw[B_P];
   auto issue_loads = [&](auto t_c) {
     constexpr int t = decltype(t_c)::value;
-    const int sA = ld_cc * BK * 4;
+    const int sA = ld_cc * BK * AESZ;
     const bool tail = k_tail && ld_cc == CPT - 1;
     const int c = ld_cc * BK + a_c4;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       unsigned voff = voffs[i][t];
       if (tail && c >= SC) voff = RD_OOB;                      // uniform `tail` is false in every hot launch
-      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)voff, sA, 0));
+      f32x4 v;
+      if constexpr (SRC16) v = rd_buf_load4_bf16(rsA, voff, sA);
+      else v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)voff, sA, 0));
       if (PARTIAL) {
         if (c + 1 >= SC) v.y = 0.f;
         if (c + 2 >= SC) v.z = 0.f;
@@ -465,8 +509,8 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
         if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
         else { bb = l / L; l -= bb * L; }
         const int z = tab[l].z;
-        rb = (unsigned)(bb * dsmp + z) * 4u;
-        if (epi.addt) tb = (unsigned)(bb * (dsmp >> 1) + z - ((z / epi.addt_plane + 1) >> 1) * epi.addt_plane) * 4u;
+        rb = (unsigned)(bb * dsmp + z) * OSZ;
+        if (epi.addt) tb = (unsigned)(bb * (dsmp >> 1) + z - ((z / epi.addt_plane + 1) >> 1) * epi.addt_plane) * OSZ;
       }
       Rb[tid] = rb; Tb[tid] = tb;
     }
@@ -474,17 +518,25 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
     constexpr int F4R = BN / 4;                         // float4s per row; 256 % F4R == 0, so a thread's columns are fixed
     constexpr int RPP = 256 / F4R;                      // rows per pass
     const int c4 = (tid % F4R) * 4;
-    const unsigned colb = (unsigned)(n0 + c4) * 4u;
+    const unsigned colb = (unsigned)(n0 + c4) * OSZ;
     const long dbase = (long)b0 * dsample;
-    if (ksplit > 1) {
+    // destination-typed accessors of this epilogue (bf16 storage mode: 8-byte accesses)
+    auto ld_act = [](__amdgpu_buffer_rsrc_t r, unsigned off) -> f32x4 {
+      if constexpr (OUT16) return rd_buf_load4_bf16(r, off); else return rd_buf_load4(r, off);
+    };
+    auto st_act = [](__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+      if constexpr (OUT16) rd_buf_store4_bf16(r, off, v); else rd_buf_store4(r, off, v);
+    };
+    auto act_base = [](const float* p, long elems) -> const float* { return (const float*)((const char*)p + elems * (long)OSZ); };
+    if (!OUT16 && ksplit > 1) {
       const __amdgpu_buffer_rsrc_t rsK = rd_make_rsrc(epi.kpart + (long)blockIdx.y * epi.kstride + dbase);
 #pragma unroll 4
       for (int row = tid / F4R; row < BM; row += RPP)
         rd_buf_store4(rsK, Rb[row] + colb, *(const f32x4*)&Cs[row * BN + c4]);
       return;
     }
-    const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc(dst + dbase);
-    const __amdgpu_buffer_rsrc_t rsT = rd_make_rsrc(epi.addt ? epi.addt + (long)b0 * (dsmp >> 1) : dst);
+    const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc(act_base(dst, dbase));
+    const __amdgpu_buffer_rsrc_t rsT = rd_make_rsrc(epi.addt ? act_base(epi.addt, (long)b0 * (dsmp >> 1)) : dst);
     const bool has_t = epi.addt != nullptr;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP || mode == RD_EPI_BIAS_PN_LRELU)
@@ -500,26 +552,26 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
         for (int row = tid / F4R; row < BM; row += RPP) {
           const unsigned rb = Rb[row];
           f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
-          if (has_t) v += rd_buf_load4(rsT, Tb[row] + colb);
+          if (has_t) v += ld_act(rsT, Tb[row] + colb);
           v += bias4;
           const float ss = rd_lanes_sum<F4R>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
           const float ri = __builtin_amdgcn_rsqf(ss * (1.0f / BN) + 1.0e-8f);      // v_rsq_f32: 1 ulp
           v *= ri;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], RD_LRELU_ALPHA * v[e]);     // LeakyReLU for alpha < 1
-          rd_buf_store1(rsR, (rb / BN) | (rb & RD_OOB) | rmask, ri);
-          rd_buf_store4(rsD, rb + colb, v);
+          rd_buf_store1(rsR, ((rb / BN) * (4u / OSZ)) | (rb & RD_OOB) | rmask, ri);
+          st_act(rsD, rb + colb, v);
         }
       }
     }
     if (!pn_done) {
-      const __amdgpu_buffer_rsrc_t rsX = rd_make_rsrc(mode == RD_EPI_GATE_AUX ? epi.aux + dbase : dst);
+      const __amdgpu_buffer_rsrc_t rsX = rd_make_rsrc(mode == RD_EPI_GATE_AUX ? act_base(epi.aux, dbase) : dst);
       const uint32_t ibase = (uint32_t)dbase + epi.idx_base + (uint32_t)(n0 + c4);
 #pragma unroll 4
       for (int row = tid / F4R; row < BM; row += RPP) {
         const unsigned rb = Rb[row];
         f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
-        if (has_t) v += rd_buf_load4(rsT, Tb[row] + colb);
+        if (has_t) v += ld_act(rsT, Tb[row] + colb);
         if (mode == RD_EPI_BIAS) {
           v += bias4;
         } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
@@ -527,19 +579,19 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = rd_lrelu(v[e]);
-            if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+            if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, ibase + (rb / OSZ) + e);
             v[e] = x;
           }
         } else if (mode == RD_EPI_GATE_AUX) {
-          const f32x4 a4 = rd_buf_load4(rsX, rb + colb);
+          const f32x4 a4 = ld_act(rsX, rb + colb);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float g = rd_lrelu_slope_from_out(a4[e]);
-            if (epi.use_drop) g *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+            if (epi.use_drop) g *= rd_drop_scale(epi.key, ibase + (rb / OSZ) + e);
             v[e] *= g;
           }
         }
-        rd_buf_store4(rsD, rb + colb, v);
+        st_act(rsD, rb + colb, v);
       }
     }
   } else {
@@ -558,7 +610,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
           const int col = n0 + wn * WTN + j * 32 + l31;
           const long idx = rowbase + col;
           float v = acc[i][j][r];
-          if (ksplit > 1) {
+          if (!OUT16 && ksplit > 1) {
             epi.kpart[(long)blockIdx.y * epi.kstride + idx] = v;
             continue;
           }
@@ -570,11 +622,11 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
             v = rd_lrelu(v + epi.bias[col]);
             if (epi.use_drop) v *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
           } else if (mode == RD_EPI_GATE_AUX) {
-            float g = rd_lrelu_slope_from_out(epi.aux[idx]);
+            float g = rd_lrelu_slope_from_out(OUT16 ? rd_ld1((const rd_bf16_t*)epi.aux + idx) : epi.aux[idx]);
             if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
             v *= g;
           }
-          dst[idx] = v;
+          if constexpr (OUT16) rd_st1((rd_bf16_t*)dst + idx, v); else dst[idx] = v;
         }
       }
     }
@@ -586,6 +638,8 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 }
 
 // split-K finish: dst[idx] = epilogue(sum_s kpart[s][idx]); the destination is dense with N floats per pixel
+// (OUT16: dst and epi.aux are bf16 -- the bf16 storage mode; the partial slabs are always fp32)
+template <bool OUT16 = false>
 __global__ void k_splitk_finish(float* dst, long total, int N, RdEpi epi) {
   const int mode = epi.mode;
   for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total / 4; i4 += (long)gridDim.x * blockDim.x) {
@@ -605,13 +659,13 @@ __global__ void k_splitk_finish(float* dst, long total, int N, RdEpi epi) {
         x = rd_lrelu(x + epi.bias[col0 + e]);
         if (epi.use_drop) x *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
       } else if (mode == RD_EPI_GATE_AUX) {
-        float g = rd_lrelu_slope_from_out(epi.aux[idx]);
+        float g = rd_lrelu_slope_from_out(OUT16 ? rd_ld1((const rd_bf16_t*)epi.aux + idx) : epi.aux[idx]);
         if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
         x *= g;
       }
       v[e] = x;
     }
-    *(f32x4*)(dst + idx0) = v;
+    if constexpr (OUT16) rd_st4((rd_bf16_t*)dst + idx0, v); else *(f32x4*)(dst + idx0) = v;
   }
 }
 
@@ -640,7 +694,8 @@ __device__ __forceinline__ void rd_wgrad_tile_row(const RdWgradTiling& T, int BR
   }
 }
 
-template <int BR, int BN, bool PARTIAL, bool SHIFT>
+// DY16 (bf16 storage mode, first critic layer): the output gradient dy is bf16, the gathered tensor fp32.
+template <int BR, int BN, bool PARTIAL, bool SHIFT, bool DY16 = false>
 __global__ void __launch_bounds__(256)
 k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
              const float* __restrict__ dy, float* __restrict__ partial, RdWgradTiling T) {
@@ -673,7 +728,8 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   // descriptors are based at the first sample this block touches (wave-uniform)
   const int bb0 = mbeg / L;
   const __amdgpu_buffer_rsrc_t rsA = rd_make_rsrc(src + (long)bb0 * plan->src_sample);
-  const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc(dy + (long)bb0 * plan->dst_sample);
+  constexpr int GSZ = DY16 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rsB = rd_make_rsrc((const float*)((const char*)dy + (long)bb0 * plan->dst_sample * GSZ));
 
   // this thread's A column group (tap, c) is fixed over the whole loop
   int a_tap, a_c;
@@ -688,7 +744,7 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
     else tdelta = t.delta;
   }
   const int a_const = tdelta + a_c * 4;
-  const int b_const = (n0 + (tid % B_F4) * 4) * 4;
+  const int b_const = (n0 + (tid % B_F4) * 4) * GSZ;
 
   // row cursors (sample index relative to bb0, row inside the sample) of this thread's A and B positions.
   // With BR = 256 a whole wave gathers the same positions (A_F4 == 64), so the A cursors, the row-table lookups and the
@@ -733,6 +789,11 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       int m = mb + tid / B_F4 + i * B_PPP;
+      if constexpr (DY16) {
+        unsigned off = m < mend ? (unsigned)((gb[i] * dsample + ez[i]) * 2 + b_const) : RD_OOB;
+        asm volatile("" : "+v"(off));
+        rg[i] = rd_buf_load4_bf16(rsB, off);
+      } else
       rg[i] = rd_buf_load4_if(rsB, m < mend, (unsigned)((gb[i] * dsample + ez[i]) * 4 + b_const));
     }
     // advance the cursors by one chunk (BKP rows)

@@ -27,6 +27,10 @@ __device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float*
 // operands are 16-byte fragments); a K chunk is 64 elements, i.e. the same 128-byte LDS rows, DMA pattern and swizzle as
 // the fp32 kernel, and B uses A's row image.  Plans need SC % 64 == 0.  Everything else (tile decode, row tables, tap
 // masks, epilogue) is shared.
+// BF kernels are the GEMMs of the bf16 storage mode: with epi.out16 the destination and the tensors the epilogue reads
+// (epi.aux, epi.addt) are bf16 too, rounded once from the fp32 accumulator after the whole epilogue (bias, T, PixelNorm,
+// LeakyReLU, dropout, gating); split-K partial slabs stay fp32.  out16 = 0 (fp32 destination) serves the op-level parity
+// tests and the column GEMM of the critic's input gradient.
 typedef __bf16 rd_bf16x8 __attribute__((ext_vector_type(8)));
 // NAMETAG only gives a launch its own kernel symbol (the dominant launch, so that per-name profiler statistics
 // describe exactly that launch); it does not change the code.
@@ -340,7 +344,7 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
       else { bb = l / L; l -= bb * L; }
       const int z = tab[l].z;
-      rb = (unsigned)(bb * dsample + z) * 4u;
+      rb = (unsigned)(bb * dsample + z) * 4u;      // byte offset of the row as fp32; halved below for a bf16 destination
       if (epi.addt) tb = (unsigned)(bb * (dsample >> 1) + z - ((z / epi.addt_plane + 1) >> 1) * epi.addt_plane) * 4u;
     }
     Rb[row] = rb; Tb[row] = tb;
@@ -361,12 +365,70 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       rd_buf_store4(rsK, Rb[row] + colb, *(const f32x4*)&Cs[row * BN + c4]);
     return;
   }
-  const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc(dst + dbase);
-  const __amdgpu_buffer_rsrc_t rsT = rd_make_rsrc(epi.addt ? epi.addt + (long)b0 * (dsample >> 1) : dst);
   const bool has_t = epi.addt != nullptr;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP || mode == RD_EPI_BIAS_PN_LRELU)
     bias4 = *(const f32x4*)(epi.bias + n0 + c4);
+  if constexpr (BF) {
+    if (epi.out16) {
+      // bf16 destination (and bf16 aux / T): same row loop on 8-byte accesses; the byte offsets of the fp32 layout are halved
+      // (an out-of-range marker stays out of range: RD_OOB >> 1 is still far above every window)
+      const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc((const float*)((const rd_bf16_t*)dst + dbase));
+      const __amdgpu_buffer_rsrc_t rsT = rd_make_rsrc(has_t ? (const float*)((const rd_bf16_t*)epi.addt + (long)b0 * (dsample >> 1)) : dst);
+      const unsigned colh = colb >> 1;
+      auto oob = [](unsigned rb) -> unsigned { return (rb >> 1) | (rb & RD_OOB); };
+      if (mode == RD_EPI_BIAS_PN_LRELU) {
+        const __amdgpu_buffer_rsrc_t rsR = rd_make_rsrc(epi.rinv ? epi.rinv + dbase / BN : dst);
+        const unsigned rmask = (c4 == 0 && epi.rinv) ? 0u : RD_OOB;
+#pragma unroll 4
+        for (int row = tid / F4R; row < BM; row += RPP) {
+          const unsigned rb = Rb[row];
+          f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
+          if (has_t) v += rd_buf_load4_bf16(rsT, oob(Tb[row]) + colh);
+          v += bias4;
+          const float ss = rd_lanes_sum<F4R>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+          const float ri = __builtin_amdgcn_rsqf(ss * (1.0f / BN) + 1.0e-8f);
+          v *= ri;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], RD_LRELU_ALPHA * v[e]);
+          rd_buf_store1(rsR, (rb / BN) | (rb & RD_OOB) | rmask, ri);
+          rd_buf_store4_bf16(rsD, oob(rb) + colh, v);
+        }
+      } else {
+        const __amdgpu_buffer_rsrc_t rsX = rd_make_rsrc(mode == RD_EPI_GATE_AUX ? (const float*)((const rd_bf16_t*)epi.aux + dbase) : dst);
+        const uint32_t ibase = (uint32_t)dbase + epi.idx_base + (uint32_t)(n0 + c4);
+#pragma unroll 4
+        for (int row = tid / F4R; row < BM; row += RPP) {
+          const unsigned rb = Rb[row];
+          f32x4 v = *(const f32x4*)&Cs[row * BN + c4];
+          if (has_t) v += rd_buf_load4_bf16(rsT, oob(Tb[row]) + colh);
+          if (mode == RD_EPI_BIAS) {
+            v += bias4;
+          } else if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
+            v += bias4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = rd_lrelu(v[e]);
+              if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+              v[e] = x;
+            }
+          } else if (mode == RD_EPI_GATE_AUX) {
+            const f32x4 a4 = rd_buf_load4_bf16(rsX, oob(rb) + colh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float g = rd_lrelu_slope_from_out(a4[e]);
+              if (epi.use_drop) g *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+              v[e] *= g;
+            }
+          }
+          rd_buf_store4_bf16(rsD, oob(rb) + colh, v);
+        }
+      }
+      return;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc(dst + dbase);
+  const __amdgpu_buffer_rsrc_t rsT = rd_make_rsrc(epi.addt ? epi.addt + (long)b0 * (dsample >> 1) : dst);
   if (mode == RD_EPI_BIAS_PN_LRELU) {
     // PixelNormalization (T:255-266) + LeakyReLU (T:333): the F4R lanes holding a row are an aligned lane group
     const __amdgpu_buffer_rsrc_t rsR = rd_make_rsrc(epi.rinv ? epi.rinv + dbase / BN : dst);

@@ -80,4 +80,5 @@ struct RdEpi {
   int nametag;                 // 1: launch under the dominant launch's own kernel symbol (profiling only)
   const float* addt;
   int addt_plane;              // floats per output hour plane (2H * 2W * Cout)
+  int out16;                   // bf16-operand kernels: 1 = the destination, aux and addt tensors are bf16 (storage mode)
 };

@@ -164,7 +164,7 @@ class Engine:
                                        float(grad_scale), self._stream()), self._h, "rdgan_adam")
 
     def set_option(self, name, value):
-        """rdgan_set_option (include/rdgan.h): "collapse", "fast_fwd", "fast_bwd" (exact algebraic forms), "mfma_bf16" (mixed
+        """rdgan_set_option (include/rdgan.h): "collapse", "fast_fwd", "fast_bwd" (exact algebraic forms), "bf16" (bf16 storage
         mode), "wave_specialized", "ws_ksplit", "tapgather", "g9_direct" (kernel variants), "sample_offset" (data-parallel
         tests)."""
         _lib.check(self.lib.rdgan_set_option(self._h, name.encode(), int(value)), self._h, "rdgan_set_option")

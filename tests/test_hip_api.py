@@ -163,8 +163,8 @@ def test_train_mirror_resume_is_bit_identical(tmp_path, monkeypatch, n_channel):
         T.use_arrays(data, idx)
 
 
-def test_train_mirror_in_mixed_bf16_mode(tmp_path, monkeypatch):
-    """T.train with the engine's "mfma_bf16" option (bf16 MFMA operands, fp32 state): a few iterations stay finite and
+def test_train_mirror_in_bf16_storage_mode(tmp_path, monkeypatch):
+    """T.train with the engine's "bf16" option (bf16 storage and MFMA operands, fp32 master weights and optimizer state): a few iterations stay finite and
     the losses track the fp32 run of the same batches to bf16 accuracy."""
     monkeypatch.chdir(tmp_path)
     rng = np.random.default_rng(3)
@@ -177,7 +177,7 @@ def test_train_mirror_in_mixed_bf16_mode(tmp_path, monkeypatch):
         for mode in (0, 1):
             T.build_networks(seed=21)
             T.hist["d_loss"].clear(); T.hist["g_loss"].clear()
-            models.get_engine(16, 8).set_option("mfma_bf16", mode)
+            models.get_engine(16, 8).set_option("bf16", mode)
             np.random.seed(5)
             T.train(1, 8, max_batches_per_epoch=3, save_models=False)
             runs[mode] = (list(T.hist["d_loss"]), list(T.hist["g_loss"]))
@@ -186,5 +186,5 @@ def test_train_mirror_in_mixed_bf16_mode(tmp_path, monkeypatch):
         np.testing.assert_allclose(runs[1][1], runs[0][1], rtol=0.1, atol=0.02)
         assert runs[1] != runs[0]
     finally:
-        models.get_engine(16, 8).set_option("mfma_bf16", 0)
+        models.get_engine(16, 8).set_option("bf16", 0)
         T.configure(n_disc=5)

@@ -1,0 +1,118 @@
+"""-m gpu: the bf16 storage mode (option "bf16", BASELINE configs[2..4]): activations and activation gradients live in
+HBM as bf16, every heavy GEMM runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 master weights, PixelNorm /
+softmax / gradient penalty / Adam arithmetic in fp32.
+
+Tolerances.  The kernels' arithmetic is pinned at 1e-5 against the oracle on bf16-rounded operands (tests/test_hip_ops.py).
+End to end every stored tensor carries one bf16 rounding (2^-9 relative), so against the fp32 oracle: generator forward
+(fractions) within 2e-2 of the largest fraction; step gradients within 6e-2 of the tensor's largest entry, measured
+against the fp64 oracle differentiating the LeakyReLU branch the bf16 run took (tests/test_hip_fullsize.py explains why).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rdgan_torch as ot
+from pr_disagg_radar_gan_amd import Engine, _lib
+from pr_disagg_radar_gan_amd.trainer import WGANGPTrainer
+from tests.hip_util import dev, rel_err, hip_gates
+from tests.test_hip_step import _params, _t64, _grad_errors
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL, GRAD_TOL = 2e-2, 6e-2
+
+
+def _check_bf16_case(nd, B, seed, critic_tol=0.3):
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 51)
+        x, cond, z = ot.synthetic_batch(B, nd, seed)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
+        out32 = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+        c32 = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 9).cpu().numpy()
+        eng.set_option("bf16", 1)
+        out = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+        assert np.all(np.isfinite(out))
+        np.testing.assert_allclose(out.sum(axis=1), 1.0, rtol=0, atol=2e-6)       # the softmax itself stays fp32
+        e16, e32 = rel_err(out, ref), rel_err(out32, ref)
+        assert e32 < 2e-5 and 1e-4 < e16 < FWD_TOL, (e16, e32)                    # really bf16, and within its rounding
+        # generator step against the oracle on the branch this run took
+        slab = eng.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
+        gates = hip_gates(eng, B)
+        loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 6,
+                                        gates=gates)
+        n = eng.n_gen
+        assert slab[n + 4] == 0
+        np.testing.assert_allclose(slab[n], loss.item(), rtol=5e-2, atol=5e-3)
+        errs = _grad_errors(slab[:n], grads, eng.gen_shapes)
+        print(f"nd {nd} B {B} bf16 gen-step grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
+        assert max(errs.values()) < GRAD_TOL, errs
+        assert min(errs.values()) > 1e-5, errs
+        # critic step: no slope pattern is left for the interpolated third (the second sweep overwrites it in place), so the
+        # bf16 noise of the critic input may flip a few LeakyReLU slopes; compared with the fp32 path of the same engine
+        cslab = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 9).cpu().numpy()
+        n = eng.n_critic
+        assert np.all(np.isfinite(cslab)) and cslab[n + 4] == 0
+        np.testing.assert_allclose(cslab[n:n + 3], c32[n:n + 3], rtol=5e-2, atol=5e-3)
+        off = 0
+        for name, s in eng.critic_shapes:
+            k = int(np.prod(s))
+            if name != "dense_1/bias:0":
+                assert rel_err(cslab[off:off + k], c32[off:off + k]) < critic_tol, (name, rel_err(cslab[off:off + k], c32[off:off + k]))
+            off += k
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("nd,B,seed", [(16, 4, 23), (16, 9, 29), (64, 1, 31)])
+def test_bf16_storage_forward_and_step_gradients(nd, B, seed):
+    """small and odd batches (partial tiles everywhere) and the large domain"""
+    _check_bf16_case(nd, B, seed)
+
+
+def test_bf16_storage_b96_production_tiles():
+    """B = 96: the tiles of the bs >= 256 step (k_wgrad_gemm_ws16<256, 64>, the 256x64 conv tile with bf16 operands, the
+    automatic K splits)"""
+    _check_bf16_case(16, 96, 41)
+
+
+def test_bf16_storage_needs_the_fast_forms():
+    eng = Engine(ndomain=16, max_batch=2)
+    try:
+        g, d = _params(16, 5)
+        x, cond, z = ot.synthetic_batch(2, 16, 3)
+        eng.set_option("bf16", 1)
+        eng.set_option("fast_fwd", 0)
+        with pytest.raises(_lib.RdganError, match="bf16 storage mode needs"):
+            eng.gen_forward(eng.to_slab(g), dev(z), dev(cond))
+    finally:
+        eng.close()
+
+
+def test_bf16_storage_training_iterations_track_fp32():
+    """a few whole iterations (n_critic = 2) in both modes from the same weights and seeds: finite, the non-finite flag stays
+    clear, and the bf16 run's losses follow the fp32 run's"""
+    eng = Engine(ndomain=16, max_batch=8)
+    try:
+        g, d = _params(16, 77)
+        batches = [tuple(dev(a) for a in ot.synthetic_batch(8, 16, 500 + i)) for i in range(3)]
+
+        def run(bf16):
+            eng.set_option("bf16", bf16)
+            tr = WGANGPTrainer(eng, g, d, n_disc=2, base_seed=3)
+            out = []
+            for it in range(3):
+                x, c, z = batches[it]
+                x2, c2, z2 = batches[(it + 1) % 3]
+                dl, gl, bad = tr.iteration([(x, c, z), (x2, c2, z2)], (z, c))
+                out.append((float(dl), float(gl), float(bad)))
+            return out
+
+        a, b = run(0), run(1)
+        for (d0, g0, f0), (d1, g1, f1) in zip(a, b):
+            assert f0 == 0 and f1 == 0
+            assert abs(d0 - d1) < 5e-2 * max(1.0, abs(d0)) and abs(g0 - g1) < 5e-2 * max(1.0, abs(g0)), (a, b)
+    finally:
+        eng.set_option("bf16", 0)
+        eng.close()

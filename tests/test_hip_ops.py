@@ -65,10 +65,15 @@ def test_conv3d_bf16_operands(g):
     ref32 = _oracle_conv(x, w, b, g).numpy()
     xd, wd, bd = dev(x), dev(w), dev(b)
     y = torch.full((B,) + od + (cout,), float("nan"), device="cuda")
-    rc = lib().rdgan_op_conv3d_bf16(ptr(xd), ptr(wd), ptr(bd), ptr(y), B, *dims, cin, cout, *od, stride, *pad, stream())
+    rc = lib().rdgan_op_conv3d_bf16(ptr(xd), ptr(wd), ptr(bd), ptr(y), B, *dims, cin, cout, *od, stride, *pad, 0, stream())
     assert rc == 0
     assert rel_err(y.cpu().numpy(), ref) < 1e-5
     assert 1e-4 < rel_err(y.cpu().numpy(), ref32) < 3e-2          # and it really is bf16: ~2^-9 per operand
+    # bf16 destination (the storage mode's epilogue): the same fp32 accumulator, rounded to nearest-even bf16 once
+    y16 = torch.full((B,) + od + (cout,), float("nan"), device="cuda", dtype=torch.bfloat16)
+    rc = lib().rdgan_op_conv3d_bf16(ptr(xd), ptr(wd), ptr(bd), ptr(y16), B, *dims, cin, cout, *od, stride, *pad, 1, stream())
+    assert rc == 0
+    assert torch.equal(y16, y.bfloat16())
 
 
 @pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
@@ -175,3 +180,38 @@ def test_rng_bit_exact():
         assert lib().rdgan_op_rng(seed, sid, ptr(m), ptr(u), n, stream()) == 0
         assert np.array_equal(m.cpu().numpy(), orng.dropout_scale_mask(seed, sid, (n,)))
         assert np.array_equal(u.cpu().numpy(), orng.uniform(seed, sid, n))
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("g", [0, 1, 2])
+def test_shared_centre_wgrad_256_row_tile(g, bf16):
+    """The weight-gradient kernels that carry the bs = 256 step -- k_wgrad_gemm_ws<256, 64> and its bf16 twin
+    k_wgrad_gemm_ws16<256, 64> -- through the production plan of generator block 3 (shared-centre form: 4 parity phases x
+    4 taps; the launcher takes the 256-row tile from B * D*H*W >= 65536, i.e. B >= 86), against the definition
+        dU[g][(ph,th),(pw,tw)] = sum_{b,s,h,w} src[b, s + (g==2), h+ph-1+th, w+pw-1+tw, :]^T  dy[b, od(s), 2h+ph, 2w+pw, :]
+    evaluated in float64 (on the bf16-rounded operands for the bf16 kernel): 1e-5."""
+    B, D, H, W, Cin, Cout = 86, 12, 8, 8, 128, 64
+    rng = np.random.default_rng(40 + g)
+    SD = D if g == 1 else D + 1
+    DD = D if g == 1 else 2 * D
+    src = rng.standard_normal((B, SD, H, W, Cin)).astype(np.float32)
+    dy = rng.standard_normal((B, DD, 2 * H, 2 * W, Cout)).astype(np.float32)
+    s64 = (_bf16_round(src) if bf16 else src).astype(np.float64)
+    d64 = (_bf16_round(dy) if bf16 else dy).astype(np.float64)
+    sp = np.zeros((B, SD, H + 2, W + 2, Cin))                       # zero halo of one pixel in h and w
+    sp[:, :, 1:-1, 1:-1] = s64
+    td = 1 if g == 2 else 0
+    ref = np.zeros((16, Cin, Cout))
+    for ph in range(2):
+        for pw in range(2):
+            dsel = d64[:, (slice(None) if g == 1 else slice(1 if g == 2 else 0, None, 2)), ph::2, pw::2]   # [B, D, H, W, Cout]
+            for th in range(2):
+                for tw in range(2):
+                    a = sp[:, td:td + D, ph + th:ph + th + H, pw + tw:pw + tw + W]                          # offsets ph-1+th (+1 halo)
+                    ref[(ph * 2 + th) * 4 + (pw * 2 + tw)] = np.tensordot(a.reshape(-1, Cin), dsel.reshape(-1, Cout), axes=(0, 0))
+    dU = torch.full((48, Cin, Cout), float("nan"), device="cuda")
+    sd, dd = dev(src), dev(dy)                     # (named: the device copies must outlive the call)
+    rc = lib().rdgan_op_fastd_wgrad(ptr(sd), ptr(dd), ptr(dU), B, D, H, W, Cin, Cout, g, bf16, stream())
+    assert rc == 0
+    got = dU[g * 16:(g + 1) * 16].cpu().numpy()
+    assert rel_err(got, ref) < 1e-5

@@ -310,74 +310,6 @@ def test_odd_batches_default_options(B):
         eng.close()
 
 
-def test_mfma_bf16_option(eng16):
-    """"mfma_bf16": the shared-centre forward / input-gradient GEMMs of generator blocks 2 and 3 take bf16 operand copies
-    (fp32 accumulation, fp32 tensors everywhere else; the kernel itself is pinned to 1e-5 against the oracle on
-    bf16-rounded inputs in test_hip_ops.py).  Against the fp32 oracle the results must sit within bf16 rounding
-    (2^-9 per operand) and must differ from the fp32 path, so the option really switches kernels."""
-    eng16.set_option("collapse", 1); eng16.set_option("wave_specialized", 1)
-    eng16.set_option("fast_fwd", 1); eng16.set_option("fast_bwd", 1)
-    g, d = _params(16, 51)
-    x, cond, z = ot.synthetic_batch(4, 16, 23)
-    gs, ds = eng16.to_slab(g), eng16.to_slab(d)
-    ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
-    loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 6)
-    out32 = eng16.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
-    try:
-        eng16.set_option("mfma_bf16", 1)
-        out = eng16.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
-        assert np.all(np.isfinite(out))
-        np.testing.assert_allclose(out.sum(axis=1), 1.0, rtol=0, atol=2e-6)
-        e16, e32 = rel_err(out, ref), rel_err(out32, ref)
-        assert e32 < 2e-5 and 1e-4 < e16 < 2e-2, (e16, e32)
-        # critic: forward and the critic-step gradients (layers 2-4 on bf16 operands)
-        masks = ot.critic_masks(7, 4, 16, torch.float64)
-        vref = ot.critic_forward(_t64(d), torch.from_numpy(x).double(), torch.from_numpy(cond).double(), masks).numpy()
-        v = eng16.critic_forward(ds, dev(x), dev(cond), seed=7).cpu().numpy()
-        assert 1e-5 < rel_err(v, vref) < 3e-2, rel_err(v, vref)
-        closs, cgrads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(), torch.from_numpy(cond).double(),
-                                             torch.from_numpy(z).double(), 9)
-        cslab = eng16.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 9).cpu().numpy()
-        np.testing.assert_allclose(cslab[eng16.n_critic:eng16.n_critic + 3], closs.numpy()[:3], rtol=5e-2, atol=5e-3)
-        cerrs = _grad_errors(cslab[:eng16.n_critic], cgrads, eng16.critic_shapes)
-        assert max(cerrs.values()) < 0.25, cerrs                     # (the penalty term squares the bf16 noise of the input gradient)
-        slab = eng16.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
-        errs = _grad_errors(slab[:eng16.n_gen], grads, eng16.gen_shapes)
-        assert max(errs.values()) < 0.15, errs                       # bf16 operands + the LeakyReLU sign flips they cause in the critic
-        assert min(errs.values()) > 1e-5, errs
-    finally:
-        eng16.set_option("mfma_bf16", 0)
-
-
-def test_mfma_bf16_odd_batch_and_domain64():
-    """mixed mode at a batch that leaves partial tiles (B = 9, nd 16) and on the large domain (nd 64, B = 1): forward and
-    both gradient slabs stay within bf16 rounding of the fp32 path of the same engine."""
-    for nd, B in ((16, 9), (64, 1)):
-        eng = Engine(ndomain=nd, max_batch=B)
-        try:
-            g, d = _params(nd, 61)
-            x, cond, z = ot.synthetic_batch(B, nd, 29)
-            gs, ds = eng.to_slab(g), eng.to_slab(d)
-            ref_f = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
-            ref_c = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 5).cpu().numpy()
-            ref_g = eng.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
-            eng.set_option("mfma_bf16", 1)
-            out_f = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
-            out_c = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 5).cpu().numpy()
-            out_g = eng.gen_grad(ds, gs, dev(z), dev(cond), 6).cpu().numpy()
-            assert 1e-5 < rel_err(out_f, ref_f) < 2e-2
-            for out, ref, n, shapes in ((out_c, ref_c, eng.n_critic, eng.critic_shapes), (out_g, ref_g, eng.n_gen, eng.gen_shapes)):
-                assert np.all(np.isfinite(out))
-                off = 0
-                for name, s in shapes:
-                    k = int(np.prod(s))
-                    if name != "conv3d_3/bias:0":
-                        assert rel_err(out[off:off + k], ref[off:off + k]) < 0.3, (nd, name)
-                    off += k
-        finally:
-            eng.close()
-
-
 def test_error_paths(eng16):
     """Argument errors come back as exceptions / -2 with a message, never as a launch: batch above max_batch, wrong shapes
     and dtypes, unknown option; the C ABI reports them through rdgan_last_error."""
