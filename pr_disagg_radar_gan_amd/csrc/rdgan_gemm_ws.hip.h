@@ -509,6 +509,11 @@ k_wgrad_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_compute = wave < 4;
   const int l31 = lane & 31, lhalf = lane >> 5;
+#ifndef RD_WGRAD_NOPRIO
+  // as in k_conv_gemm_ws: everything but the MFMA loop at raised priority (beside the other resident workgroup's MFMA
+  // stream a priority-0 loader wave gets about one issue slot per 64-cycle MFMA)
+  __builtin_amdgcn_s_setprio(3);
+#endif
   const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
   const int tiles = T.RT * T.NT;
   const int bx = swz % tiles, by = (swz / tiles) % T.nsplit, bz = swz / (tiles * T.nsplit);
@@ -613,6 +618,9 @@ k_wgrad_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     __syncthreads();
+#ifndef RD_WGRAD_NOPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     for (int q = 0; q < nchunks; ++q) {
       const int buf = q & 1;
       const float* As = smem + buf * STAGE + lhalf * BR + wm * WTM + l31;
@@ -643,6 +651,9 @@ k_wgrad_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict_
       }
       __syncthreads();
     }
+#ifndef RD_WGRAD_NOPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
   }
 
   // ---- partial tile [BR][BN] through LDS, coalesced float4 stores by all 8 waves

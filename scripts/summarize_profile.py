@@ -1,0 +1,67 @@
+"""Condense the outputs of scripts/gpu_profile_r02.sh into the small tables kept under profiles/:
+   python3 scripts/summarize_profile.py gpurun_out/prof_r02 profiles r02
+* <tag>_<run>_kernel_stats.csv : the rocprofv3 --stats table (name shortened), unchanged numbers
+* <tag>_hbm_traffic_<mode>.csv  : per kernel name: launches per iteration, mean FETCH_SIZE x 2 (gfx950: the counter tallies
+  half the bytes of wide streaming reads, MI355X_MICROARCH.md) and WRITE_SIZE per launch, the launch's mean duration from the
+  --stats run of the same configuration, and the resulting HBM GB/s."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def short(n):
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*", "", n)
+
+
+stats = {}
+for f in sorted(glob.glob(os.path.join(src, "*_kernel_stats.csv"))):
+    run = os.path.basename(f)[:-len("_kernel_stats.csv")]
+    rows = list(csv.DictReader(open(f)))
+    stats[run] = {short(r["Name"]): r for r in rows}
+    with open(os.path.join(dst, f"{tag}_{run}_kernel_stats.csv"), "w", newline="") as o:
+        w = csv.writer(o)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+for mode, run in (("0", "fp32_bs256"), ("1", "bf16_bs256")):
+    acc = defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
+    for cset in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(src, f"pmc_bf16{mode}_{cset}.csv")
+        if not os.path.exists(f):
+            continue
+        per_dispatch = defaultdict(float)
+        names = {}
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != cset:
+                continue
+            k = r["Dispatch_Id"]
+            per_dispatch[k] += float(r["Counter_Value"])
+            names[k] = short(r["Kernel_Name"])
+        for k, v in per_dispatch.items():
+            acc[names[k]][cset].append(v)
+    if not acc:
+        continue
+    out = os.path.join(dst, f"{tag}_hbm_traffic_{'bf16' if mode == '1' else 'fp32'}_bs256.csv")
+    with open(out, "w", newline="") as o:
+        w = csv.writer(o)
+        w.writerow(["Name", "launches_in_2_iterations", "fetch_MB_per_launch_x2_corrected", "write_MB_per_launch", "avg_us_from_stats",
+                    "hbm_GBps"])
+        rows = []
+        for n, d in acc.items():
+            # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB
+            fe = 2.0 * sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1) * 1024 / 1e6
+            wr = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1) * 1024 / 1e6
+            st = stats.get(run, {}).get(n)
+            us = float(st["AverageNs"]) / 1e3 if st else float("nan")
+            rows.append((n, len(d["FETCH_SIZE"]) or len(d["WRITE_SIZE"]), fe, wr, us, (fe + wr) * 1e6 / (us * 1e-6) / 1e9 if st else float("nan")))
+        rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
+        for r in rows:
+            w.writerow([r[0], r[1], f"{r[2]:.2f}", f"{r[3]:.2f}", f"{r[4]:.1f}", f"{r[5]:.0f}"])
+    print("wrote", out)
