@@ -123,6 +123,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * neighbouring hour planes in LDS: weight gradient without the [rows][27] im2col matrix, input gradient fused with
  * block 3's PixelNorm+LeakyReLU backward (no intermediate gradient tensor).  Needs 4 (nd+2)^2 floats of LDS (nd <= 72);
  * 0 (and larger domains) = im2col + column GEMMs + separate PixelNorm backward.
+ * "edge_kernels" (default 1): in the bf16 storage mode the generator's last conv (64 -> 1) runs in its dedicated streaming
+ * kernel (one pass over the block-3 output at HBM speed, same arithmetic and tap-sum format as "tapgather"); 2 = also with
+ * fp32 storage (bit-identical to the tiled GEMM, not faster there); 0 = the tiled GEMM kernel everywhere.
  * "sample_offset" (default 0): global index of this rank's first sample.  RandomWeightedAverage's alpha (T:222-223) of
  * local sample k is uniform(key(seed, ALPHA), sample_offset + k), so ranks that share a seed draw the alphas of the
  * global batch (used by the data-parallel equivalence tests; the dropout masks stay keyed by the local element index).

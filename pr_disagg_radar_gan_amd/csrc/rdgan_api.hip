@@ -17,6 +17,7 @@
 #include "rdgan_gemm_ws16.hip.h"
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
+#include "rdgan_edge.hip.h"
 
 #define RD_GP_WEIGHT 10.0f   // the literal at T:392
 
@@ -385,6 +386,7 @@ struct rdgan_handle {
   int tapgather = 1;              // 1: last generator conv sums its in-tile taps in the GEMM epilogue; 0: full column matrix + gather kernel
   int ws_ksplit = 1;              // 1: split K of mid-size producer/consumer launches to fill whole rounds of workgroups; 0: off; >1: force (tests)
   int wave_spec = 1;              // 1: producer/consumer (wave-specialised, LDS-DMA) kernel for the big clean GEMMs
+  int edge_kernels = 1;           // 1: dedicated streaming kernels for the generator's last conv (rdgan_edge.hip.h); 0: the tiled GEMM kernels
   int sample_offset = 0;          // global index of this rank's first sample: RandomWeightedAverage's alpha of sample k is uniform(key, sample_offset + k)
   int* d_flag;
   // profiling
@@ -1174,6 +1176,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "fast_fwd")) { h->fast_fwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value ? 1 : 0; return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "edge_kernels")) { h->edge_kernels = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   if (!strcmp(name, "sample_offset")) { if (value < 0) return bad_arg(h, "set_option: sample_offset < 0"); h->sample_offset = value; return 0; }
   if (!strcmp(name, "ws_ksplit")) { h->ws_ksplit = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }   // > 1 = force (tests)
   return bad_arg(h, "set_option: unknown option");
@@ -1332,7 +1335,28 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // sums the in-tile taps itself and writes 3 (9) floats per grid point instead of 32.
   const int gq = 256 % (nd * nd) == 0 ? 3 : (256 % nd == 0 ? 9 : 0);
   const long ncol = (long)B * nd * nd;
-  if (gq && h->tapgather) {
+  if (gq && h->tapgather && (h->edge_kernels == 2 || (h->edge_kernels && a16))) {
+    // dedicated streaming kernel (rdgan_edge.hip.h): same tiles, same arithmetic and output as the tap-gathering GEMM below.
+    // Default in the bf16 storage mode (one pass over h3 at 5.4 TB/s: 37 us against 153 us at bs 256); with fp32 storage its
+    // one-tile-per-workgroup form (64 KB tiles, two workgroups per CU in lockstep) only matches the GEMM (159 vs 147 us),
+    // so fp32 keeps the GEMM unless "edge_kernels" is 2 (tests).
+    ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
+    const long rows9 = (long)B * h->gpix[3];
+    h->flops_acc += 2.0 * rows9 * 64 * 27;
+    static bool attr_done = false;
+    if (!attr_done) {
+      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_fwd<rd_bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024));
+      attr_done = true;
+    }
+    const dim3 g9((unsigned)((rows9 + 255) / 256));
+    if (a16) hipLaunchKernelGGL(k_g9_fwd<rd_bf16_t>, g9, dim3(256), 36 * 1024, st, (const rd_bf16_t*)h->h3, gp + h->goff[8], h->P9, rows9, nd,
+                                nd * nd, gq);
+    else hipLaunchKernelGGL(k_g9_fwd<float>, g9, dim3(256), 72 * 1024, st, (const float*)h->h3, gp + h->goff[8], h->P9, rows9, nd,
+                            nd * nd, gq);
+    hipLaunchKernelGGL(k_tapsum_softmax<RDGAN_NHOURS>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->P9,
+                       gp + h->goff[9], out, B, nd, nd, gq, h->d_flag);
+  } else if (gq && h->tapgather) {
     RdEpi e = epi_make(RD_EPI_TAPGATHER);
     e.gw = nd; e.ghw = nd * nd; e.gq = gq;
     if (a16) RD_TRY(launch_conv_a16(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, e, st, -1, true, false));

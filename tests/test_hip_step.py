@@ -275,6 +275,26 @@ def test_last_conv_paths_other_domains(nd, tapgather):
         eng.close()
 
 
+@pytest.mark.parametrize("nd,B", [(8, 5), (16, 3), (32, 2), (64, 1)])
+def test_last_conv_streaming_kernel_equals_the_tiled_gemm(nd, B):
+    """"edge_kernels": the dedicated streaming kernel of the 64 -> 1 conv multiplies in the same k order and sums the same
+    taps as the tap-gathering GEMM, so the fp32 forward is bit-identical (and both are within 2e-5 of the oracle)."""
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, _ = _params(nd, 33)
+        x, cond, z = ot.synthetic_batch(B, nd, 19)
+        gs = eng.to_slab(g)
+        eng.set_option("edge_kernels", 2)
+        a = eng.gen_forward(gs, dev(z), dev(cond)).clone()
+        eng.set_option("edge_kernels", 0)
+        b = eng.gen_forward(gs, dev(z), dev(cond))
+        assert torch.equal(a, b)
+        ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
+        assert rel_err(a.cpu().numpy(), ref) < 2e-5
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [9, 33])
 def test_odd_batches_default_options(B):
     """Batches that leave partial tiles everywhere (rows % 128 != 0, tiles spanning several samples), default options:
