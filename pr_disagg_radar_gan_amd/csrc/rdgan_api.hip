@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <unordered_set>
 
 #include "../../include/rdgan.h"
 #include "rdgan_plan.h"
@@ -389,6 +390,9 @@ struct rdgan_handle {
   int edge_kernels = 1;           // 1: dedicated streaming kernels for the generator's last conv (rdgan_edge.hip.h); 0: the tiled GEMM kernels
   int sample_offset = 0;          // global index of this rank's first sample: RandomWeightedAverage's alpha of sample k is uniform(key, sample_offset + k)
   int* d_flag;
+  // kernels whose dynamic-LDS limit has been raised on THIS handle's device (hipFuncSetAttribute is per device; keeping the
+  // record per handle rather than per process makes two handles on two devices, or on two threads, independent)
+  std::unordered_set<const void*> lds_attr_done;
   // profiling
   double flops_acc = 0;           // algorithmic FLOPs (2 * rows * taps * K * N of the forms actually run) of every GEMM launched so far
   unsigned prof_mask = 0;
@@ -415,6 +419,14 @@ struct rdgan_handle {
 static int bad_arg(rdgan_handle* h, const char* msg) {
   if (h) h->err = msg;
   return -2;
+}
+
+// raise a kernel's dynamic shared-memory limit once per handle (always, for the handle-less op-level entry points)
+static int ensure_lds(rdgan_handle* h, const void* kern, size_t lds) {
+  if (h && h->lds_attr_done.count(kern)) return 0;
+  RD_CHECK(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (h) h->lds_attr_done.insert(kern);
+  return 0;
 }
 
 struct ProfScope {
@@ -458,12 +470,8 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   constexpr size_t lds_epi = BK == 32 ? ((size_t)BM * BN * sizeof(float) + (size_t)BM * 16) : 0;
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
 #endif
-  static bool attr_done = false;
   auto kern = k_conv_gemm<BM, BN, WM, WN, BK, PARTIAL, SHIFT, SRC16, OUT16>;
-  if (!attr_done) {
-    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  RD_TRY(ensure_lds(h, (const void*)kern, lds));
   long tm = plan_tiles(hp, B, BM);
   if (tm <= 0) return 0;
   {  // a tile's buffer descriptor is based at its first sample: its span must stay below 2 GiB
@@ -512,24 +520,13 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
   constexpr size_t lds_loop = 2 * (size_t)(BM * 32 + 32 * BN) * sizeof(float);
   constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float) + (size_t)BM * 16;
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  static bool attr_done = false;
   auto kern = k_conv_gemm_ws<BM, BN, WM, WN, TG, BF>;
   if constexpr (BM == 256 && BN == 64 && TG == 4) {     // the dominant launch runs under its own symbol (same code)
-    if (epi.nametag == 1) {
-      static bool attr_done1 = false;
-      kern = k_conv_gemm_ws<BM, BN, WM, WN, TG, BF, 1>;
-      if (!attr_done1) {
-        RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done1 = true;
-      }
-    }
+    if (epi.nametag == 1) kern = k_conv_gemm_ws<BM, BN, WM, WN, TG, BF, 1>;
   }
+  RD_TRY(ensure_lds(h, (const void*)kern, lds));
   constexpr int KCH = BF ? 64 : 32;                    // K elements per chunk
   if (BF && hp.SC % 64) return bad_arg(h, "conv: bf16 operands need a multiple of 64 channels per tap");
-  if (!attr_done && epi.nametag != 1) {
-    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
   long tm = plan_tiles(hp, B, BM);
   if (tm <= 0) return 0;
   long minL = hp.ph[0].L;
@@ -716,12 +713,8 @@ template <int BR, int BN, bool PARTIAL, bool SHIFT, bool DY16 = false>
 static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int B, const float* src, const float* dy,
                             float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(32 * BR + 32 * BN) * sizeof(float);
-  static bool attr_done = false;
   auto kern = k_wgrad_gemm<BR, BN, PARTIAL, SHIFT, DY16>;
-  if (!attr_done) {
-    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  RD_TRY(ensure_lds(h, (const void*)kern, lds));
   dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, dy, partial, T);
   RD_CHECK(h, hipGetLastError());
@@ -734,12 +727,8 @@ static int launch_wgrad_ws_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, i
   constexpr size_t lds_loop = 2 * (size_t)(32 * BR + 32 * BN) * sizeof(float);
   constexpr size_t lds_epi = (size_t)BR * BN * sizeof(float);
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  static bool attr_done = false;
   auto kern = k_wgrad_gemm_ws<BR, BN>;
-  if (!attr_done) {
-    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  RD_TRY(ensure_lds(h, (const void*)kern, lds));
   dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dp, B, src, dy, partial, T);
   RD_CHECK(h, hipGetLastError());
@@ -805,12 +794,8 @@ static int launch_wgrad16_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, in
   constexpr size_t lds_loop = 2 * (size_t)(64 * BR * 2 + 64 * BN * 2);
   constexpr size_t lds_epi = (size_t)BR * BN * sizeof(float);
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  static bool attr_done = false;
   auto kern = k_wgrad_gemm_ws16<BR, BN>;
-  if (!attr_done) {
-    RD_CHECK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  RD_TRY(ensure_lds(h, (const void*)kern, lds));
   dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dp, B, (const unsigned short*)src16, (const unsigned short*)dy16, partial, T);
   RD_CHECK(h, hipGetLastError());
@@ -1343,12 +1328,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
     const long rows9 = (long)B * h->gpix[3];
     h->flops_acc += 2.0 * rows9 * 64 * 27;
-    static bool attr_done = false;
-    if (!attr_done) {
-      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_fwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_fwd<rd_bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024));
-      attr_done = true;
-    }
+    RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_fwd<rd_bf16_t> : (const void*)k_g9_fwd<float>, a16 ? 36 * 1024 : 72 * 1024));
     const dim3 g9((unsigned)((rows9 + 255) / 256));
     if (a16) hipLaunchKernelGGL(k_g9_fwd<rd_bf16_t>, g9, dim3(256), 36 * 1024, st, (const rd_bf16_t*)h->h3, gp + h->goff[8], h->P9, rows9, nd,
                                 nd * nd, gq);
@@ -1644,14 +1624,8 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   if (g9_direct) {
     ProfScope ps(h, RDGAN_TAG_GCONV_WGRAD, st);
     const size_t lds = std::max<size_t>(g9_lds, 4 * 27 * 16 * sizeof(f32x4));
-    static bool attr_done = false;
-    if (!attr_done) {
-      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_wgrad_pairs<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_bwd_pairs<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_wgrad_pairs<rd_bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      RD_CHECK(h, hipFuncSetAttribute((const void*)k_g9_bwd_pairs<rd_bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr_done = true;
-    }
+    RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_wgrad_pairs<rd_bf16_t> : (const void*)k_g9_wgrad_pairs<float>, 96 * 1024));
+    RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_bwd_pairs<rd_bf16_t> : (const void*)k_g9_bwd_pairs<float>, 96 * 1024));
     const int nwg = B * (RDGAN_NHOURS / 2);
     if (a16) hipLaunchKernelGGL(k_g9_wgrad_pairs<rd_bf16_t>, dim3(nwg), dim3(256), lds, st, h->dl, (const rd_bf16_t*)h->h3, h->wpartial,
                                 RDGAN_NHOURS, nd, nd);
