@@ -123,6 +123,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * neighbouring hour planes in LDS: weight gradient without the [rows][27] im2col matrix, input gradient fused with
  * block 3's PixelNorm+LeakyReLU backward (no intermediate gradient tensor).  Needs 4 (nd+2)^2 floats of LDS (nd <= 72);
  * 0 (and larger domains) = im2col + column GEMMs + separate PixelNorm backward.
+ * "resident" (default 1; bf16 storage mode): the forward GEMMs of the shared-centre form whose tile holds whole source
+ * planes keep the tile's source rows resident in LDS and stream only the weights (each source row is fetched once per
+ * channel chunk instead of once per tap and chunk); same arithmetic in the same order, bit-identical to 0.
  * "edge_kernels" (default 1): in the bf16 storage mode the generator's last conv (64 -> 1) runs in its dedicated streaming
  * kernel (one pass over the block-3 output at HBM speed, same arithmetic and tap-sum format as "tapgather"); 2 = also with
  * fp32 storage (bit-identical to the tiled GEMM, not faster there); 0 = the tiled GEMM kernel everywhere.

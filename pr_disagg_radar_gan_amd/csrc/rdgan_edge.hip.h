@@ -1,6 +1,8 @@
-// Dedicated kernels for the two "edge" convolutions of the step, whose GEMM shapes are too thin for the tiled conv kernels:
-// the generator's last Conv3D (64 -> 1, T:345) and the critic's first Conv3D (1 + n_cond -> 64, stride 2 'valid', T:286).
-// Both are HBM-bound streams over one big tensor; the tiled kernels spend their time in per-tile prologues instead.
+// Dedicated kernel for the generator's last Conv3D (64 -> 1, T:345), whose GEMM shape (K = 64, N = 27) is too thin for the
+// tiled conv kernels: it is an HBM-bound stream over the block-3 output, and the tiled kernel spends its time in per-tile
+// prologues instead.  (Round 2 also tried dedicated kernels for the critic's first Conv3D (2 -> 64 channels, K = 54): a
+// sample-in-LDS version is bound by LDS broadcasts, versions feeding the FMAs from scalar loads run into SGPR spills (forward)
+// or scalar-cache misses (weight gradient); none beat the implicit-GEMM path, so that layer stays on it.)
 #pragma once
 #include "rdgan_gemm_ws.hip.h"
 

@@ -34,11 +34,18 @@ __device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float*
 typedef __bf16 rd_bf16x8 __attribute__((ext_vector_type(8)));
 // NAMETAG only gives a launch its own kernel symbol (the dominant launch, so that per-name profiler statistics
 // describe exactly that launch); it does not change the code.
-template <int BM, int BN, int WM, int WN, int TG, bool BF = false, int NAMETAG = 0>
+// RES (bf16 kernels, plans whose taps of a phase are (h,w)-shifted views of the same source planes: the forward GEMMs of the
+// shared-centre form): the tile's gathered rows stay RESIDENT in LDS -- each source row is fetched once per channel chunk
+// instead of once per tap and channel chunk (64 KB instead of 256 KB per 256x64 tile of generator block 3) -- and only the
+// weights stream through the two stages.  A compute lane reads its fragment for tap t from LDS row r + dh*SW + dw (the
+// source planes hold whole (h,w) planes, H*W divides BM) and zeroes it where the tap falls outside the image.  With the K loop
+// down to 8 chunks the streaming form is bound by what a CU can pull from L2 into LDS; this one is not.
+template <int BM, int BN, int WM, int WN, int TG, bool BF = false, int NAMETAG = 0, bool RES = false>
 __global__ void __launch_bounds__(512, 4)
 k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
                const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {
   static_assert(WM * WN == 4, "4 compute waves");
+  static_assert(!RES || BF, "resident-tile mode: bf16 kernels only");
   constexpr int BK = 32;
   static_assert(TG == 4 || TG == 8, "taps per register group");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -166,11 +173,32 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
         const int tap = min(g * TG + t, ntaps - 1);
         const RdTap ti = P.tap[tap];
         tapw[t] = BF ? ti.w * wrpt * plan->N * 2 : ti.w * wrpt * ldw * 4;
-        const int tdelta = BF ? ti.delta >> 1 : ti.delta;     // plan deltas are fp32 byte offsets
+        if constexpr (!RES) {
+          const int tdelta = BF ? ti.delta >> 1 : ti.delta;     // plan deltas are fp32 byte offsets
 #pragma unroll
-        for (int k = 0; k < NI_A; ++k)
-          voffs[k][t] = ((rbits[k] & ti.mask) == ti.mask) ? (unsigned)(roff[k] + tdelta) : RD_OOB;
+          for (int k = 0; k < NI_A; ++k)
+            voffs[k][t] = ((rbits[k] & ti.mask) == ti.mask) ? (unsigned)(roff[k] + tdelta) : RD_OOB;
+        }
       }
+    };
+    // RES: the un-shifted source rows of the tile, one 128-byte row per tile row and channel chunk, at the hour plane the
+    // phase's taps share (all taps of a phase have the same d offset); rows whose plane lies outside the tensor read zeros
+    unsigned resoff[NI_A];
+    if constexpr (RES) {
+      const RdTap t0 = P.tap[0];
+      const int d_off = (t0.code & 255) / 2 - 1;
+      const int pl_delta = d_off * plan->SH * plan->SW * plan->s_cstride * ESZ;
+      const int dmask = t0.mask & 0xF;
+#pragma unroll
+      for (int k = 0; k < NI_A; ++k) {
+        const int r = wl * (BM / 4) + k * 8 + (lane >> 3);
+        resoff[k] = (m0 + r < rows && (rbits[k] & dmask) == dmask) ? (unsigned)(roff[k] + pl_delta) : RD_OOB;
+      }
+    }
+    auto load_resident = [&](int cc) {         // channel chunk cc of every tile row -> A_res[cc]
+      float* Ar = smem + cc * (BM * BK) + wl * (BM / 4) * BK;
+#pragma unroll
+      for (int k = 0; k < NI_A; ++k) rd_lds_dma16(rsA, Ar + k * 8 * BK, (int)resoff[k], cc * BK * 4);
     };
     int ld_g = 0, ld_cc = 0, ld_t = 0, ld_gt = min(TG, ntaps);
     if (q0 != 0) {
@@ -185,12 +213,15 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
     auto issue = [&](int stage, auto t_c) {
       constexpr int t = decltype(t_c)::value;
       float* As = smem + stage * STAGE + wl * (BM / 4) * BK;
-      float* Bs = smem + stage * STAGE + BM * BK + wl * NI_B * 256;
+      float* Bs = RES ? smem + CPT * (BM * BK) + stage * (BK * BN) + wl * NI_B * 256
+                      : smem + stage * STAGE + BM * BK + wl * NI_B * 256;
       const int sA = ld_cc * BK * 4;
       const int sB = BF ? tapw[t] + ld_cc * BK * 4 : tapw[t] + ld_cc * BK * ldw * 4;
+      if constexpr (!RES) {
 #pragma unroll
-      for (int k = 0; k < NI_A; ++k)
-        rd_lds_dma16(rsA, As + k * 8 * BK, (int)voffs[k][t], sA);
+        for (int k = 0; k < NI_A; ++k)
+          rd_lds_dma16(rsA, As + k * 8 * BK, (int)voffs[k][t], sA);
+      }
 #pragma unroll
       for (int j = 0; j < NI_B; ++j)
         rd_lds_dma16(rsB, Bs + j * 256, boff[j], sB);
@@ -225,6 +256,7 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
         }
       }
     };
+    if constexpr (RES) { if (nchunks > 0) load_resident(0); }
     if (nchunks > 0) load_chunk(0);
 #ifdef RD_STAMP
     if (ws_st && wave == 4) atomicAdd(&rd_stamp_ws[4], rd_stamp() - ws_t0);
@@ -233,6 +265,8 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
     for (int q = 0; q < nchunks; ++q) {
       // stage (q+1)&1 was last read during chunk q-1, whose closing barrier every wave has passed
       if (q + 1 < nchunks) load_chunk((q + 1) & 1);
+      // RES: channel chunk cc is first read by chunk q = cc * ntaps; chunks 1 .. CPT-1 come in behind chunk 0's weights
+      if constexpr (RES) { if (q + 1 < CPT) load_resident(q + 1); }
       __syncthreads();
     }
   } else {
@@ -250,7 +284,65 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
     if (ws_st && wave == 0) atomicAdd(&rd_stamp_ws[0], rd_stamp() - ws_t0);
 #endif
     __builtin_amdgcn_s_setprio(0);
-    if constexpr (BF) {
+    if constexpr (BF && RES) {
+      // validity bits of this lane's TM tile rows (row table), and the tap walk of the loaders: chunk q = (cc, t), t fastest
+      int rbits_c[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = wm * WTM + i * 32 + l31;
+        int l = l0 + r;
+        if (L >= BM) { if (l >= L) l -= L; }
+        else l -= (l / L) * L;
+        rbits_c[i] = m0 + r < rows ? tab[l].y : 0;
+      }
+      const int SWs = plan->SW;
+      int cq_t = 0, cq_cc = 0;
+      for (int q = 0; q < nchunks; ++q) {
+        const int buf = q & 1;
+        const RdTap ti = P.tap[cq_t];
+        const int h_off = (((ti.code >> 8) & 255) - 6) / 2 - 1, w_off = ((ti.code >> 16) - 12) / 2 - 1;
+        const int shift = h_off * SWs + w_off;
+        const float* Ar = smem + cq_cc * (BM * BK);
+        const float* Bs = smem + CPT * (BM * BK) + buf * (BK * BN) + (wn * WTN + l31) * BK;
+        const float* arow[TM];
+        int asw[TM];
+        unsigned amask[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const bool ok = (rbits_c[i] & ti.mask) == ti.mask;
+          const int rp = ok ? wm * WTM + i * 32 + l31 + shift : wm * WTM + i * 32 + l31;   // (a valid tap stays inside the row's plane)
+          arow[i] = Ar + rp * BK;
+          asw[i] = (rp >> 1) & 7;
+          amask[i] = ok ? 0xFFFFFFFFu : 0u;
+        }
+        f32x4 fa[2][TM], fb[2][TN];
+        auto load_frag = [&](int slot, int kk) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            u32x4_t v = *(const u32x4_t*)&arow[i][((kk * 2 + lhalf) ^ asw[i]) * 4];
+            v.x &= amask[i]; v.y &= amask[i]; v.z &= amask[i]; v.w &= amask[i];
+            fa[slot][i] = __builtin_bit_cast(f32x4, v);
+          }
+          const int col = ((kk * 2 + lhalf) ^ a_sw) * 4;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[slot][j] = *(const f32x4*)&Bs[j * 32 * BK + col];
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int cur = kk & 1;
+          if (kk + 1 < 4) load_frag(cur ^ 1, kk + 1);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, fa[cur][i]),
+                                                                  __builtin_bit_cast(rd_bf16x8, fb[cur][j]), acc[i][j], 0, 0, 0);
+        }
+        if (++cq_t == ntaps) { cq_t = 0; ++cq_cc; }
+        __syncthreads();
+      }
+    } else if constexpr (BF) {
       for (int q = 0; q < nchunks; ++q) {
         const int buf = q & 1;
         const float* As = smem + buf * STAGE + (wm * WTM + l31) * BK;

@@ -77,6 +77,30 @@ def test_bf16_storage_b96_production_tiles():
     _check_bf16_case(16, 96, 41)
 
 
+@pytest.mark.parametrize("nd,B", [(16, 32), (8, 70), (32, 8)])
+def test_resident_tile_kernel_is_bit_identical(nd, B):
+    """"resident": the bf16 forward GEMMs whose 256-row tile holds whole source planes keep the tile's rows in LDS and
+    read the taps as shifted rows (k_conv_gemm_ws<..., RES>); same products in the same order, so the forward pass and the
+    gradient slabs are bit-identical to the streaming form.  Batches chosen so that the 256x64 tile is picked
+    (>= 512 tiles) and, at ndomain 8, so that tiles span several samples and end in a partial tile."""
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 52)
+        x, cond, z = ot.synthetic_batch(B, nd, 37)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        a = eng.gen_forward(gs, dev(z), dev(cond)).clone()
+        ga = eng.gen_grad(ds, gs, dev(z), dev(cond), 6).clone()
+        eng.set_option("resident", 0)
+        b = eng.gen_forward(gs, dev(z), dev(cond))
+        assert torch.equal(a, b)
+        gb = eng.gen_grad(ds, gs, dev(z), dev(cond), 6)
+        assert torch.equal(ga, gb)
+        assert bool(torch.isfinite(a).all())
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:
