@@ -67,7 +67,8 @@ class WGANGPTrainer:
         self._allreduce(grad)
         self.t += 1
         self.eng.adam(params, grad, v, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
-        return grad[-LOSS_SLOTS:-LOSS_SLOTS + 5] / self.world
+        tail = grad[-LOSS_SLOTS:-LOSS_SLOTS + 5]
+        return tail if self.world == 1 else tail / self.world      # (a view at world 1: no extra kernel on the step path)
 
     def _update_overlapped(self, params, grad, v, which):
         cur = torch.cuda.current_stream(params.device)
@@ -115,6 +116,17 @@ class WGANGPTrainer:
             for ev in (self.d_ready, self.g_ready):
                 if ev is not None:
                     cur.wait_event(ev)
+
+    def iteration_raw(self, critic_batches, gen_batch):
+        """The same iteration without any arithmetic on the loss tails: returns (critic tail, generator tail), each
+        [total, valid, fake, gp, nonfinite] as left by the LAST critic step / the generator step (views into the gradient
+        slabs at world 1: read them before the next iteration).  For loops that look at the losses only now and then."""
+        assert len(critic_batches) == self.n_disc
+        for (x, c, z) in critic_batches:
+            dl = self.critic_step(x, c, z)
+        gl = self.gen_step(*gen_batch)
+        self.join()
+        return dl, gl
 
     def iteration(self, critic_batches, gen_batch):
         """critic_batches: n_disc tuples (x_real, cond, z); gen_batch: (z, cond).  Returns (d_loss, g_loss)
