@@ -293,7 +293,10 @@ def main():
     if rank == 0:
         value = world * B * args.steps / dt
         avg_ms = kern_ms / max(kern_n, 1)
-        taps = 27 if opts.get("collapse") == "0" else (8 if opts.get("fast_fwd") == "0" else 4)
+        # tap products per output position of the tagged launch (generator block 3 forward): direct 27, collapsed 8, or the
+        # difference part of the shared-centre form 4 (fp32 default); the bf16 storage mode defaults to the collapsed form
+        fast_fwd = opts.get("fast_fwd", "0" if bf16 else "1")
+        taps = 27 if opts.get("collapse") == "0" else (8 if fast_fwd == "0" else 4)
         peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
         achieved = gconv3_flops(B, ND, taps) / (avg_ms * 1e-3) / 1e12 if kern_n else None
         med = float(np.median(it_ms))
@@ -322,10 +325,12 @@ def main():
             "iteration_ms": {"median": round(med, 4), "p10": round(float(np.percentile(it_ms, 10)), 4),
                              "p90": round(float(np.percentile(it_ms, 90)), 4), "n": int(args.steps),
                              "clock": "HIP events on the compute stream around each iteration"},
-            "roofline": {"bound": "mfma", "kernel": ("k_conv_gemm_ws<256, 64, 4, 1, 4, %s, 1>" % ("true" if bf16 else "false"))
+            "roofline": {"bound": "mfma", "kernel": ("k_conv_gemm_ws<256, 64, 4, 1, %d, %s, 1>" % (8 if taps == 8 else 4, "true" if bf16 else "false"))
                                                     + " (own symbol: this launch only), generator block 3 forward, "
-                                                    "difference part (E x U over 8 parity phases x 4 taps + shared part T + bias + "
-                                                    "PixelNorm + LeakyReLU in the epilogue)",
+                                                    + ("collapsed form (8 parity phases x 8 taps + bias + PixelNorm + LeakyReLU in the epilogue)"
+                                                       if taps == 8 else
+                                                       "difference part (E x U over 8 parity phases x 4 taps + shared part T + bias + "
+                                                       "PixelNorm + LeakyReLU in the epilogue)"),
                          "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
                          "traffic": DOMINANT_TRAFFIC_BYTES if is_metric and taps == 4 else None,

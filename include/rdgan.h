@@ -108,7 +108,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "ws_ksplit" (default 1): mid-size producer/consumer launches whose workgroup count would leave part of the 256 CUs
  * idle in the last round split their K loop over 2..8 workgroups (partials folded by a finish kernel, fixed order);
  * 0 = never, n > 1 = force n-way splits wherever the shape allows (tests).
- * "fast_fwd" / "fast_bwd" (default 1, need "collapse" 1): generator blocks 2 and 3 (block inputs with >= 6 hour
+ * "fast_fwd" / "fast_bwd" (default -1 = by storage mode: on with fp32 storage, off in the bf16 storage mode, where the matrix
+ * pipe is 16x faster and the plain collapsed form -- one GEMM per block, no difference / plane-sum passes -- is quicker;
+ * 1 / 0 force it; need "collapse" 1): generator blocks 2 and 3 (block inputs with >= 6 hour
  * planes) in the shared-centre form along the hour axis: out[2s] = S x[s] - W0 E[s], out[2s+1] = S x[s] + W2 E[s+1]
  * with E[j] = x[j] - x[j-1] and S = W0+W1+W2, so both outputs of a source position share the S x[s] product -- 48
  * instead of 64 tap products per position, algebraically identical.  Forward: T = S x once per output plane pair,

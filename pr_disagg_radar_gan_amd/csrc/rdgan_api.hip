@@ -380,8 +380,8 @@ struct rdgan_handle {
   void *bG1F, *bG1B, *bW1B;
   int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
   int g9_direct = 1;              // 1: backward of the 64 -> 1 conv straight from the dlogits (no im2col matrix), fused with block 3's PixelNorm backward
-  int fast_fwd = 1;               // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products)
-  int fast_bwd = 1;               // 1: generator blocks' weight/input gradients in the shared-centre form along d (48 instead of 64 tap products)
+  int fast_fwd = -1;              // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products); -1: by storage mode
+  int fast_bwd = -1;              // 1: generator blocks' weight/input gradients in the shared-centre form along d (48 instead of 64 tap products); -1: by storage mode
   float *GWC[4], *GWD[4], *dWc;   // collapsed generator weights, their dgrad form, collapsed wgrad scratch
   int collapse = 1;               // 1: 8-tap collapsed generator blocks (default); 0: direct 27-tap form
   int tapgather = 1;              // 1: last generator conv sums its in-tile taps in the GEMM epilogue; 0: full column matrix + gather kernel
@@ -541,9 +541,9 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
   constexpr size_t lds_epi = (size_t)BM * BN * sizeof(float) + (size_t)BM * 16;
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   auto kern = k_conv_gemm_ws<BM, BN, WM, WN, TG, BF>;
-  if constexpr (BM == 256 && BN == 64 && TG == 4) {     // the dominant launch runs under its own symbol (same code)
+  if constexpr (BM == 256 && BN == 64 && (TG == 4 || BF)) {     // the dominant launch runs under its own symbol (same code)
     if (epi.nametag == 1) kern = k_conv_gemm_ws<BM, BN, WM, WN, TG, BF, 1>;
-    if constexpr (BF) {
+    if constexpr (BF && TG == 4) {
       if (res) kern = epi.nametag == 1 ? k_conv_gemm_ws<BM, BN, WM, WN, TG, true, 1, true> : k_conv_gemm_ws<BM, BN, WM, WN, TG, true, 0, true>;
     } else res = false;
   } else res = false;
@@ -1184,8 +1184,8 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "wave_specialized")) { h->wave_spec = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }   // 2 = also for small problems (tests)
   if (!strcmp(name, "bf16") || !strcmp(name, "mfma_bf16")) { h->a16 = value ? 1 : 0; return 0; }   // ("mfma_bf16": round-1 name)
   if (!strcmp(name, "g9_direct")) { h->g9_direct = value ? 1 : 0; return 0; }
-  if (!strcmp(name, "fast_fwd")) { h->fast_fwd = value ? 1 : 0; return 0; }
-  if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "fast_fwd")) { h->fast_fwd = value < 0 ? -1 : (value ? 1 : 0); return 0; }     // -1 = by storage mode
+  if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value < 0 ? -1 : (value ? 1 : 0); return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "edge_kernels")) { h->edge_kernels = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
@@ -1246,13 +1246,19 @@ static inline float* act_off(const rdgan_handle* h, float* p, long elems) {
 // bf16 storage mode needs the forms whose GEMMs all exist as bf16 kernels
 static int a16_check(rdgan_handle* h) {
   if (!h->a16) return 0;
-  if (!h->collapse || !h->fast_fwd || !h->fast_bwd || !h->g9_direct)
-    return bad_arg(h, "bf16 storage mode needs the options collapse, fast_fwd, fast_bwd and g9_direct at 1");
+  if (!h->collapse || !h->g9_direct)
+    return bad_arg(h, "bf16 storage mode needs the options collapse and g9_direct at 1");
   if (4 * (size_t)(h->nd + 2) * (h->nd + 2) * sizeof(float) > 96 * 1024) return bad_arg(h, "bf16 storage mode: ndomain too large");
   return 0;
 }
 
 // the shared-centre form pays where the hour axis of the block input is long enough for its (D+1)/D boundary plane
+// "fast_fwd" / "fast_bwd" at their default (-1) follow the storage mode: the shared-centre form saves a quarter of the tap
+// products, which pays where the matrix pipe is the bound (fp32: 64 FLOP/clk/SIMD); with bf16 operands the pipe is 16x faster
+// and nowhere near busy, so the plain collapsed form wins there -- one GEMM per block instead of two, no hour-difference /
+// plane-sum / recombination passes (measured at bs 256: 3.89 vs 4.09 ms per iteration)
+static int fast_fwd_on(const rdgan_handle* h) { return h->fast_fwd < 0 ? !h->a16 : h->fast_fwd; }
+static int fast_bwd_on(const rdgan_handle* h) { return h->fast_bwd < 0 ? !h->a16 : h->fast_bwd; }
 static bool gen_block_fast(const rdgan_handle* h, int l, int enabled) {
   return h->collapse && enabled && h->gdim[l - 1][0] >= 6;
 }
@@ -1281,7 +1287,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     // UpSampling3D + Conv3D + bias (T:330-331), then PixelNorm + LeakyReLU (T:332-333)
     const float* Wl = gp + h->goff[2 * l];
     int pl = PL_G1F + l - 1;
-    if (gen_block_fast(h, l, h->fast_fwd)) {
+    if (gen_block_fast(h, l, fast_fwd_on(h))) {
       // shared-centre form along the hour axis: T = S x[s] once per output plane pair, then the difference part
       const int* sd = h->gdim[l - 1];
       const long P = (long)sd[1] * sd[2] * h->gch[l - 1];
@@ -1320,7 +1326,6 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       }
       continue;
     }
-    if (a16 && l != 1) return bad_arg(h, "bf16 storage mode: generator blocks 2 and 3 need the shared-centre form");
     if (h->collapse) {
       hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * h->gch[l - 1] * h->gch[l])), dim3(256), 0, st, Wl,
                          h->GWC[l], h->gch[l - 1] * h->gch[l]);
@@ -1331,9 +1336,11 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
     ep.rinv = rs[l];
     ep.out16 = a16;
-    if (a16) {     // block 1 (collapsed form, 64 taps) on the bf16 matrix pipe
-      RD_TRY(launch_weights_to_bf16_t(h, h->GWC[1], h->bG1F, 64, h->gch[0], h->gch[1], st));
-      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, hs[0], h->bG1F, hs[1], ep, st, RDGAN_TAG_GCONV_FWD));
+    ep.nametag = a16 && l == 3;
+    if (a16) {     // collapsed form (64 taps) on the bf16 matrix pipe; the bf16 weight image is rebuilt per block
+      RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F, 64, h->gch[l - 1], h->gch[l], st));
+      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], h->bG1F, hs[l], ep, st,
+                           l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
     } else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], Wl, h->gch[l], hs[l], ep, st,
                        l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
@@ -1681,18 +1688,18 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
     RdSliceMap map;
     collapsed_dgrad_slice_map(map.src);
     for (int l = 1; l <= 3; ++l) {   // Wd[q][Cout][Cin] <- Wc (written by gen_forward_impl above unless that block ran in the shared-centre form)
-      if (gen_block_fast(h, l, h->fast_bwd)) continue;
-      if (a16) continue;              // (block 1 reads the bf16 image of Wc re-ordered by tap instead, below)
-      if (gen_block_fast(h, l, h->fast_fwd))
+      if (gen_block_fast(h, l, fast_bwd_on(h))) continue;
+      if (gen_block_fast(h, l, fast_fwd_on(h)))
         hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * h->gch[l - 1] * h->gch[l])), dim3(256), 0, st,
                            gp + h->goff[2 * l], h->GWC[l], h->gch[l - 1] * h->gch[l]);
+      if (a16) continue;              // (bf16 storage: the input gradient reads the bf16 image of Wc re-ordered by tap, below)
       hipLaunchKernelGGL(k_transpose_map, dim3((h->gch[l] + 31) / 32, (h->gch[l - 1] + 31) / 32, 64), dim3(256), 0, st,
                          h->GWC[l], h->GWD[l], h->gch[l - 1], h->gch[l], map);
     }
   }
   for (int l = 3; l >= 1; --l) {
     // shared-centre backward only where the hour axis is long enough to pay for its (D+1)/D boundary plane
-    const bool fast = gen_block_fast(h, l, h->fast_bwd);
+    const bool fast = gen_block_fast(h, l, fast_bwd_on(h));
     if (l == 3 && g9_direct) {
       // input gradient of the 64 -> 1 conv + block 3's PixelNorm+LeakyReLU backward (+ plane-pair sums)
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
@@ -1723,8 +1730,11 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       fastd_weight_map(wm);
       {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-        if (!gen_block_fast(h, l, h->fast_fwd)) {      // (otherwise the forward pass above has left both)
-          hipLaunchKernelGGL(k_diff_d<float>, dim3(ew_blocks((long)B * (D + 1) * P / 4)), dim3(256), 0, st, (const float*)hs[l - 1],
+        if (!gen_block_fast(h, l, fast_fwd_on(h))) {      // (otherwise the forward pass above has left both)
+          const dim3 dg(ew_blocks((long)B * (D + 1) * P / 4));
+          if (a16) hipLaunchKernelGGL(k_diff_d<rd_bf16_t>, dg, dim3(256), 0, st, (const rd_bf16_t*)hs[l - 1], (rd_bf16_t*)h->fE[l], B, D, P);
+          else
+          hipLaunchKernelGGL(k_diff_d<float>, dg, dim3(256), 0, st, (const float*)hs[l - 1],
                              h->fE[l], B, D, P);
           hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, gp + h->goff[2 * l], h->fU[l],
                              (int)cc, 48, wm);
@@ -1781,8 +1791,8 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
     } else if (col) {
       int plf = PL_G1FC + l - 1, plb = PL_G1BC + l - 1;
       if (a16) {
-        if (l != 1 || !wgrad16_ok(h->plans[plf], B)) return bad_arg(h, "bf16 storage mode: unsupported collapsed block");
-        RD_TRY(launch_wgrad16(h, h->plans[plf], h->d_plans + plf, B, hs[0], dys[1], h->dWc, h->wpartial, h->wpartial_cap, st,
+        if (!wgrad16_ok(h->plans[plf], B)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this block");
+        RD_TRY(launch_wgrad16(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap, st,
                               RDGAN_TAG_GCONV_WGRAD));
       } else
       RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap,
@@ -1794,10 +1804,10 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
         RdSliceMap map;
         collapsed_dgrad_slice_map(map.src);
         hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 64), dim3(256), 0, st,
-                           h->GWC[1], (unsigned short*)h->bG1B, cc, map);
+                           h->GWC[l], (unsigned short*)h->bG1B, cc, map);
         RdEpi eb = epi_make(RD_EPI_PLAIN);
         eb.out16 = 1;
-        RD_TRY(launch_conv16(h, h->plans[plb], h->d_plans + plb, B, dys[1], h->bG1B, gups[1], eb, st, RDGAN_TAG_GCONV_DGRAD));
+        RD_TRY(launch_conv16(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->bG1B, gups[l], eb, st, RDGAN_TAG_GCONV_DGRAD));
       } else
       RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWD[l], h->gch[l - 1], gups[l],
                          epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));

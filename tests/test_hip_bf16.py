@@ -22,9 +22,11 @@ pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL = 2e-2, 6e-2
 
 
-def _check_bf16_case(nd, B, seed, critic_tol=0.3):
+def _check_bf16_case(nd, B, seed, critic_tol=0.3, fast=None):
     eng = Engine(ndomain=nd, max_batch=B)
     try:
+        if fast is not None:            # default: the collapsed form in the bf16 mode; 1 = the shared-centre form forced
+            eng.set_option("fast_fwd", fast); eng.set_option("fast_bwd", fast)
         g, d = _params(nd, 51)
         x, cond, z = ot.synthetic_batch(B, nd, seed)
         gs, ds = eng.to_slab(g), eng.to_slab(d)
@@ -71,10 +73,15 @@ def test_bf16_storage_forward_and_step_gradients(nd, B, seed):
     _check_bf16_case(nd, B, seed)
 
 
-def test_bf16_storage_b96_production_tiles():
+@pytest.mark.parametrize("fast", [None, 1])
+def test_bf16_storage_b96_production_tiles(fast):
     """B = 96: the tiles of the bs >= 256 step (k_wgrad_gemm_ws16<256, 64>, the 256x64 conv tile with bf16 operands, the
-    automatic K splits)"""
-    _check_bf16_case(16, 96, 41)
+    automatic K splits), in the mode's default collapsed form and with the shared-centre form forced (resident-tile kernel)"""
+    _check_bf16_case(16, 96, 41, fast=fast)
+
+
+def test_bf16_storage_shared_centre_form_small_batch():
+    _check_bf16_case(16, 5, 43, fast=1)
 
 
 @pytest.mark.parametrize("nd,B", [(16, 32), (8, 70), (32, 8)])
@@ -89,6 +96,7 @@ def test_resident_tile_kernel_is_bit_identical(nd, B):
         x, cond, z = ot.synthetic_batch(B, nd, 37)
         gs, ds = eng.to_slab(g), eng.to_slab(d)
         eng.set_option("bf16", 1)
+        eng.set_option("fast_fwd", 1); eng.set_option("fast_bwd", 1)      # the shared-centre form: 4-tap plans
         a = eng.gen_forward(gs, dev(z), dev(cond)).clone()
         ga = eng.gen_grad(ds, gs, dev(z), dev(cond), 6).clone()
         eng.set_option("resident", 0)
@@ -107,7 +115,7 @@ def test_bf16_storage_needs_the_fast_forms():
         g, d = _params(16, 5)
         x, cond, z = ot.synthetic_batch(2, 16, 3)
         eng.set_option("bf16", 1)
-        eng.set_option("fast_fwd", 0)
+        eng.set_option("collapse", 0)
         with pytest.raises(_lib.RdganError, match="bf16 storage mode needs"):
             eng.gen_forward(eng.to_slab(g), dev(z), dev(cond))
     finally:
