@@ -1660,11 +1660,12 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
     const size_t lds = std::max<size_t>(g9_lds, 4 * 27 * 16 * sizeof(f32x4));
     RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_wgrad_pairs<rd_bf16_t> : (const void*)k_g9_wgrad_pairs<float>, 96 * 1024));
     RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_bwd_pairs<rd_bf16_t> : (const void*)k_g9_bwd_pairs<float>, 96 * 1024));
-    const int nwg = B * (RDGAN_NHOURS / 2);
+    const int nunits = B * (RDGAN_NHOURS / 2);
+    const int nwg = std::min(nunits, 3072);            // (bs 256: one unit per workgroup, as before)
     if (a16) hipLaunchKernelGGL(k_g9_wgrad_pairs<rd_bf16_t>, dim3(nwg), dim3(256), lds, st, h->dl, (const rd_bf16_t*)h->h3, h->wpartial,
-                                RDGAN_NHOURS, nd, nd);
+                                RDGAN_NHOURS, nd, nd, nunits);
     else hipLaunchKernelGGL(k_g9_wgrad_pairs<float>, dim3(nwg), dim3(256), lds, st, h->dl, (const float*)h->h3, h->wpartial,
-                            RDGAN_NHOURS, nd, nd);
+                            RDGAN_NHOURS, nd, nd, nunits);
     hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(256), 0, st, h->wpartial, nwg, 1728, grad + h->goff[8]);
   } else {
     {
