@@ -147,7 +147,7 @@ __global__ void k_pn_lrelu_bwd_pairs(const T* __restrict__ g, const T* __restric
 //   gh3[u][c] = sum_tap dl[u - off(tap)] * w9[tap][c];   dy = pn_lrelu_bwd(gh3, h3, rinv);   gS = dy[2s] + dy[2s+1]
 // One workgroup per (sample, hour-plane pair s); the four dl planes 2s-1 .. 2s+2 sit in LDS with a zero halo, a thread
 // owns one channel quad (its 27 x 4 kernel weights in registers) and walks the plane's pixels 16 at a time.
-// gS is optional (shared-centre backward).  H*W % 32 == 0 (ndomain is a multiple of 8).  T = element type of h3 / dy / gS (bf16 storage mode).
+// gS is optional (shared-centre backward).  H*W % 16 == 0.  T = element type of h3 / dy / gS (bf16 storage mode).
 template <typename T = float>
 __global__ void __launch_bounds__(256)
 k_g9_bwd_pairs(const float* __restrict__ dl, const float* __restrict__ w9, const T* __restrict__ h3,
@@ -169,10 +169,6 @@ k_g9_bwd_pairs(const float* __restrict__ dl, const float* __restrict__ w9, const
   __syncthreads();
   for (int it = threadIdx.x >> 4; it < HW; it += 16) {
     const int hh = it / W, ww = it - hh * W;
-    // (the activation loads go out in front of the tap loop, which hides their latency)
-    const long pixA = (b * D + 2 * s) * HW + it, pixB = pixA + HW, pr = (b * Ds + s) * HW + it;
-    const f32x4 ha = rd_ld4(h3 + pixA * 64 + c4), hb = rd_ld4(h3 + pixB * 64 + c4);
-    const float ria = rinv[pixA], rib = rinv[pixB];
     f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = ga;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd)
@@ -185,8 +181,10 @@ k_g9_bwd_pairs(const float* __restrict__ dl, const float* __restrict__ w9, const
           const f32x4 w = wq[(kd * 3 + kh) * 3 + kw];
           ga += da * w; gb += db * w;
         }
-    const f32x4 oa = rd_pn_lrelu_bwd_row<16>(ga, ha, ria);
-    const f32x4 ob = rd_pn_lrelu_bwd_row<16>(gb, hb, rib);
+    const long pixA = (b * D + 2 * s) * HW + it, pixB = pixA + HW, pr = (b * Ds + s) * HW + it;
+    const f32x4 ha = rd_ld4(h3 + pixA * 64 + c4), hb = rd_ld4(h3 + pixB * 64 + c4);
+    const f32x4 oa = rd_pn_lrelu_bwd_row<16>(ga, ha, rinv[pixA]);
+    const f32x4 ob = rd_pn_lrelu_bwd_row<16>(gb, hb, rinv[pixB]);
     rd_st4(dy + pixA * 64 + c4, oa);
     rd_st4(dy + pixB * 64 + c4, ob);
     if (gS) rd_st4(gS + pr * 64 + c4, oa + ob);
@@ -218,29 +216,20 @@ k_g9_wgrad_pairs(const float* __restrict__ dl, const T* __restrict__ h3, float* 
     dls[i] = v;
   }
   __syncthreads();
-  // pixels in batches of 2 per thread with the batch's activation loads issued up front (one load pair per pixel in front of
-  // its 54 FMAs leaves the loop waiting a memory round trip per pixel: 2.4 TB/s); H*W % 32 == 0
-  for (int it0 = threadIdx.x >> 4; it0 < HW; it0 += 32) {
-    f32x4 ha[2], hb[2];
+  // (tried: batches of 2 / 4 pixels with their activation loads up front -- 218 / 256+ VGPRs, lower occupancy, no gain)
+  for (int it = threadIdx.x >> 4; it < HW; it += 16) {
+    const int hh = it / W, ww = it - hh * W;
+    const long pixA = (b * D + 2 * s) * HW + it;
+    const f32x4 ha = rd_ld4(h3 + pixA * 64 + c4), hb = rd_ld4(h3 + (pixA + HW) * 64 + c4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long pixA = (b * D + 2 * s) * HW + it0 + 16 * j;
-      ha[j] = rd_ld4(h3 + pixA * 64 + c4); hb[j] = rd_ld4(h3 + (pixA + HW) * 64 + c4);
-    }
+    for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int it = it0 + 16 * j;
-      const int hh = it / W, ww = it - hh * W;
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int o = (hh + 2 - kh) * PW + (ww + 2 - kw);
-            acc[(kd * 3 + kh) * 3 + kw] += dls[(2 - kd) * PHW + o] * ha[j] + dls[(3 - kd) * PHW + o] * hb[j];
-          }
-    }
+        for (int kw = 0; kw < 3; ++kw) {
+          const int o = (hh + 2 - kh) * PW + (ww + 2 - kw);
+          acc[(kd * 3 + kh) * 3 + kw] += dls[(2 - kd) * PHW + o] * ha + dls[(3 - kd) * PHW + o] * hb;
+        }
   }
   }
   // fold the 4 pixel slots of a wave (lanes l, l^16, l^32 share a channel quad), then the 4 waves through LDS
