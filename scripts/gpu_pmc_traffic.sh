@@ -4,8 +4,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/wl.py <<'PY'
-import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from pr_disagg_radar_gan_amd import Engine, weights as W
 from pr_disagg_radar_gan_amd.trainer import synthetic_batch_device
 eng = Engine(16, 256)
