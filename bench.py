@@ -54,11 +54,12 @@ def gconv3_flops(batch, nd, taps=4):
     return 2.0 * batch * 24 * nd * nd * taps * 128 * 64
 
 
-# HBM traffic of ONE launch of the dominant kernel at config 2, from separate rocprofv3 --pmc passes
-# (scripts/gpu_pmc_traffic.sh -> profiles/r01_e_pmc_hbm_traffic_gen_forward.json): FETCH_SIZE 241.6 MB x 2 (gfx950 counts
-# half the bytes of wide streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE 399.4 MB.  Algorithmic: E 109 MB + T 2 x 201 MB
-# read, 403 MB output + 6 MB 1/l2 written.  Not measurable inside this process, hence a recorded constant.
-DOMINANT_TRAFFIC_BYTES = 2 * 241.6e6 + 399.4e6
+# HBM traffic of ONE launch of the dominant kernel, from separate rocprofv3 --pmc passes (scripts/gpu_profile_r02.sh ->
+# profiles/r02_hbm_traffic_{fp32,bf16}_bs256.csv): FETCH_SIZE x 2 (gfx950 counts half the bytes of wide streaming reads,
+# MI355X_MICROARCH.md) + WRITE_SIZE.  fp32 (difference part of block 3): 495.4 MB + 409.0 MB; algorithmic: E 109 MB + T 2 x 201 MB
+# read, 403 MB output + 6 MB 1/l2 written.  bf16 storage mode (collapsed block 3): 62.8 MB + 207.6 MB; algorithmic: h2 50 MB read,
+# 201 MB output + 6 MB 1/l2 written.  Not measurable inside this process, hence recorded constants (bs 256 only).
+DOMINANT_TRAFFIC_BYTES = {False: 495.36e6 + 408.95e6, True: 62.81e6 + 207.62e6}
 
 # FLOPs of one critic / generator step per sample in the reference's direct 27-tap form, by ndomain; prices
 # the measured iteration as "direct-equivalent" TFLOP/s
@@ -333,8 +334,8 @@ def main():
                                                        "PixelNorm + LeakyReLU in the epilogue)"),
                          "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
-                         "traffic": DOMINANT_TRAFFIC_BYTES if is_metric and taps == 4 else None,
-                         "traffic_source": "profiles/r01_e_pmc_hbm_traffic_gen_forward.json (separate --pmc passes, bytes per launch)",
+                         "traffic": DOMINANT_TRAFFIC_BYTES[bf16] if (ND, B) == (16, 256) and taps == (8 if bf16 else 4) else None,
+                         "traffic_source": "profiles/r02_hbm_traffic_%s_bs256.csv (separate --pmc passes, bytes per launch)" % ("bf16" if bf16 else "fp32"),
                          "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": gconv3_flops(B, ND, taps),
                          "iteration": {"executed_gflop": round(flops_iter / 1e9, 2), "tflops": round(it_tflops, 2),
