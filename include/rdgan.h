@@ -128,7 +128,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "resident" (default 1; bf16 storage mode): the forward GEMMs of the shared-centre form whose tile holds whole source
  * planes keep the tile's source rows resident in LDS and stream only the weights (each source row is fetched once per
  * channel chunk instead of once per tap and chunk); same arithmetic in the same order, bit-identical to 0.
- * "edge_kernels" (default 1): in the bf16 storage mode the generator's last conv (64 -> 1) runs in its dedicated streaming
+ * "edge_kernels" (default 1): the first critic layer (2 -> 64 channels, K = 54; one condition channel) runs as one K = 64 GEMM
+ * per 128-row tile -- forward, the penalty's second sweep and the weight gradient (rdgan_edge.hip.h) -- instead of nine K
+ * chunks of the tiled kernel; and in the bf16 storage mode the generator's last conv (64 -> 1) runs in its dedicated streaming
  * kernel (one pass over the block-3 output at HBM speed, same arithmetic and tap-sum format as "tapgather"); 2 = also with
  * fp32 storage (bit-identical to the tiled GEMM, not faster there); 0 = the tiled GEMM kernel everywhere.
  * "sample_offset" (default 0): global index of this rank's first sample.  RandomWeightedAverage's alpha (T:222-223) of

@@ -1438,6 +1438,46 @@ static inline const float* d1_weights(const rdgan_handle* h, const float* dp) {
   return h->CP != h->Cin ? h->W1P : dp + h->doff[0];
 }
 
+// First critic layer as one K = 64 GEMM per tile (rdgan_edge.hip.h): one condition channel (2 floats per voxel), any ndomain
+static bool d1_gemm_ok(const rdgan_handle* h) { return h->edge_kernels && h->CP == 2 && h->Cin == 2; }
+static int launch_d1_fwd(rdgan_handle* h, const float* in, const float* w, const float* bias, float* out, const float* aux, int NBt,
+                         int mode, int use_drop, uint32_t key, uint32_t idx_base, hipStream_t st) {
+  ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+  const long rows = (long)NBt * h->dL[1];
+  h->flops_acc += 2.0 * rows * 54 * 64;
+  constexpr size_t lds = (size_t)(128 * 64 + 64 * 64) * 4 + 2 * 128 * 8;
+  const dim3 grid((unsigned)std::min<long>((rows + 127) / 128, 768));       // three workgroups per CU, each walks its tiles
+  const int nd = h->nd, Do = h->ddim[1][0], Ho = h->ddim[1][1], Wo = h->ddim[1][2];
+#define RD_D1F(TO, MODE)                                                                                                   \
+  do {                                                                                                                     \
+    RD_TRY(ensure_lds(h, (const void*)k_d1_gemm_fwd<TO, MODE>, lds));                                                      \
+    hipLaunchKernelGGL((k_d1_gemm_fwd<TO, MODE>), grid, dim3(256), lds, st, in, w, bias, (TO*)out, (const TO*)aux, rows, nd, \
+                       Do, Ho, Wo, use_drop, key, idx_base);                                                               \
+  } while (0)
+  if (h->a16) { if (mode == 0) RD_D1F(rd_bf16_t, 0); else RD_D1F(rd_bf16_t, 1); }
+  else { if (mode == 0) RD_D1F(float, 0); else RD_D1F(float, 1); }
+#undef RD_D1F
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+static int launch_d1_wgrad(rdgan_handle* h, const float* in, const float* u1, float* dW, int NBt, hipStream_t st) {
+  ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+  const long rows = (long)NBt * h->dL[1];
+  h->flops_acc += 2.0 * rows * 54 * 64;
+  // one slice of rows per workgroup: four workgroups per CU, whole 32-row chunks
+  long G = std::min<long>(1024, (rows + 31) / 32);
+  long rpw = ((rows + G - 1) / G + 31) / 32 * 32;
+  G = (rows + rpw - 1) / rpw;
+  if ((size_t)G * 4096 > h->wpartial_cap) return bad_arg(h, "d1 wgrad: partial workspace too small");
+  const int nd = h->nd, Do = h->ddim[1][0], Ho = h->ddim[1][1], Wo = h->ddim[1][2];
+  if (h->a16) hipLaunchKernelGGL(k_d1_gemm_wgrad<rd_bf16_t>, dim3((unsigned)G), dim3(256), 0, st, in, (const rd_bf16_t*)u1, h->wpartial, rows,
+                                 rpw, nd, Do, Ho, Wo);
+  else hipLaunchKernelGGL(k_d1_gemm_wgrad<float>, dim3((unsigned)G), dim3(256), 0, st, in, u1, h->wpartial, rows, rpw, nd, Do, Ho, Wo);
+  hipLaunchKernelGGL(k_d1_wgrad_fold, dim3(54 * 64 / 16), dim3(256), 0, st, h->wpartial, (int)G, dW);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
 // forward over NBt samples already laid out in h->cin; writes h->dh[1..4], h->v
 static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64_t seed, hipStream_t st) {
   const int use_drop = seed != 0;
@@ -1448,7 +1488,9 @@ static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64
     RdEpi ep = epi_make(RD_EPI_BIAS_LRELU_DROP, dp + h->doff[2 * (l - 1) + 1], nullptr, use_drop,
                         rd_make_key(seed, RD_STREAM_D1 + l - 1), 0);
     ep.out16 = a16;
-    if (a16 && l == 1)
+    if (l == 1 && d1_gemm_ok(h))
+      RD_TRY(launch_d1_fwd(h, in, dp + h->doff[0], dp + h->doff[1], h->dh[1], nullptr, NBt, 0, use_drop, ep.key, 0, st));
+    else if (a16 && l == 1)
       RD_TRY(launch_conv_a16(h, h->plans[pl], h->d_plans + pl, NBt, in, d1_weights(h, dp), h->dch[l], h->dh[l], ep, st,
                              RDGAN_TAG_CRITIC_GEMM, false, true));
     else if (a16)
@@ -1568,7 +1610,9 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
       float* dst = act_off(h, h->dh[l], third);
       RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, dst, use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 1), (uint32_t)third);
       ep.out16 = a16;
-      if (a16 && l == 1)
+      if (l == 1 && d1_gemm_ok(h))
+        RD_TRY(launch_d1_fwd(h, in, dp + h->doff[0], nullptr, dst, dst, B, 1, use_drop, ep.key, (uint32_t)third, st));
+      else if (a16 && l == 1)
         RD_TRY(launch_conv_a16(h, h->plans[pl], h->d_plans + pl, B, in, d1_weights(h, dp), h->dch[l], dst, ep, st,
                                RDGAN_TAG_CRITIC_GEMM, false, true));
       else if (a16)
@@ -1584,7 +1628,9 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
     int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
     const float* in = l == 1 ? h->cin : h->dh[l - 1];
     const bool padded = l == 1 && h->CP != h->Cin;   // D1 with padding channels: gradient of the padded kernel, then drop the pad rows
-    if (a16 && l >= 2) {      // layers 2-4: bf16 activations against bf16 output gradients
+    if (l == 1 && d1_gemm_ok(h)) {
+      RD_TRY(launch_d1_wgrad(h, in, h->du[1], grad + h->doff[0], NBt, st));
+    } else if (a16 && l >= 2) {      // layers 2-4: bf16 activations against bf16 output gradients
       if (!wgrad16_ok(h->plans[pl], NBt)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this critic layer");
       RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], grad + h->doff[2 * (l - 1)], h->wpartial,
                             h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM));

@@ -1,8 +1,9 @@
-// Dedicated kernel for the generator's last Conv3D (64 -> 1, T:345), whose GEMM shape (K = 64, N = 27) is too thin for the
-// tiled conv kernels: it is an HBM-bound stream over the block-3 output, and the tiled kernel spends its time in per-tile
-// prologues instead.  (Round 2 also tried dedicated kernels for the critic's first Conv3D (2 -> 64 channels, K = 54): a
-// sample-in-LDS version is bound by LDS broadcasts, versions feeding the FMAs from scalar loads run into SGPR spills (forward)
-// or scalar-cache misses (weight gradient); none beat the implicit-GEMM path, so that layer stays on it.)
+// Dedicated kernels for the two "edge" convolutions of the step, whose GEMM shapes are too thin for the tiled conv kernels:
+// the generator's last Conv3D (64 -> 1: K = 64, N = 27; T:345) and the critic's first Conv3D (2 -> 64 channels, stride 2
+// 'valid': K = 54; T:286).  The tiled kernels spend their time in per-tile prologues and (first critic layer) in nine K chunks
+// of 8 with a barrier each.  What did NOT work for the first critic layer (round 2): a whole sample in LDS with FMAs on
+// LDS-broadcast inputs (LDS-bound), FMAs fed from scalar loads (SGPR spills in the forward, scalar-cache misses in the weight
+// gradient).  What does: the im2col row as ONE K = 64 operand row staged through registers, the matrix pipe, persistent tiles.
 #pragma once
 #include "rdgan_gemm_ws.hip.h"
 
@@ -136,5 +137,334 @@ k_g9_fwd(const T* __restrict__ h3, const float* __restrict__ w9 /* [27][64] */, 
       }
     }
     Q[(pl * NQ + j) * HW + hw] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// First critic layer (T:286-289): Conv3D(64, 3x3x3, stride 2, 'valid') on the 2-channel volume (sample | condition),
+// as ONE K = 64 GEMM per tile: an output position's im2col row is 9 (kd,kh) segments of 6 contiguous floats (kw, ci) =
+// 54 values, padded to 64.  The tiled conv kernel walks the 9 segments as 9 K chunks of 8 (6 used) with a barrier each;
+// here a workgroup stages the whole [128 rows][64] operand once (each segment = three 8-byte loads), multiplies it against
+// the kernel [64][64] (rows 54.. zero) on the fp32 matrix pipe (exact, k in the reference's tap order), and runs the
+// layer's epilogue on the tile.  Any ndomain; one condition channel (2 floats per voxel).
+// MODE 0: out = dropout(LeakyReLU(conv + bias))                        (forward, T:286-289)
+// MODE 1: out = gate(aux) * conv, gate = LeakyReLU'(aux) * dropout     (second forward sweep of the gradient penalty; aux may be out)
+// TO = element type of out / aux (bf16 storage mode).  idx_base: added to the flat output index for the dropout counter.
+// rows = samples * NPOS; cin [samples][D][nd][nd][2].
+// ------------------------------------------------------------------------------------
+// A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: the kernel image is staged once, and the next tile's
+// segment loads are issued (into registers) before the current tile's epilogue, which hides their latency.
+template <typename TO, int MODE>
+__global__ void __launch_bounds__(256, 3)
+k_d1_gemm_fwd(const float* __restrict__ cin, const float* __restrict__ w, const float* __restrict__ bias, TO* out, const TO* aux,
+              long rows, int nd, int Do, int Ho, int Wo, int use_drop, uint32_t key, uint32_t idx_base) {
+  constexpr int BM = 128;
+  constexpr bool BF = sizeof(TO) == 2;    // bf16 storage mode: operands rounded to bf16, v_mfma_f32_32x32x16_bf16
+  constexpr int NSG = (BM * 9 + 255) / 256;             // segments per thread (5; the last one only for tid < 128)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // fp32: As [128 rows][64 k] floats, 16-byte chunk c of row r at c ^ (r & 15);  Ws [64 k][64 n]
+  // bf16: As [128 rows] of 128 bytes,  chunk c at c ^ ((r >> 1) & 7);            Ws [64 n] rows of 128 bytes (k), same swizzle
+  // the As region is reused for the fp32 output tile [128][64] (32 KiB); behind Ws: two row-offset tables
+  float* As = smem;
+  float* Ws = smem + BM * 64;
+  long* rowoff = (long*)(smem + BM * 64 + 64 * 64);     // [2][128] element offset of the row's window in cin, -1 = no row
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  const int NPOS = Do * Ho * Wo, HoWo = Ho * Wo;
+  const long nin = (long)RDGAN_NHOURS * nd * nd * 2;
+  const long ntiles = (rows + BM - 1) / BM;
+  auto decode_rows = [&](long tile, int slot) {        // threads 0 .. 127: one row each
+    if (tid < BM) {
+      const long m = tile * BM + tid;
+      long off = -1;
+      if (m < rows) {
+        const long b = m / NPOS;
+        const int p = (int)(m - b * NPOS);
+        const int od = p / HoWo, q = p - od * HoWo, oh = q / Wo, ow = q - oh * Wo;
+        off = b * nin + ((long)(2 * od * nd + 2 * oh) * nd + 2 * ow) * 2;
+      }
+      rowoff[slot * BM + tid] = off;
+    }
+  };
+  float2 sa[NSG][3];
+  auto load_segments = [&](int slot) {                 // consecutive lanes: consecutive rows of one segment (kd,kh)
+#pragma unroll
+    for (int u = 0; u < NSG; ++u) {
+      const int sgi = tid + u * 256;
+      float2 a = {0.f, 0.f}, c = a, e = a;
+      if (sgi < BM * 9) {
+        const int sg = sgi >> 7, r = sgi & (BM - 1);
+        const long off = rowoff[slot * BM + r];
+        if (off >= 0) {
+          const int kd = sg / 3, kh = sg - kd * 3;
+          const float* src = cin + off + (kd * nd + kh) * nd * 2;
+          a = *(const float2*)src; c = *(const float2*)(src + 2); e = *(const float2*)(src + 4);
+        }
+      }
+      sa[u][0] = a; sa[u][1] = c; sa[u][2] = e;
+    }
+  };
+  // kernel [54][64] (+ zero rows) in the operand layout, once
+  if constexpr (BF) {
+    for (int i = tid; i < 64 * 8; i += 256) {            // (n, chunk c): 8 consecutive k
+      const int n = i >> 3, c = i & 7;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int k = c * 8 + e; v[e] = k < 54 ? w[k * 64 + n] : 0.f; }
+      u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
+      *(u32x4_t*)((char*)Ws + n * 128 + ((c ^ ((n >> 1) & 7)) * 16)) = o;
+    }
+  } else {
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int k = i >> 4;
+      f32x4 wq = {0.f, 0.f, 0.f, 0.f};
+      if (k < 54) wq = *(const f32x4*)(w + 4 * i);
+      *(f32x4*)&Ws[4 * i] = wq;
+    }
+  }
+  const int c4 = (tid & 15) * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 0) bias4 = *(const f32x4*)(bias + c4);
+  long tile = blockIdx.x;
+  int slot = 0;
+  if (tile < ntiles) decode_rows(tile, 0);
+  __syncthreads();
+  if (tile < ntiles) load_segments(0);
+  for (; tile < ntiles; tile += gridDim.x, slot ^= 1) {
+    const long m0 = tile * BM;
+    // ---- this tile's operand rows: registers -> LDS (segment sg -> logical k = 6 sg .. 6 sg + 5, then zero to 63)
+#pragma unroll
+    for (int u = 0; u < NSG; ++u) {
+      const int sgi = tid + u * 256;
+      if (sgi < BM * 9) {
+        const int sg = sgi >> 7, r = sgi & (BM - 1), k0 = sg * 6;
+        if constexpr (BF) {
+          char* rowp = (char*)As + r * 128;
+          const int sw = (r >> 1) & 7;
+          // bf16 pair holding k, k + 1: byte (k & 7) * 2 of chunk k >> 3
+          *(unsigned*)(rowp + ((((k0) >> 3) ^ sw) * 16) + ((k0) & 7) * 2) = rd_pack_bf16(sa[u][0].x, sa[u][0].y);
+          *(unsigned*)(rowp + ((((k0 + 2) >> 3) ^ sw) * 16) + ((k0 + 2) & 7) * 2) = rd_pack_bf16(sa[u][1].x, sa[u][1].y);
+          *(unsigned*)(rowp + ((((k0 + 4) >> 3) ^ sw) * 16) + ((k0 + 4) & 7) * 2) = rd_pack_bf16(sa[u][2].x, sa[u][2].y);
+        } else {
+          float* rowp = As + r * 64;
+          const int sw = r & 15;
+          *(float2*)(rowp + ((((k0) >> 2) ^ sw) << 2) + ((k0) & 3)) = sa[u][0];
+          *(float2*)(rowp + ((((k0 + 2) >> 2) ^ sw) << 2) + ((k0 + 2) & 3)) = sa[u][1];
+          *(float2*)(rowp + ((((k0 + 4) >> 2) ^ sw) << 2) + ((k0 + 4) & 3)) = sa[u][2];
+        }
+      }
+    }
+    for (int i = tid; i < BM * 5; i += 256) {            // k = 54 .. 63: zero (five pairs per row)
+      const int r = i / 5, k = 54 + 2 * (i - r * 5);
+      if constexpr (BF) *(unsigned*)((char*)As + r * 128 + (((k >> 3) ^ ((r >> 1) & 7)) * 16) + (k & 7) * 2) = 0u;
+      else *(float2*)(As + r * 64 + (((k >> 2) ^ (r & 15)) << 2) + (k & 3)) = (float2){0.f, 0.f};
+    }
+    const long next = tile + gridDim.x;
+    if (next < ntiles) decode_rows(next, slot ^ 1);
+    __syncthreads();
+    // ---- each wave: 32 rows x 64 columns
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    {
+      const int i = wave * 32 + l31;
+      if constexpr (BF) {
+        const char* Ab = (const char*)As + i * 128;
+        const int a_sw = (i >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const f32x4 fa = *(const f32x4*)(Ab + (((kk * 2 + lhalf) ^ a_sw) * 16));
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = j * 32 + l31;
+            const f32x4 fb = *(const f32x4*)((const char*)Ws + n * 128 + (((kk * 2 + lhalf) ^ ((n >> 1) & 7)) * 16));
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, fa), __builtin_bit_cast(rd_bf16x8, fb),
+                                                             acc[j], 0, 0, 0);
+          }
+        }
+      } else {
+        const float* Wl = Ws + lhalf * 4 * 64 + l31;
+#pragma unroll
+        for (int j8 = 0; j8 < 8; ++j8) {
+          const f32x4 fa = *(const f32x4*)&As[i * 64 + (((j8 * 2 + lhalf) ^ (i & 15)) << 2)];
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], Wl[(j8 * 8 + s) * 64 + j * 32], acc[j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                         // operand reads done (the region becomes the output tile); next row offsets visible
+    if (next < ntiles) load_segments(slot ^ 1);        // in flight during the epilogue below
+    float* Cs = smem;                        // [128][64]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        Cs[row * 64 + j * 32 + l31] = acc[j][r];
+      }
+    __syncthreads();
+    // ---- epilogue: thread -> channel quad tid % 16, rows tid / 16 + 16 k
+#pragma unroll 4
+    for (int row = tid >> 4; row < BM; row += 16) {
+      const long m = m0 + row;
+      if (m >= rows) break;
+      f32x4 v = *(const f32x4*)&Cs[row * 64 + c4];
+      const long idx = m * 64 + c4;
+      if (MODE == 0) {
+        v += bias4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = rd_lrelu(v[e]);
+          if (use_drop) t *= rd_drop_scale(key, (uint32_t)idx + idx_base + e);
+          v[e] = t;
+        }
+      } else {
+        const f32x4 a4 = rd_ld4(aux + idx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float g = rd_lrelu_slope_from_out(a4[e]);
+          if (use_drop) g *= rd_drop_scale(key, (uint32_t)idx + idx_base + e);
+          v[e] *= g;
+        }
+      }
+      rd_st4(out + idx, v);
+    }
+    __syncthreads();                         // output tile read: the region may take the next operand rows
+  }
+}
+
+// Weight gradient of the same layer: dW1[(tap,ci)][co] = sum over rows of im2col[row][(tap,ci)] * u1[row][co], as a GEMM
+// with the rows as K: a workgroup owns a contiguous slice of rows, stages 32 rows at a time (the im2col rows as above, u1 as
+// fp32) and accumulates the [64][64] product (wave = one 32x32 quadrant) on the fp32 matrix pipe; partial[blockIdx.x][64][64]
+// (rows 54.. unused) goes to k_d1_wgrad_fold.  Fixed order: deterministic.  TG = element type of u1.
+template <typename TG>
+__global__ void __launch_bounds__(256, 4)
+k_d1_gemm_wgrad(const float* __restrict__ cin, const TG* __restrict__ u1, float* __restrict__ partial, long rows,
+                long rows_per_wg, int nd, int Do, int Ho, int Wo) {
+  constexpr int BKR = 32;                   // rows per chunk
+  constexpr int AST = 68;                   // im2col row stride in floats: consecutive rows 4 banks apart (64 would put a column in one bank)
+  __shared__ __attribute__((aligned(16))) float As[2][BKR * AST];    // [row][k] (k >= 54: zero)
+  __shared__ __attribute__((aligned(16))) float Gs[2][BKR * 64];     // [row][co]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long mbeg = (long)blockIdx.x * rows_per_wg, mend = min(rows, mbeg + rows_per_wg);
+  const int NPOS = Do * Ho * Wo, HoWo = Ho * Wo;
+  const long nin = (long)RDGAN_NHOURS * nd * nd * 2;
+  const int nchunks = mend > mbeg ? (int)((mend - mbeg + BKR - 1) / BKR) : 0;
+  for (int i = tid; i < 2 * BKR * 10; i += 256) {      // the zero columns k = 54 .. 63 of both stages, once
+    const int st = i / (BKR * 10), j = i - st * (BKR * 10), r = j / 10;
+    As[st][r * AST + 54 + (j - r * 10)] = 0.f;
+  }
+  // element offset of each row's window in cin (-1 = no row), decoded by 32 threads one chunk ahead of its loads
+  __shared__ long rowoff[2][BKR];
+  auto decode_rows = [&](int q) {
+    if (tid < BKR) {
+      const long m = mbeg + (long)q * BKR + tid;
+      long off = -1;
+      if (m < mend) {
+        const long b = m / NPOS;
+        const int p = (int)(m - b * NPOS);
+        const int od = p / HoWo, qq = p - od * HoWo, oh = qq / Wo, ow = qq - oh * Wo;
+        off = b * nin + ((long)(2 * od * nd + 2 * oh) * nd + 2 * ow) * 2;
+      }
+      rowoff[q & 1][tid] = off;
+    }
+  };
+  // staging is split: the loads of chunk q + 1 go out in front of chunk q's MFMAs, their LDS writes come behind them
+  constexpr int NSG = (BKR * 9 + 255) / 256;          // im2col segments per thread (2)
+  constexpr int NGQ = BKR * 16 / 256;                 // u1 quads per thread (2)
+  float2 sa[NSG][3];
+  f32x4 sg_[NGQ];
+  auto load_regs = [&](int q) {
+    const long mb = mbeg + (long)q * BKR;
+#pragma unroll
+    for (int u = 0; u < NSG; ++u) {
+      const int sgi = tid + u * 256;
+      const int sg = sgi >> 5, r = sgi & (BKR - 1);           // (lanes along the rows of one segment: see k_d1_gemm_fwd)
+      float2 a = {0.f, 0.f}, c = a, e = a;
+      const long off = sgi < BKR * 9 ? rowoff[q & 1][r] : -1;
+      if (off >= 0) {
+        const int kd = sg / 3, kh = sg - kd * 3;
+        const float* src = cin + off + (kd * nd + kh) * nd * 2;
+        a = *(const float2*)src; c = *(const float2*)(src + 2); e = *(const float2*)(src + 4);
+      }
+      sa[u][0] = a; sa[u][1] = c; sa[u][2] = e;
+    }
+#pragma unroll
+    for (int u = 0; u < NGQ; ++u) {
+      const int i = tid + u * 256;
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      const long m = mb + r;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (m < mend) g = rd_ld4(u1 + m * 64 + c4);
+      sg_[u] = g;
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NSG; ++u) {
+      const int sgi = tid + u * 256;
+      if (sgi < BKR * 9) {
+        const int sg = sgi >> 5, r = sgi & (BKR - 1);
+        float* d = &As[buf][r * AST + sg * 6];
+        *(float2*)d = sa[u][0]; *(float2*)(d + 2) = sa[u][1]; *(float2*)(d + 4) = sa[u][2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NGQ; ++u) {
+      const int i = tid + u * 256;
+      *(f32x4*)&Gs[buf][(i >> 4) * 64 + (i & 15) * 4] = sg_[u];
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  decode_rows(0); decode_rows(1);                      // (rows beyond mend decode to -1)
+  __syncthreads();
+  if (nchunks > 0) { load_regs(0); store_lds(0); }
+  __syncthreads();
+  for (int q = 0; q < nchunks; ++q) {
+    const int buf = q & 1;
+    if (q + 1 < nchunks) load_regs(q + 1);
+    decode_rows(q + 2);                                  // slot q & 1: last read by load_regs(q), a barrier ago
+    // A operand = im2col^T: lane (i = l31, k = lhalf) <- As[row = 2 s + lhalf][wm * 32 + l31]; B = u1[row][wn * 32 + l31]
+    const float* Al = &As[buf][lhalf * AST + wm * 32 + l31];
+    const float* Gl = &Gs[buf][lhalf * 64 + wn * 32 + l31];
+#pragma unroll
+    for (int s = 0; s < BKR / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Al[s * 2 * AST], Gl[s * 128], acc, 0, 0, 0);
+    if (q + 1 < nchunks) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+  float* o = partial + (long)blockIdx.x * 4096;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+    o[row * 64 + wn * 32 + l31] = acc[r];
+  }
+}
+// dW1[i] = sum over workgroups of partial[g][i], i < 54 * 64 (fixed order)
+// (block = 16 outputs x 16 slices of the workgroup range, folded through LDS in a fixed order)
+__global__ void __launch_bounds__(256)
+k_d1_wgrad_fold(const float* __restrict__ partial, int G, float* __restrict__ dw) {
+  __shared__ float red[256];
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+  float s = 0.f;
+  if (i < 54 * 64)
+    for (int g = sl; g < G; g += 16) s += partial[(long)g * 4096 + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && i < 54 * 64) {
+    float t = red[threadIdx.x];
+    for (int j = 1; j < 16; ++j) t += red[j * 16 + threadIdx.x];
+    dw[i] = t;
   }
 }

@@ -295,6 +295,40 @@ def test_last_conv_streaming_kernel_equals_the_tiled_gemm(nd, B):
         eng.close()
 
 
+@pytest.mark.parametrize("nd,B,seed", [(16, 5, 77), (8, 3, 0), (64, 1, 5)])
+def test_first_critic_layer_gemm_kernels_equal_the_tiled_path(nd, B, seed):
+    """"edge_kernels": the first critic layer as one K = 64 GEMM per tile (forward, second sweep of the gradient penalty,
+    weight gradient) against the tiled implicit-GEMM path of the same engine -- same products; the forward sums in the same k
+    order, the weight gradient folds its row slices in another order (1e-6) -- and against the oracle."""
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 34)
+        x, cond, z = ot.synthetic_batch(B, nd, 20)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        v1 = eng.critic_forward(ds, dev(x), dev(cond), seed=seed).cpu().numpy()
+        c1 = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), seed).cpu().numpy()
+        g1 = eng.gen_grad(ds, gs, dev(z), dev(cond), seed).cpu().numpy()
+        eng.set_option("edge_kernels", 0)
+        v0 = eng.critic_forward(ds, dev(x), dev(cond), seed=seed).cpu().numpy()
+        c0 = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), seed).cpu().numpy()
+        g0 = eng.gen_grad(ds, gs, dev(z), dev(cond), seed).cpu().numpy()
+        assert rel_err(v1, v0) < 1e-5
+        n = eng.n_critic
+        np.testing.assert_allclose(c1[n:n + 4], c0[n:n + 4], rtol=1e-5, atol=1e-7)
+        off = 0
+        for name, s in eng.critic_shapes:
+            k = int(np.prod(s))
+            if name != "dense_1/bias:0":
+                assert rel_err(c1[off:off + k], c0[off:off + k]) < 2e-5, name
+            off += k
+        assert rel_err(g1[:eng.n_gen], g0[:eng.n_gen]) < 2e-5
+        masks = ot.critic_masks(seed, B, nd, torch.float64)
+        ref = ot.critic_forward(_t64(d), torch.from_numpy(x).double(), torch.from_numpy(cond).double(), masks).numpy()
+        assert rel_err(v1, ref) < 2e-5
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [9, 33])
 def test_odd_batches_default_options(B):
     """Batches that leave partial tiles everywhere (rows % 128 != 0, tiles spanning several samples), default options:
