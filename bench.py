@@ -31,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+L2_TO_LDS_PEAK_TBPS = 17.8         # rows gathered from L2 into LDS, chip-wide: 16.8-18.8 TB/s measured (MI355X_MICROARCH.md, "Indexed rows")
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles): 16x the fp32 rate
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable with a float4 copy)
 
@@ -315,8 +316,8 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": cfg["name"] if (ND, n_critic) == (cfg["nd"], cfg["n_critic"]) and args.batch is None
-                                   else f"ndomain={ND}, 24h, bs={B} per GPU, n_critic={n_critic}",
+            "config": {"workload": cfg["name"] if (ND, n_critic, bf16) == (cfg["nd"], cfg["n_critic"], bool(cfg["bf16"])) and args.batch is None
+                                   else f"ndomain={ND}, 24h, bs={B} per GPU, {'bf16 storage' if bf16 else 'fp32'}, n_critic={n_critic}",
                        "batch_per_gpu": B, "global_batch": world * B, "n_critic": n_critic, "parallelism": f"dp{world}",
                        "world": world, "rccl_ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
                        "exchange": None if world == 1 else ("one all-reduce of the flat gradient slab per optimizer update"
@@ -345,8 +346,20 @@ def main():
                                                "elementwise kernels' time"},
                          "iteration_direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2),
                          "kernel_classes": classes},
-            "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},
         }
+        if bf16 and taps == 8 and ND == 16 and B >= 22 and kern_n:
+            # what binds the bf16 launch: every K chunk of a 256x64 tile is a 40 KB stage pulled from L2 into LDS (32 KB of rows +
+            # 8 KB of weights, 16 chunks per tile, 24 tiles per sample; PMC TCC_REQ x 128 B per launch agrees within 5 %,
+            # profiles/r02_l2_requests_bf16_bs256.csv) and LDS holds one stage in flight per workgroup, two workgroups per CU.
+            # Ceiling of that path: the guide's measured L2 -> LDS gather rate, 16.8-18.8 TB/s chip-wide.
+            fill = B * 24 * 16 * (32768 + 8192)
+            out["roofline"]["lds_fill"] = {"bytes_per_launch": fill, "achieved_TBps": round(fill / (avg_ms * 1e-3) / 1e12, 2),
+                                           "peak_TBps": L2_TO_LDS_PEAK_TBPS, "frac": round(fill / (avg_ms * 1e-3) / 1e12 / L2_TO_LDS_PEAK_TBPS, 3),
+                                           "note": "L2 -> LDS fill of the streaming tiles: the resource this launch runs closest to "
+                                                   "(MFMA 0.32, HBM 0.13 of their roofs)"}
+        out.update({
+            "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},
+        })
         if world == 1 and not args.no_cpu_baseline and ND == 16:
             # bounded sample: the default configuration's iteration at the GPU line's batch (~6 s per CPU iteration);
             # n_critic = 5 configurations at bs 64 so that the default run still ends within minutes

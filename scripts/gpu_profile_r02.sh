@@ -15,11 +15,12 @@ run_stats() {   # name, bench args...
 run_stats fp32_bs256 --steps 10 --warmup 3 && \
 run_stats bf16_bs256 --steps 10 --warmup 3 --opt bf16=1 && \
 run_stats bf16_cfg3 --config 3 --steps 3 --warmup 1 || exit 1
+# third pass: L2 requests (128 B each) / hits / misses -- what a kernel pulls through L2 into LDS, against its HBM bytes
 for mode in 0 1; do
-  for set in FETCH_SIZE WRITE_SIZE; do
-    d=$O/pmc_bf16${mode}_$set
+  for set in FETCH_SIZE WRITE_SIZE "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+    d=$O/pmc_bf16${mode}_${set%% *}
     timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $d -- python3 $R/scripts/wl_iteration.py --bf16 $mode > $d.log 2>&1 || { echo "pmc $mode $set failed"; tail -5 $d.log; exit 1; }
-    find $d -name "*counter_collection.csv" -exec cp {} $O/pmc_bf16${mode}_$set.csv \;
+    find $d -name "*counter_collection.csv" -exec cp {} $O/pmc_bf16${mode}_${set%% *}.csv \;
     rm -rf $d
   done
 done
