@@ -133,6 +133,11 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * chunks of the tiled kernel; and in the bf16 storage mode the generator's last conv (64 -> 1) runs in its dedicated streaming
  * kernel (one pass over the block-3 output at HBM speed, same arithmetic and tap-sum format as "tapgather"); 2 = also with
  * fp32 storage (bit-identical to the tiled GEMM, not faster there); 0 = the tiled GEMM kernel everywhere.
+ * "side_stream" (default 1): inside a call the weight-only kernels (generator weight forms, critic weight transposes and
+ * bf16 images) and the bias-gradient column sums are issued on a second stream owned by the handle, beside the GEMMs on the
+ * caller's stream and ordered against it by events (fork at entry, joins in front of the first reader / at the end of the
+ * call): ~50 launches of 5-30 us per iteration leave the critical path.  The call's contract is unchanged (everything is
+ * complete when `stream` is); same kernels on the same data, results bit-identical to 0.
  * "sample_offset" (default 0): global index of this rank's first sample.  RandomWeightedAverage's alpha (T:222-223) of
  * local sample k is uniform(key(seed, ALPHA), sample_offset + k), so ranks that share a seed draw the alphas of the
  * global batch (used by the data-parallel equivalence tests; the dropout masks stay keyed by the local element index).

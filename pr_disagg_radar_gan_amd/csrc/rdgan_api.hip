@@ -377,7 +377,7 @@ struct rdgan_handle {
   // [64][Cout][Cin] and (re-ordered by tap) [64][Cin][Cout], the first critic kernel [ldp1][64]
   void *bU[4], *bUT;
   void *bWF[5], *bWB[5];
-  void *bG1F, *bG1B, *bW1B;
+  void *bG1F[4], *bG1B, *bW1B;
   int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
   int g9_direct = 1;              // 1: backward of the 64 -> 1 conv straight from the dlogits (no im2col matrix), fused with block 3's PixelNorm backward
   int fast_fwd = -1;              // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products); -1: by storage mode
@@ -390,6 +390,13 @@ struct rdgan_handle {
   int resident = 1;               // 1: bf16 forward GEMMs of the shared-centre form keep the tile's source rows resident in LDS (k_conv_gemm_ws<..., RES>)
   int edge_kernels = 1;           // 1: dedicated streaming kernels for the generator's last conv (rdgan_edge.hip.h); 0: the tiled GEMM kernels
   int sample_offset = 0;          // global index of this rank's first sample: RandomWeightedAverage's alpha of sample k is uniform(key, sample_offset + k)
+  float* g9b_tmp;                 // 64 partial sums of the last conv's bias gradient
+  // Side stream (option "side_stream", default on): weight-only kernels (generator weight forms, critic weight transposes /
+  // bf16 images) and the bias-gradient column sums run beside the caller's stream, ordered by events: ~50 launches of 5-30 us
+  // per iteration that would otherwise sit between the GEMMs.  Same kernels, same arithmetic: results are bit-identical.
+  int side_on = 1;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cw = nullptr, ev_g[4] = {nullptr, nullptr, nullptr, nullptr};
   int* d_flag;
   // kernels whose dynamic-LDS limit has been raised on THIS handle's device (hipFuncSetAttribute is per device; keeping the
   // record per handle rather than per process makes two handles on two devices, or on two threads, independent)
@@ -422,11 +429,27 @@ static int bad_arg(rdgan_handle* h, const char* msg) {
   return -2;
 }
 
+// side stream ordered behind everything issued on `st` so far (or `st` itself with the option off)
+static hipStream_t side_fork(rdgan_handle* h, hipStream_t st) {
+  if (!h || !h->side_on || !h->side) return st;
+  if (hipEventRecord(h->ev_fork, st) != hipSuccess || hipStreamWaitEvent(h->side, h->ev_fork, 0) != hipSuccess) return st;
+  return h->side;
+}
+// `st` waits for everything issued on the side stream so far
+static int side_join(rdgan_handle* h, hipStream_t st, hipEvent_t ev);
+
 // raise a kernel's dynamic shared-memory limit once per handle (always, for the handle-less op-level entry points)
 static int ensure_lds(rdgan_handle* h, const void* kern, size_t lds) {
   if (h && h->lds_attr_done.count(kern)) return 0;
   RD_CHECK(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (h) h->lds_attr_done.insert(kern);
+  return 0;
+}
+
+static int side_join(rdgan_handle* h, hipStream_t st, hipEvent_t ev) {
+  if (!h || !h->side_on || !h->side || st == h->side) return 0;
+  RD_CHECK(h, hipEventRecord(ev, h->side));
+  RD_CHECK(h, hipStreamWaitEvent(st, ev, 0));
   return 0;
 }
 
@@ -1133,13 +1156,15 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
           carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->bWF[l] = p;
           carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->bWB[l] = p;
         }
-        carve(p, 32L * 256 * 256 + 8); h->bG1F = p;
+        h->bG1F[0] = nullptr;
+        for (int l = 1; l <= 3; ++l) { carve(p, 32L * gch[l - 1] * gch[l] + 8); h->bG1F[l] = p; }
         carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
         carve(p, 32L * h->ldp1 + 8); h->bW1B = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
     }
     { float* f = nullptr; carve(f, 64); if (pass == 1) h->d_flag = (int*)f; }
+    carve(h->g9b_tmp, 64);
     if (pass == 0) {
       h->ws_bytes = off + 256;
       e = hipMalloc((void**)&h->ws, h->ws_bytes);
@@ -1147,12 +1172,21 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
       (void)hipMemset(h->ws, 0, h->ws_bytes);
     }
   }
+  // side stream + ordering events (no timing); failure to create them only turns the option off
+  {
+    bool ok = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+    hipEvent_t* evs[] = {&h->ev_fork, &h->ev_join, &h->ev_cw, &h->ev_g[1], &h->ev_g[2], &h->ev_g[3]};
+    for (hipEvent_t* e2 : evs) ok = ok && hipEventCreateWithFlags(e2, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { h->side_on = 0; (void)hipGetLastError(); }
+  }
   *out = h;
   return 0;
 }
 
 extern "C" void rdgan_destroy(rdgan_handle* h) {
   if (!h) return;
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  for (hipEvent_t e2 : {h->ev_fork, h->ev_join, h->ev_cw, h->ev_g[1], h->ev_g[2], h->ev_g[3]}) if (e2) (void)hipEventDestroy(e2);
   for (int t = 0; t < RDGAN_NUM_TAGS; ++t) {
     for (auto e : h->ev_start[t]) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop[t]) (void)hipEventDestroy(e);
@@ -1188,6 +1222,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value < 0 ? -1 : (value ? 1 : 0); return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "side_stream")) { h->side_on = (value && h->side) ? 1 : 0; return 0; }
   if (!strcmp(name, "edge_kernels")) { h->edge_kernels = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   if (!strcmp(name, "sample_offset")) { if (value < 0) return bad_arg(h, "set_option: sample_offset < 0"); h->sample_offset = value; return 0; }
   if (!strcmp(name, "ws_ksplit")) { h->ws_ksplit = value < 0 ? 0 : (value > 8 ? 8 : value); return 0; }   // > 1 = force (tests)
@@ -1263,13 +1298,32 @@ static bool gen_block_fast(const rdgan_handle* h, int l, int enabled) {
   return h->collapse && enabled && h->gdim[l - 1][0] >= 6;
 }
 
+// `ws`: stream of the weight-only kernels (the handle's side stream, forked by the caller, or `st` itself): the weight forms of
+// block l are complete behind event ev_g[l], which `st` waits for in front of the block's GEMM
 static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, const float* cond, float* out, int B,
-                            hipStream_t st) {
+                            hipStream_t st, hipStream_t ws) {
   const int nd = h->nd;
   const bool a16 = h->a16 != 0;
   RD_TRY(a16_check(h));
+  // ---- weight forms (read only the weights)
   // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
-  RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, st));
+  RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, ws));
+  for (int l = 1; l <= 3; ++l) {
+    const float* Wl = gp + h->goff[2 * l];
+    const long cc = (long)h->gch[l - 1] * h->gch[l];
+    if (gen_block_fast(h, l, fast_fwd_on(h))) {
+      RdWeightMap wm;
+      fastd_weight_map(wm);
+      ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, ws);
+      hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, ws, Wl, h->fU[l], (int)cc, 48, wm);
+      if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->fU[l], h->bU[l], 48, h->gch[l - 1], h->gch[l], ws));
+    } else if (h->collapse) {
+      hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * cc)), dim3(256), 0, ws, Wl, h->GWC[l], (int)cc);
+      if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
+    }
+    if (ws != st) RD_CHECK(h, hipEventRecord(h->ev_g[l], ws));
+  }
+  // ---- activations
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_concat, dim3(ew_blocks((long)B * h->n_in)), dim3(256), 0, st, z, cond, h->xcat, B,
@@ -1287,20 +1341,16 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     // UpSampling3D + Conv3D + bias (T:330-331), then PixelNorm + LeakyReLU (T:332-333)
     const float* Wl = gp + h->goff[2 * l];
     int pl = PL_G1F + l - 1;
+    if (ws != st) RD_CHECK(h, hipStreamWaitEvent(st, h->ev_g[l], 0));       // this block's weight forms
     if (gen_block_fast(h, l, fast_fwd_on(h))) {
       // shared-centre form along the hour axis: T = S x[s] once per output plane pair, then the difference part
       const int* sd = h->gdim[l - 1];
       const long P = (long)sd[1] * sd[2] * h->gch[l - 1];
-      const long cc = (long)h->gch[l - 1] * h->gch[l];
-      RdWeightMap wm;
-      fastd_weight_map(wm);
       {
         ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
         const dim3 dg(ew_blocks((long)B * (sd[0] + 1) * P / 4));
         if (a16) hipLaunchKernelGGL(k_diff_d<rd_bf16_t>, dg, dim3(256), 0, st, (const rd_bf16_t*)hs[l - 1], (rd_bf16_t*)h->fE[l], B, sd[0], P);
         else hipLaunchKernelGGL(k_diff_d<float>, dg, dim3(256), 0, st, (const float*)hs[l - 1], h->fE[l], B, sd[0], P);
-        hipLaunchKernelGGL(k_weight_transform, dim3(ew_blocks(48L * cc / 4)), dim3(256), 0, st, Wl, h->fU[l], (int)cc, 48, wm);
-        if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->fU[l], h->bU[l], 48, h->gch[l - 1], h->gch[l], st));
       }
       const int pls = PL_F1WS + l - 1, ple = PL_F1FE + l - 1;
       RdEpi et = epi_make(RD_EPI_PLAIN);
@@ -1327,8 +1377,6 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       continue;
     }
     if (h->collapse) {
-      hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * h->gch[l - 1] * h->gch[l])), dim3(256), 0, st, Wl,
-                         h->GWC[l], h->gch[l - 1] * h->gch[l]);
       Wl = h->GWC[l];
       pl = PL_G1FC + l - 1;
     }
@@ -1337,9 +1385,8 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     ep.rinv = rs[l];
     ep.out16 = a16;
     ep.nametag = a16 && l == 3;
-    if (a16) {     // collapsed form (64 taps) on the bf16 matrix pipe; the bf16 weight image is rebuilt per block
-      RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F, 64, h->gch[l - 1], h->gch[l], st));
-      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], h->bG1F, hs[l], ep, st,
+    if (a16) {     // collapsed form (64 taps) on the bf16 matrix pipe
+      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], h->bG1F[l], hs[l], ep, st,
                            l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
     } else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], Wl, h->gch[l], hs[l], ep, st,
@@ -1397,7 +1444,7 @@ extern "C" int rdgan_gen_forward(rdgan_handle* h, const float* gen_params, const
   if (!h || !gen_params || !z || !cond || !out) return bad_arg(h, "gen_forward: null pointer");
   if (B < 1 || B > h->MB) return bad_arg(h, "gen_forward: B outside [1, max_batch]");
   RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), (hipStream_t)stream));
-  return gen_forward_impl(h, gen_params, z, cond, out, B, (hipStream_t)stream);
+  return gen_forward_impl(h, gen_params, z, cond, out, B, (hipStream_t)stream, side_fork(h, (hipStream_t)stream));
 }
 
 // tf.debugging.check_numerics behind the generator's softmax (T:349-350): the softmax kernels raise a device flag on
@@ -1581,9 +1628,13 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
   // fake = G(z, cond), generator frozen (T:363,370): reads no critic weight, so it is issued in front of the wait for
   // them -- the previous critic update's all-reduce + Adam (on the caller's other stream) hide behind it
-  RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st));
-  if (critic_ready_event) RD_CHECK(h, hipStreamWaitEvent(st, (hipEvent_t)critic_ready_event, 0));
-  RD_TRY(prep_critic_weights(h, dp, st));
+  // The weight-only kernels (generator weight forms, then the critic's transposes / bf16 images behind the "critic ready"
+  // event) go to the side stream beside the generator forward; the compute stream waits for them where it needs them.
+  hipStream_t ws = side_fork(h, st);
+  RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st, ws));
+  if (critic_ready_event) RD_CHECK(h, hipStreamWaitEvent(ws, (hipEvent_t)critic_ready_event, 0));
+  RD_TRY(prep_critic_weights(h, dp, ws));
+  RD_TRY(side_join(h, st, h->ev_cw));
   // [real; fake; alpha*real + (1-alpha)*fake] with the condition as 2nd channel (T:275-282, T:376)
   const bool a16 = h->a16 != 0;
   {
@@ -1594,6 +1645,14 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   }
   RD_TRY(critic_forward_impl(h, dp, NBt, seed, st));           // T:372,373,379 as one batch
   RD_TRY(critic_dgrad_chain(h, dp, NBt, B, 0, seed, st));       // dL/dh for real|fake, dD/dh for x_hat
+  // bias gradients: only the real|fake passes reach the loss through the bias (the penalty term does not).  Column sums of
+  // the output gradients the chain has just left: on the side stream, beside the penalty's second sweep and the weight-gradient
+  // GEMMs below (nothing below writes du[l]; the column-sum scratch is used by these launches only)
+  {
+    hipStream_t cs = side_fork(h, st);
+    for (int l = 1; l <= 4; ++l)
+      RD_TRY(launch_colsum(h, h->du[l], (long)2 * B * h->dL[l], h->dch[l], grad + h->doff[2 * (l - 1) + 1], cs, h->a16 != 0));
+  }
   // gradient penalty (T:238-241, T:382): g0 = dD/dx_hat, n = ||g0||, r0 = d(10 mean((n-1)^2))/dg0
   RD_TRY(critic_input_grad(h, act_off(h, h->du[1], (long)2 * B * h->dL[1] * 64), B, st));
   float* cin_hat = h->cin + (long)2 * B * h->dL[0] * h->CP;
@@ -1638,9 +1697,8 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
     RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], padded ? h->dW1P : grad + h->doff[2 * (l - 1)],
                         h->wpartial, h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM, a16));
     if (padded) hipLaunchKernelGGL(k_unpad_w1, dim3(27), dim3(256), 0, st, h->dW1P, grad + h->doff[0], h->Cin, h->CP);
-    // bias gradient: only the real|fake passes reach the loss through the bias (the penalty term does not)
-    RD_TRY(launch_colsum(h, h->du[l], (long)2 * B * h->dL[l], h->dch[l], grad + h->doff[2 * (l - 1) + 1], st, a16));
   }
+  RD_TRY(side_join(h, st, h->ev_join));                 // the bias-gradient sums issued on the side stream above
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     if (a16) hipLaunchKernelGGL(k_critic_dense_wgrad<rd_bf16_t>, dim3((h->F + 15) / 16), dim3(256), 0, st, (const rd_bf16_t*)h->dh[4],
@@ -1675,9 +1733,11 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       RD_TRY(launch_transpose(h, gp + h->goff[2 * l], h->GWT[l], 27, h->gch[l - 1], h->gch[l], h->gch[l - 1], st));
   // the generator forward reads no critic weight: the last critic update (all-reduce + Adam on the caller's other
   // stream) hides behind it; everything below the wait reads them
-  RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st));
-  if (critic_ready_event) RD_CHECK(h, hipStreamWaitEvent(st, (hipEvent_t)critic_ready_event, 0));
-  RD_TRY(prep_critic_weights(h, dp, st));
+  hipStream_t ws = side_fork(h, st);                    // weight-only kernels beside the generator forward (see rdgan_critic_grad_after)
+  RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st, ws));
+  if (critic_ready_event) RD_CHECK(h, hipStreamWaitEvent(ws, (hipEvent_t)critic_ready_event, 0));
+  RD_TRY(prep_critic_weights(h, dp, ws));
+  RD_TRY(side_join(h, st, h->ev_cw));
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, (const float*)nullptr,
@@ -1723,8 +1783,11 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
     RD_TRY(launch_conv(h, h->plans[PL_G9B], h->d_plans + PL_G9B, B, h->P9, gp + h->goff[8], 64, h->gh3,
                        epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
   }
-  RD_TRY(launch_colsum(h, h->dl, npix3 / 64, 64, h->ga0, st));   // 64 partial sums of dl (npix3 % 64 == 0)
-  RD_TRY(launch_colsum(h, h->ga0, 64, 1, grad + h->goff[9], st));
+  {   // bias gradient of the last conv = sum of dl: on the side stream (dl is not written again in this call)
+    hipStream_t cs = side_fork(h, st);
+    RD_TRY(launch_colsum(h, h->dl, npix3 / 64, 64, h->g9b_tmp, cs));   // 64 partial sums of dl (npix3 % 64 == 0)
+    RD_TRY(launch_colsum(h, h->g9b_tmp, 64, 1, grad + h->goff[9], cs));
+  }
   // three [upsample, conv, pixelnorm, lrelu] blocks, last to first
   float* hs[4] = {h->h0, h->h1, h->h2, h->h3};
   float* rs[4] = {nullptr, h->r1, h->r2, h->r3};
@@ -1802,7 +1865,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       }
       hipLaunchKernelGGL(k_weight_transform_adj, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->fdU, grad + h->goff[2 * l],
                          (int)cc, 48, wm);
-      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st, a16));
+      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], side_fork(h, st), a16));   // bias gradient, beside the GEMMs (dys[l] is read-only from here on)
       const int pbs = PL_F1BS + l - 1, pbe = PL_F1BE + l - 1;
       RdEpi eb = epi_make(RD_EPI_PLAIN);
       eb.out16 = a16;
@@ -1846,7 +1909,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
                           st, RDGAN_TAG_GCONV_WGRAD));
       hipLaunchKernelGGL(k_fold_collapsed_wgrad, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->dWc,
                          grad + h->goff[2 * l], (int)cc);
-      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st, a16));
+      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], side_fork(h, st), a16));   // bias gradient, beside the GEMMs (dys[l] is read-only from here on)
       if (a16) {      // the collapsed forms re-ordered by tap are already [N = Cin][K = Cout]
         RdSliceMap map;
         collapsed_dgrad_slice_map(map.src);
@@ -1862,7 +1925,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       int plf = PL_G1F + l - 1, plb = PL_G1B + l - 1;
       RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], grad + h->goff[2 * l], h->wpartial,
                           h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
-      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], st));
+      RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], side_fork(h, st)));
       RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWT[l], h->gch[l - 1], gups[l],
                          epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
     }
@@ -1883,7 +1946,8 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   }
   RD_TRY(launch_wgrad(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, h->ga0, grad + h->goff[0], h->wpartial,
                       h->wpartial_cap, st, RDGAN_TAG_GCONV_WGRAD));
-  RD_TRY(launch_colsum(h, h->ga0, B, h->n_nodes, grad + h->goff[1], st));
+  RD_TRY(launch_colsum(h, h->ga0, B, h->n_nodes, grad + h->goff[1], side_fork(h, st)));   // (same stream as the other column sums: they share their scratch)
+  RD_TRY(side_join(h, st, h->ev_join));                 // the bias-gradient sums issued on the side stream above
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     RD_CHECK(h, hipMemsetAsync(grad + h->n_gen, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));

@@ -329,6 +329,37 @@ def test_first_critic_layer_gemm_kernels_equal_the_tiled_path(nd, B, seed):
         eng.close()
 
 
+@pytest.mark.parametrize("nd,B,bf16", [(16, 40, 0), (16, 40, 1), (64, 1, 0), (8, 3, 1)])
+def test_side_stream_is_bit_identical(nd, B, bf16):
+    """"side_stream" (default on): the weight-only kernels and the bias-gradient column sums run on the handle's own stream
+    beside the GEMMs, ordered by events.  Same kernels on the same data, so the generator output and both gradient slabs --
+    repeated, so that a call also meets the previous call's side work -- equal the single-stream run bit for bit; and the
+    values are not garbage: the default run is the one every other test compares with the oracle."""
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 61)
+        x, cond, z = ot.synthetic_batch(B, nd, 62)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        if bf16:
+            eng.set_option("bf16", 1)
+        runs = []
+        for side in (1, 0):
+            eng.set_option("side_stream", side)
+            outs = []
+            for rep in range(3):
+                outs.append(eng.gen_forward(gs, dev(z), dev(cond)).clone())
+                outs.append(eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 100 + rep).clone())
+                outs.append(eng.gen_grad(ds, gs, dev(z), dev(cond), 200 + rep).clone())
+            torch.cuda.synchronize()
+            runs.append(outs)
+        for a, b in zip(*runs):
+            assert torch.equal(a, b)
+        assert all(bool(torch.isfinite(a).all()) for a in runs[0])
+        assert float(runs[0][1][:eng.n_critic].abs().max()) > 0 and float(runs[0][2][:eng.n_gen].abs().max()) > 0
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [9, 33])
 def test_odd_batches_default_options(B):
     """Batches that leave partial tiles everywhere (rows % 128 != 0, tiles spanning several samples), default options:
