@@ -128,7 +128,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "resident" (default 1; bf16 storage mode): the forward GEMMs of the shared-centre form whose tile holds whole source
  * planes keep the tile's source rows resident in LDS and stream only the weights (each source row is fetched once per
  * channel chunk instead of once per tap and chunk); same arithmetic in the same order, bit-identical to 0.
- * "edge_kernels" (default 1): the first critic layer (2 -> 64 channels, K = 54; one condition channel) runs as one K = 64 GEMM
+ * "edge_kernels" (default 1): the weight gradient of the generator's last conv (64 -> 1) runs on the matrix pipe with the block-3
+ * output streamed once (k_g9_wgrad_mfma; ndomain a power of two, otherwise the scalar kernel); the first critic layer (2 -> 64
+ * channels, K = 54; one condition channel) runs as one K = 64 GEMM
  * per 128-row tile -- forward, the penalty's second sweep and the weight gradient (rdgan_edge.hip.h) -- instead of nine K
  * chunks of the tiled kernel; and in the bf16 storage mode the generator's last conv (64 -> 1) runs in its dedicated streaming
  * kernel (one pass over the block-3 output at HBM speed, same arithmetic and tap-sum format as "tapgather"); 2 = also with
@@ -222,6 +224,10 @@ int rdgan_op_conv3d_wgrad_bf16(const float* x, const float* gy, float* dw, int B
  * bf16 = 1: operands rounded to bf16 on the device, fp32 accumulation (Cin % 128 == 0). */
 int rdgan_op_fastd_wgrad(const float* src, const float* dy, float* dU, int B, int D, int H, int W, int Cin, int Cout,
                          int g, int bf16, void* stream);
+/* Weight gradient of the last generator conv (64 -> 1; backward of T:345) alone, through the production kernels:
+ * dW[27][64] from dl [B][24][nd][nd] and h3 [B][24][nd][nd][64].  kernel = 1: the matrix-pipe kernel (k_g9_wgrad_mfma),
+ * 0: the scalar kernel it replaced (k_g9_wgrad_pairs; nd <= 72); bf16 = 1: h3 rounded to bf16 first (storage mode). */
+int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, int B, int nd, int bf16, int kernel, void* stream);
 /* PixelNormalization + LeakyReLU(0.2) forward (T:255-266, T:333) and its backward. C in {64,128,256}. */
 int rdgan_op_pixelnorm_lrelu(const float* y, float* h, float* rinv, long npix, int C, void* stream);
 int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* rinv, float* dy,

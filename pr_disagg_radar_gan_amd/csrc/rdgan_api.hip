@@ -19,6 +19,10 @@
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
 #include "rdgan_edge.hip.h"
+// k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
+static bool g9w_mfma_ok(int nd, long npix) { return nd >= 8 && nd <= 128 && (nd & (nd - 1)) == 0 && npix < 0x7FFFFFFFL; }
+static size_t g9w_mfma_lds(bool bf16) { return std::max<size_t>((size_t)128 * (bf16 ? 128 : 256) + (1440 + 144) * sizeof(float), 32768); }
+static int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
 #define RD_GP_WEIGHT 10.0f   // the literal at T:392
 
@@ -1764,14 +1768,27 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   if (g9_direct) {
     ProfScope ps(h, RDGAN_TAG_GCONV_WGRAD, st);
     const size_t lds = std::max<size_t>(g9_lds, 4 * 27 * 16 * sizeof(f32x4));
-    RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_wgrad_pairs<rd_bf16_t> : (const void*)k_g9_wgrad_pairs<float>, 96 * 1024));
     RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_bwd_pairs<rd_bf16_t> : (const void*)k_g9_bwd_pairs<float>, 96 * 1024));
-    const int nunits = B * (RDGAN_NHOURS / 2);
-    const int nwg = std::min(nunits, 3072);            // (bs 256: one unit per workgroup, as before)
-    if (a16) hipLaunchKernelGGL(k_g9_wgrad_pairs<rd_bf16_t>, dim3(nwg), dim3(256), lds, st, h->dl, (const rd_bf16_t*)h->h3, h->wpartial,
-                                RDGAN_NHOURS, nd, nd, nunits);
-    else hipLaunchKernelGGL(k_g9_wgrad_pairs<float>, dim3(nwg), dim3(256), lds, st, h->dl, (const float*)h->h3, h->wpartial,
-                            RDGAN_NHOURS, nd, nd, nunits);
+    int nwg;
+    if (h->edge_kernels && g9w_mfma_ok(nd, npix3)) {
+      // weight gradient on the matrix pipe, the h3 tensor streamed once (rdgan_edge.hip.h)
+      const size_t lds_m = g9w_mfma_lds(a16);
+      RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_wgrad_mfma<rd_bf16_t> : (const void*)k_g9_wgrad_mfma<float>, lds_m));
+      nwg = (int)std::min<long>((npix3 + 127) / 128, 768);          // persistent: three workgroups per CU
+      h->flops_acc += 2.0 * npix3 * 64 * 27;
+      if (a16) hipLaunchKernelGGL(k_g9_wgrad_mfma<rd_bf16_t>, dim3(nwg), dim3(256), lds_m, st, h->dl, (const rd_bf16_t*)h->h3, h->wpartial,
+                                  npix3, RDGAN_NHOURS, nd, nd, ilog2(nd));
+      else hipLaunchKernelGGL(k_g9_wgrad_mfma<float>, dim3(nwg), dim3(256), lds_m, st, h->dl, (const float*)h->h3, h->wpartial,
+                              npix3, RDGAN_NHOURS, nd, nd, ilog2(nd));
+    } else {
+      RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_wgrad_pairs<rd_bf16_t> : (const void*)k_g9_wgrad_pairs<float>, 96 * 1024));
+      const int nunits = B * (RDGAN_NHOURS / 2);
+      nwg = std::min(nunits, 3072);            // (bs 256: one unit per workgroup, as before)
+      if (a16) hipLaunchKernelGGL(k_g9_wgrad_pairs<rd_bf16_t>, dim3(nwg), dim3(256), lds, st, h->dl, (const rd_bf16_t*)h->h3, h->wpartial,
+                                  RDGAN_NHOURS, nd, nd, nunits);
+      else hipLaunchKernelGGL(k_g9_wgrad_pairs<float>, dim3(nwg), dim3(256), lds, st, h->dl, (const float*)h->h3, h->wpartial,
+                              RDGAN_NHOURS, nd, nd, nunits);
+    }
     hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(256), 0, st, h->wpartial, nwg, 1728, grad + h->goff[8]);
   } else {
     {
@@ -2158,6 +2175,51 @@ extern "C" int rdgan_op_fastd_wgrad(const float* src, const float* dy, float* dU
   if (partial) (void)hipFree(partial);
   if (xb) (void)hipFree(xb);
   if (gb) (void)hipFree(gb);
+  return rc;
+}
+
+// Weight gradient of the last generator conv (64 -> 1) alone, through the production kernels: kernel = 1 the matrix-pipe kernel
+// (k_g9_wgrad_mfma), 0 the scalar kernel (k_g9_wgrad_pairs); bf16 = 1 rounds h3 to bf16 first (storage mode)
+extern "C" int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, int B, int nd, int bf16, int kernel, void* stream) {
+  if (!dl || !h3 || !dW || B < 1 || nd < 1) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = RDGAN_NHOURS;
+  const long npix = (long)B * D * nd * nd;
+  if (npix >= 0x7FFFFFFFL) return -2;
+  const int nunits = B * (D / 2);
+  if (kernel && !g9w_mfma_ok(nd, npix)) return -2;
+  const int nwg = kernel ? (int)std::min<long>((npix + 127) / 128, 768) : std::min(nunits, 3072);
+  float* partial = nullptr;
+  void* hb = nullptr;
+  int rc = (int)hipMalloc((void**)&partial, (size_t)nwg * 1728 * sizeof(float));
+  if (rc == 0 && bf16) {
+    rc = (int)hipMalloc(&hb, npix * 64 * 2);
+    if (rc == 0) rc = launch_to_bf16(nullptr, h3, hb, npix * 64, st);
+  }
+  if (rc == 0 && kernel) {
+    const size_t lds = g9w_mfma_lds(bf16 != 0);
+    rc = ensure_lds(nullptr, bf16 ? (const void*)k_g9_wgrad_mfma<rd_bf16_t> : (const void*)k_g9_wgrad_mfma<float>, lds);
+    if (rc == 0) {
+      if (bf16) hipLaunchKernelGGL(k_g9_wgrad_mfma<rd_bf16_t>, dim3(nwg), dim3(256), lds, st, dl, (const rd_bf16_t*)hb, partial, npix, D, nd, nd, ilog2(nd));
+      else hipLaunchKernelGGL(k_g9_wgrad_mfma<float>, dim3(nwg), dim3(256), lds, st, dl, h3, partial, npix, D, nd, nd, ilog2(nd));
+    }
+  } else if (rc == 0) {
+    const size_t g9_lds = 4 * (size_t)(nd + 2) * (nd + 2) * sizeof(float);
+    const size_t lds = std::max<size_t>(g9_lds, 4 * 27 * 16 * sizeof(f32x4));
+    if (lds > 96 * 1024) rc = -2;
+    if (rc == 0) rc = ensure_lds(nullptr, bf16 ? (const void*)k_g9_wgrad_pairs<rd_bf16_t> : (const void*)k_g9_wgrad_pairs<float>, 96 * 1024);
+    if (rc == 0) {
+      if (bf16) hipLaunchKernelGGL(k_g9_wgrad_pairs<rd_bf16_t>, dim3(nwg), dim3(256), lds, st, dl, (const rd_bf16_t*)hb, partial, D, nd, nd, nunits);
+      else hipLaunchKernelGGL(k_g9_wgrad_pairs<float>, dim3(nwg), dim3(256), lds, st, dl, h3, partial, D, nd, nd, nunits);
+    }
+  }
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(256), 0, st, partial, nwg, 1728, dW);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  if (partial) (void)hipFree(partial);
+  if (hb) (void)hipFree(hb);
   return rc;
 }
 

@@ -141,6 +141,138 @@ k_g9_fwd(const T* __restrict__ h3, const float* __restrict__ w9 /* [27][64] */, 
 }
 
 // ------------------------------------------------------------------------------------
+// Last generator conv, weight gradient (T:345 backward): dW9[tap][c] = sum_u dl[u - off(tap)] * h3[u][c] as a GEMM on the matrix
+// pipe, C[32 taps][64 c] += A^T[32][128 pixels] x B[128][64] per 128-pixel tile (W a power of two <= 128: the tile is R = 128 / W
+// whole w rows).  B = the h3 rows of the tile, in by LDS-DMA: the 403 MB tensor is read once.  A is never materialised: for each
+// (kd, kh) and tile row the dlogits row at (d + 1 - kd, h + 1 - kh) is staged in LDS with a zero halo in w (9 R rows of W + 2
+// floats, border rows zero; dl is 1 channel, 6 MB, L2-resident), and a lane reads A[tap][pixel] = stage[(kd, kh)][row][w + 2 - kw]
+// at (lane-constant tap offset) + (pixel offset).  Persistent workgroups (four per CU), each wave multiplies 32 of the tile's
+// pixels and keeps its [32][64] sums in registers; per workgroup one partial [27][64] slab, folded by k_reduce_partials
+// (deterministic).  fp32 MFMAs (v_mfma_f32_32x32x2_f32) also in the bf16 storage mode -- the bf16 rows are widened on the
+// fragment read -- so the products are exactly those of the scalar kernel it replaces (k_g9_wgrad_pairs: one activation load
+// pair per pixel in front of 54 FMAs fed by LDS broadcasts, 2.4-2.7 TB/s).  First version of this kernel: the 27 neighbours of
+// every pixel gathered from global memory into an A^T tile -- ~700 VALU instructions per pixel and tile for the index
+// arithmetic, slower than the MFMAs and the DMA together (105 us at bs 256; 64-pixel tiles: 127 us).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256, 3)        // (four workgroups per CU would fit in LDS, but 128 VGPRs spill the fragments)
+k_g9_wgrad_mfma(const float* __restrict__ dl, const T* __restrict__ h3, float* __restrict__ partial, long rows, int D, int H, int W,
+                int wlog2) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int TP = 128;                                      // pixels per tile
+  constexpr int ROWB = BF ? 128 : 256;                        // bytes per row of 64 channels
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                                            // [TP] rows of ROWB bytes
+  float* St = smem + TP * ROWB / 4;                            // [9][R][W + 2] staged dlogits rows
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  const int R = TP >> wlog2, RS = W + 2, rlog2 = 7 - wlog2;
+  // lane-constant part of the A address: tap = l31 = (kd*3 + kh)*3 + kw -> stage row block (kd*3 + kh), column shift 2 - kw
+  const bool tapok = l31 < 27;
+  const int tkk = l31 / 3, tkw = l31 - tkk * 3;
+  const int tapoff = tapok ? tkk * R * RS + 2 - tkw : 0;
+  f32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+  const long ntiles = (rows + TP - 1) / TP;
+  // Software pipeline over the workgroup's tiles: the fragments of tile i are read into registers, then -- behind a barrier --
+  // the DMA of tile i+1 and the dlogits loads of its staged rows are issued, and only then come tile i's 32 MFMAs: the h3 rows
+  // and the dlogits of the next tile fly while the matrix pipe works (the first version waited for each tile's DMA with
+  // nothing else to do: 104 us at bs 256).
+  auto issue_b = [&](unsigned m0) {       // B: 32 rows per wave by DMA (rows beyond the tensor -> zeros)
+    const __amdgpu_buffer_rsrc_t rs = rd_make_rsrc((const float*)(h3 + (long)m0 * 64));
+    constexpr int RPI = 1024 / ROWB, CPR = ROWB / 16;
+#pragma unroll
+    for (int k = 0; k < 32 / RPI; ++k) {
+      const int r = wave * 32 + k * RPI + lane / CPR;
+      unsigned voff = m0 + r < (unsigned)rows ? (unsigned)(r * ROWB + (lane % CPR) * 16) : RD_OOB;
+      asm volatile("" : "+v"(voff));
+      rd_lds_dma16(rs, Bs + (wave * 32 + k * RPI) * (ROWB / 4), (int)voff, 0);
+    }
+  };
+  // staged rows: pass q = (kd, kh) stages R rows of W + 2 floats, thread -> (tile row r = tid / 2W, column wc = tid % 2W);
+  // row (q, r) is dl[b, d+1-kd, h+1-kh, :] of the tile row's (b, d, h), zero outside the picture
+  const int sr = tid >> (wlog2 + 1), swc = tid & (2 * W - 1);
+  float sv[9];
+  unsigned sok = 0;                       // bit q: row (q, r) exists (the select waits until store_stage: the loads stay in flight)
+  auto load_stage = [&](unsigned m0) {
+    sok = 0;
+    const unsigned rowid = (m0 >> wlog2) + (unsigned)sr;
+    const unsigned t = rowid / (unsigned)H;
+    const int h_ = (int)(rowid - t * (unsigned)H);
+    const unsigned b = t / (unsigned)D;
+    const int d_ = (int)(t - b * (unsigned)D);
+    const bool live = (long)rowid * W < rows && swc >= 1 && swc <= W;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int dd = d_ + 1 - q / 3, hh = h_ + 1 - q % 3;
+      const bool ok = live && (unsigned)dd < (unsigned)D && (unsigned)hh < (unsigned)H;
+      const unsigned idx = ok ? ((b * (unsigned)D + (unsigned)dd) * (unsigned)H + (unsigned)hh) * (unsigned)W + (unsigned)(swc - 1) : 0u;
+      sv[q] = dl[idx];
+      sok |= ok ? 1u << q : 0u;
+    }
+  };
+  auto store_stage = [&]() {
+    if (swc < RS) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) St[(q * R + sr) * RS + swc] = (sok >> q & 1u) ? sv[q] : 0.f;
+    }
+  };
+  long tile = blockIdx.x;
+  if (tile < ntiles) {
+    issue_b((unsigned)(tile * TP));
+    load_stage((unsigned)(tile * TP));
+    store_stage();
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                           // (vmcnt(0) in front of it) tile: h3 rows landed, rows staged
+    // this wave's 32 pixels: k-step s multiplies pixels base + s (lanes 0-31) and base + 16 + s (lanes 32-63)
+    const int base = wave * 32 + 16 * lhalf;
+    float a[16], b0[16], b1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int p = base + s;
+      const float av = St[tapoff + (p >> wlog2) * RS + (p & (W - 1))];
+      a[s] = tapok ? av : 0.f;
+      if constexpr (BF) {
+        const unsigned short* Bh = (const unsigned short*)Bs;
+        b0[s] = __builtin_bit_cast(float, (unsigned)Bh[p * 64 + l31] << 16);
+        b1[s] = __builtin_bit_cast(float, (unsigned)Bh[p * 64 + 32 + l31] << 16);
+      } else {
+        b0[s] = Bs[p * 64 + l31];
+        b1[s] = Bs[p * 64 + 32 + l31];
+      }
+    }
+    __syncthreads();                                           // every wave holds its fragments: the tile's LDS is free
+    const long next = tile + gridDim.x;
+    if (next < ntiles) {            // dlogits loads first: loads return in order, and store_stage must not wait for the DMA behind them
+      load_stage((unsigned)(next * TP));
+      issue_b((unsigned)(next * TP));
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1[s], acc[1], 0, 0, 0);
+    }
+    if (next < ntiles) store_stage();
+  }
+  __syncthreads();
+  // fold the four waves through LDS: red[wave][tap][c]; accumulator register r of a lane = row (r&3) + 8 (r>>2) + 4 lhalf
+  float* red = smem;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tap = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+      red[(wave * 32 + tap) * 64 + j * 32 + l31] = acc[j][r];
+    }
+  __syncthreads();
+  for (int i = tid; i < 27 * 64; i += 256)
+    partial[(long)blockIdx.x * 1728 + i] = red[i] + red[32 * 64 + i] + red[2 * 32 * 64 + i] + red[3 * 32 * 64 + i];
+}
+
+// ------------------------------------------------------------------------------------
 // First critic layer (T:286-289): Conv3D(64, 3x3x3, stride 2, 'valid') on the 2-channel volume (sample | condition),
 // as ONE K = 64 GEMM per tile: an output position's im2col row is 9 (kd,kh) segments of 6 contiguous floats (kw, ci) =
 // 54 values, padded to 64.  The tiled conv kernel walks the 9 segments as 9 K chunks of 8 (6 used) with a barrier each;

@@ -215,3 +215,34 @@ def test_shared_centre_wgrad_256_row_tile(g, bf16):
     assert rc == 0
     got = dU[g * 16:(g + 1) * 16].cpu().numpy()
     assert rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("nd,B,bf16", [(16, 3, 0), (16, 3, 1), (8, 5, 0), (8, 3, 1), (24, 1, 0), (32, 1, 0), (64, 1, 1), (128, 1, 0), (16, 40, 0)])
+def test_last_conv_weight_gradient_kernels(nd, B, bf16, kernel):
+    """Backward of the 64 -> 1 conv (T:345) w.r.t. its kernel, through the production kernels alone: the matrix-pipe kernel
+    k_g9_wgrad_mfma (kernel = 1: 128-pixel tiles of whole w rows -- 16, 8, 2 rows at ndomain 8, 16, 64; tiles that straddle
+    hour planes and samples at ndomain 8; persistent workgroups that walk several tiles at B = 40) and the scalar kernel it replaced (0), against the definition
+        dW[kd,kh,kw,c] = sum_{b,d,h,w} dl[b, d+1-kd, h+1-kh, w+1-kw] * h3[b, d, h, w, c]
+    evaluated in float64 (on the bf16-rounded h3 for the storage mode): 1e-5."""
+    rng = np.random.default_rng(70 + nd + B)
+    D = 24
+    dl = rng.standard_normal((B, D, nd, nd)).astype(np.float32)
+    h3 = rng.standard_normal((B, D, nd, nd, 64)).astype(np.float32)
+    h64 = (_bf16_round(h3) if bf16 else h3).astype(np.float64)
+    dlp = np.zeros((B, D + 2, nd + 2, nd + 2))
+    dlp[:, 1:-1, 1:-1, 1:-1] = dl
+    ref = np.zeros((3, 3, 3, 64))
+    for kd in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                sh = dlp[:, 2 - kd:2 - kd + D, 2 - kh:2 - kh + nd, 2 - kw:2 - kw + nd]       # dl[d+1-kd, ...] with the +1 halo
+                ref[kd, kh, kw] = np.tensordot(sh.reshape(-1), h64.reshape(-1, 64), axes=(0, 0))
+    d_dl, d_h3 = dev(dl), dev(h3)
+    dW = torch.full((27 * 64,), float("nan"), device="cuda")
+    rc = lib().rdgan_op_g9_wgrad(ptr(d_dl), ptr(d_h3), ptr(dW), B, nd, bf16, kernel, stream())
+    if (kernel == 1 and nd & (nd - 1)) or (kernel == 0 and nd > 72):
+        assert rc == -2          # the matrix-pipe kernel takes power-of-two widths (the engine falls back to the scalar kernel,
+        return                   # whose four dlogits planes must fit in LDS: ndomain <= 72)
+    assert rc == 0
+    assert rel_err(dW.cpu().numpy().reshape(3, 3, 3, 64), ref) < 1e-5
