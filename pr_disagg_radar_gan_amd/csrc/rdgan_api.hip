@@ -19,6 +19,7 @@
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
 #include "rdgan_edge.hip.h"
+static_assert(RDGAN_LOSS_SLOTS == 8, "k_critic_losses / k_gen_loss write slots 0..7");
 // k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
 static bool g9w_mfma_ok(int nd, long npix) { return nd >= 8 && nd <= 128 && (nd & (nd - 1)) == 0 && npix < 0x7FFFFFFFL; }
 static size_t g9w_mfma_lds(bool bf16) { return std::max<size_t>((size_t)128 * (bf16 ? 128 : 256) + (1440 + 144) * sizeof(float), 32768); }
@@ -1331,7 +1332,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL(k_concat, dim3(ew_blocks((long)B * h->n_in)), dim3(256), 0, st, z, cond, h->xcat, B,
-                       RDGAN_LATENT_DIM, nd * nd * h->nc);
+                       RDGAN_LATENT_DIM, nd * nd * h->nc, h->d_flag);       // (first kernel of every entry: clears the non-finite flag)
   }
   // Dense + LeakyReLU (T:326-327); the Reshape (T:328) is a view
   if (a16) RD_TRY(launch_conv_a16(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, gp + h->goff[0], h->n_nodes, h->h0,
@@ -1419,8 +1420,10 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
                                 nd * nd, gq);
     else hipLaunchKernelGGL(k_g9_fwd<float>, g9, dim3(256), 72 * 1024, st, (const float*)h->h3, gp + h->goff[8], h->P9, rows9, nd,
                             nd * nd, gq);
-    hipLaunchKernelGGL(k_tapsum_softmax<RDGAN_NHOURS>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->P9,
-                       gp + h->goff[9], out, B, nd, nd, gq, h->d_flag);
+    if (gq == 3) hipLaunchKernelGGL((k_tapsum_softmax<RDGAN_NHOURS, 3>), dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, st, h->P9,
+                                    gp + h->goff[9], out, B, nd, nd, h->d_flag);
+    else hipLaunchKernelGGL((k_tapsum_softmax<RDGAN_NHOURS, 9>), dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, st, h->P9,
+                            gp + h->goff[9], out, B, nd, nd, h->d_flag);
   } else if (gq && h->tapgather) {
     RdEpi e = epi_make(RD_EPI_TAPGATHER);
     e.gw = nd; e.ghw = nd * nd; e.gq = gq;
@@ -1428,8 +1431,10 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     else
     RD_TRY(launch_conv(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, e, st, -1));
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_tapsum_softmax<RDGAN_NHOURS>, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, st, h->P9,
-                       gp + h->goff[9], out, B, nd, nd, gq, h->d_flag);
+    if (gq == 3) hipLaunchKernelGGL((k_tapsum_softmax<RDGAN_NHOURS, 3>), dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, st, h->P9,
+                                    gp + h->goff[9], out, B, nd, nd, h->d_flag);
+    else hipLaunchKernelGGL((k_tapsum_softmax<RDGAN_NHOURS, 9>), dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, st, h->P9,
+                            gp + h->goff[9], out, B, nd, nd, h->d_flag);
   } else {
     if (a16) RD_TRY(launch_conv_a16(h, h->plans[PL_G9F], h->d_plans + PL_G9F, B, h->h3, h->W9T, 32, h->P9, epi_make(RD_EPI_PLAIN), st, -1,
                                     true, false));
@@ -1447,7 +1452,6 @@ extern "C" int rdgan_gen_forward(rdgan_handle* h, const float* gen_params, const
                                  float* out, int B, void* stream) {
   if (!h || !gen_params || !z || !cond || !out) return bad_arg(h, "gen_forward: null pointer");
   if (B < 1 || B > h->MB) return bad_arg(h, "gen_forward: B outside [1, max_batch]");
-  RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), (hipStream_t)stream));
   return gen_forward_impl(h, gen_params, z, cond, out, B, (hipStream_t)stream, side_fork(h, (hipStream_t)stream));
 }
 
@@ -1629,7 +1633,6 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   hipStream_t st = (hipStream_t)stream;
   const int NBt = 3 * B;
   const int use_drop = seed != 0;
-  RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
   // fake = G(z, cond), generator frozen (T:363,370): reads no critic weight, so it is issued in front of the wait for
   // them -- the previous critic update's all-reduce + Adam (on the caller's other stream) hide behind it
   // The weight-only kernels (generator weight forms, then the critic's transposes / bf16 images behind the "critic ready"
@@ -1709,9 +1712,9 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
                                 grad + h->doff[8], NBt, h->F, B);
     else hipLaunchKernelGGL(k_critic_dense_wgrad<float>, dim3((h->F + 15) / 16), dim3(256), 0, st, (const float*)h->dh[4],
                             grad + h->doff[8], NBt, h->F, B);
-    RD_CHECK(h, hipMemsetAsync(grad + h->doff[9], 0, sizeof(float), st));   // sum of dv over real|fake = 0
-    RD_CHECK(h, hipMemsetAsync(grad + h->n_critic, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));
-    hipLaunchKernelGGL(k_critic_losses, dim3(1), dim3(256), 0, st, h->v, h->gpv, grad + h->n_critic, B, RD_GP_WEIGHT, h->d_flag);
+    // (grad[doff[9]] = sum of dv over real|fake = 0, cleared by the loss kernel together with the unused loss slots)
+    hipLaunchKernelGGL(k_critic_losses, dim3(1), dim3(256), 0, st, h->v, h->gpv, grad + h->n_critic, B, RD_GP_WEIGHT, h->d_flag,
+                       grad + h->doff[9]);
   }
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -1731,7 +1734,6 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   if (B < 1 || B > h->MB) return bad_arg(h, "gen_grad: B outside [1, max_batch]");
   hipStream_t st = (hipStream_t)stream;
   const int nd = h->nd;
-  RD_CHECK(h, hipMemsetAsync(h->d_flag, 0, sizeof(int), st));
   if (!h->collapse)
     for (int l = 1; l <= 3; ++l)
       RD_TRY(launch_transpose(h, gp + h->goff[2 * l], h->GWT[l], 27, h->gch[l - 1], h->gch[l], h->gch[l - 1], st));
@@ -1967,7 +1969,6 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   RD_TRY(side_join(h, st, h->ev_join));                 // the bias-gradient sums issued on the side stream above
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    RD_CHECK(h, hipMemsetAsync(grad + h->n_gen, 0, sizeof(float) * RDGAN_LOSS_SLOTS, st));
     hipLaunchKernelGGL(k_gen_loss, dim3(1), dim3(256), 0, st, h->v, grad + h->n_gen, B, h->d_flag);
   }
   RD_CHECK(h, hipGetLastError());

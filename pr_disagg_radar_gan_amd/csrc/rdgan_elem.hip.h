@@ -31,8 +31,10 @@ __device__ __forceinline__ float rd_block_sum(float v, float* red) {
 }
 
 // G0 (T:322-323): out[b] = [z[b] (nz) | cond[b].flatten (nc)]
+// (also clears the non-finite flag of the call it opens: a 4-byte hipMemsetAsync is a launch of its own, ~9 us)
 __global__ void k_concat(const float* __restrict__ z, const float* __restrict__ cond, float* __restrict__ out,
-                         int B, int nz, int nc) {
+                         int B, int nz, int nc, int* __restrict__ zero_flag) {
+  if (zero_flag && blockIdx.x == 0 && threadIdx.x == 0) *zero_flag = 0;
   const int w = nz + nc;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)B * w; i += (long)gridDim.x * blockDim.x) {
     int b = (int)(i / w), j = (int)(i - (long)b * w);
@@ -327,51 +329,65 @@ __global__ void k_colgather_softmax(const float* __restrict__ P, const float* __
 
 // G9+G10+G11 after the tap-gathering column GEMM (RD_EPI_TAPGATHER): Q[b][d][NQ][h][w] holds, per grid point, the sums
 // over (kh,kw) for each kd (NQ = 3) or over kw for each (kd,kh) (NQ = 9).  logits = bias + the remaining sum over
-// kd (and kh), then softmax over the 24 hours.  One thread per (sample, h, w) column, logits kept in registers.
-template <int D>
-__global__ void k_tapsum_softmax(const float* __restrict__ Q, const float* __restrict__ bias, float* __restrict__ out,
-                                 int B, int H, int W, int NQ, int* __restrict__ nonfinite) {
+// kd (and kh), then softmax over the 24 hours.  FOUR lanes per (sample, h, w) column, six hours each (lanes l, l+16, l+32,
+// l+48 of a wave share a column: 16 consecutive w per quarter wave, max and sum folded by two xor-shuffles): with one thread
+// per column the launch was 1 wave per SIMD walking 72 loads (34 us for 25 MB).
+template <int D, int NQ>
+__global__ void __launch_bounds__(256)
+k_tapsum_softmax(const float* __restrict__ Q, const float* __restrict__ bias, float* __restrict__ out,
+                 int B, int H, int W, int* __restrict__ nonfinite) {
+  static_assert(D % 4 == 0, "hours per lane");
+  constexpr int DP = D / 4;
   const long ncol = (long)B * H * W;
-  const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (gid >= ncol) return;
+  const int lane = threadIdx.x & 63, part = lane >> 4;
+  const long col = (blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (lane & 15);
+  const bool live = col < ncol;
+  const long gid = live ? col : 0;
   const int w = (int)(gid % W), h = (int)((gid / W) % H);
   const long b = gid / ((long)W * H);
   const float bv = bias[0];
   const long hw = (long)H * W;
   const float* q = Q + b * D * NQ * hw;
-  float lg[D];
+  float lg[DP];
   float mx = -3.0e38f;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
+  for (int i = 0; i < DP; ++i) {
+    const int d = part * DP + i;
     float s = bv;
 #pragma unroll
     for (int td = 0; td < 3; ++td) {
       const int sd = d + td - 1;
       if (sd < 0 || sd >= D) continue;
-      if (NQ == 3) {
+      if constexpr (NQ == 3) {
         s += q[((long)sd * 3 + td) * hw + (long)h * W + w];
       } else {
+#pragma unroll
         for (int th = 0; th < 3; ++th) {
           const int shh = h + th - 1;
           if ((unsigned)shh < (unsigned)H) s += q[((long)sd * 9 + td * 3 + th) * hw + (long)shh * W + w];
         }
       }
     }
-    lg[d] = s;
+    lg[i] = s;
     mx = fmaxf(mx, s);
   }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float den = 0.f;
 #pragma unroll
-  for (int d = 0; d < D; ++d) { lg[d] = expf(lg[d] - mx); den += lg[d]; }
+  for (int i = 0; i < DP; ++i) { lg[i] = expf(lg[i] - mx); den += lg[i]; }
+  // (fixed order of the four partial sums: (p0 + p1) + (p2 + p3) on every lane)
+  den += __shfl_xor(den, 16, 64);
+  den += __shfl_xor(den, 32, 64);
   bool bad = false;
   float* o = out + b * D * hw + (long)h * W + w;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const float p = lg[d] / den;
+  for (int i = 0; i < DP; ++i) {
+    const float p = lg[i] / den;
     bad |= !(fabsf(p) <= 3.0e38f);
-    o[d * hw] = p;
+    if (live) o[(part * DP + i) * hw] = p;
   }
-  if (bad) atomicOr(nonfinite, 1);
+  if (bad && live) atomicOr(nonfinite, 1);
 }
 
 // softmax-over-hours backward: dl = p * (g - sum_d p*g), one thread per (sample,h,w) column.
@@ -633,8 +649,10 @@ __global__ void k_gp_norm_r0(const float* __restrict__ g0, float* __restrict__ c
 // X3 (T:215-216, T:388-392): losses of the critic step as Keras reports them:
 // out[0] = total, out[1] = mean(-v_real), out[2] = mean(v_fake), out[3] = mean(gp^2); out[4] = non-finite flag
 // (the flag also carries the generator's check_numerics, T:349-350: *gflag != 0 when its softmax produced NaN/Inf)
+// (out[5..7] and *zero1 -- the gradient of the critic's last bias, which the loss does not reach -- are cleared here rather
+// than by memsets of their own)
 __global__ void k_critic_losses(const float* __restrict__ v, const float* __restrict__ gp, float* __restrict__ out,
-                                int B, float gp_weight, const int* __restrict__ gflag) {
+                                int B, float gp_weight, const int* __restrict__ gflag, float* __restrict__ zero1) {
   __shared__ float red[4];
   float a = 0.f, f = 0.f, g = 0.f;
   for (int i = threadIdx.x; i < B; i += blockDim.x) { a -= v[i]; f += v[B + i]; g += gp[i] * gp[i]; }
@@ -644,6 +662,8 @@ __global__ void k_critic_losses(const float* __restrict__ v, const float* __rest
     float tot = a + f + gp_weight * g;
     out[0] = tot; out[1] = a; out[2] = f; out[3] = g;
     out[4] = (fabsf(tot) <= 3.0e38f && *gflag == 0) ? 0.f : 1.f;
+    out[5] = 0.f; out[6] = 0.f; out[7] = 0.f;
+    if (zero1) *zero1 = 0.f;
   }
 }
 // generator step loss (T:408): out[0] = mean(-v); out[4] = non-finite flag
@@ -656,6 +676,7 @@ __global__ void k_gen_loss(const float* __restrict__ v, float* __restrict__ out,
     a /= B;
     out[0] = a; out[1] = 0.f; out[2] = 0.f; out[3] = 0.f;
     out[4] = (fabsf(a) <= 3.0e38f && *gflag == 0) ? 0.f : 1.f;
+    out[5] = 0.f; out[6] = 0.f; out[7] = 0.f;
   }
 }
 
