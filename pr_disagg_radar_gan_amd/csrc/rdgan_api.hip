@@ -396,6 +396,7 @@ struct rdgan_handle {
   int edge_kernels = 1;           // 1: dedicated streaming kernels for the generator's last conv (rdgan_edge.hip.h); 0: the tiled GEMM kernels
   int sample_offset = 0;          // global index of this rank's first sample: RandomWeightedAverage's alpha of sample k is uniform(key, sample_offset + k)
   float* g9b_tmp;                 // 64 partial sums of the last conv's bias gradient
+  float* gp_part;                 // [max_batch][64] partial sums of squares of the penalty's per-sample gradient norm
   // Side stream (option "side_stream", default on): weight-only kernels (generator weight forms, critic weight transposes /
   // bf16 images) and the bias-gradient column sums run beside the caller's stream, ordered by events: ~50 launches of 5-30 us
   // per iteration that would otherwise sit between the GEMMs.  Same kernels, same arithmetic: results are bit-identical.
@@ -1170,6 +1171,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     }
     { float* f = nullptr; carve(f, 64); if (pass == 1) h->d_flag = (int*)f; }
     carve(h->g9b_tmp, 64);
+    carve(h->gp_part, (size_t)MB * 64);
     if (pass == 0) {
       h->ws_bytes = off + 256;
       e = hipMalloc((void**)&h->ws, h->ws_bytes);
@@ -1665,7 +1667,11 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   float* cin_hat = h->cin + (long)2 * B * h->dL[0] * h->CP;
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_gp_norm_r0, dim3(B), dim3(256), 0, st, h->g0, cin_hat, h->gpv, (int)h->dL[0], B, RD_GP_WEIGHT, h->CP);
+    // S blocks per sample when there are few samples of many elements (ndomain 64)
+    const int per = (int)h->dL[0];
+    const int S = std::max(1, std::min({(1024 + B - 1) / B, per / 4096, 64}));
+    if (S > 1) hipLaunchKernelGGL(k_gp_norm_part, dim3(B * S), dim3(256), 0, st, h->g0, h->gp_part, per, S);
+    hipLaunchKernelGGL(k_gp_norm_r0, dim3(B * S), dim3(256), 0, st, h->g0, cin_hat, h->gpv, per, B, RD_GP_WEIGHT, h->CP, S, h->gp_part);
   }
   // second forward sweep of the double backward: r_l = gate_l * conv_l(r_{l-1}), in place over the x_hat third
   {

@@ -623,23 +623,41 @@ __global__ void k_d1_col2im(const float* __restrict__ P, float* __restrict__ g0,
 
 // X2 (T:238-241): per-sample n = ||g0||_2 ; gp = n - 1.  Then r0 = d(10*mean(gp^2))/dg0 =
 // (10/B) * 2 (n-1)/n * g0, written as the 2-channel (r0, 0) input of the second forward sweep into the
-// interpolated third of the critic-input buffer.  One block per sample.
+// interpolated third of the critic-input buffer.  S blocks per sample (grid B * S): with S == 1 the block folds the sample's
+// sum of squares itself; with S > 1 (few samples of many elements: ndomain 64 at 64 samples was 64 workgroups walking 98 304
+// elements each, 231 us) k_gp_norm_part has left S partial sums per sample, added here in a fixed order.
+__global__ void k_gp_norm_part(const float* __restrict__ g0, float* __restrict__ part, int per, int S) {
+  __shared__ float red[4];
+  const long b = blockIdx.x / S;
+  const int c = blockIdx.x - (int)b * S;
+  const int len = (per + S - 1) / S, i0 = c * len, i1 = min(per, i0 + len);
+  float s = 0.f;
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) { float v = g0[b * per + i]; s += v * v; }
+  s = rd_block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
 __global__ void k_gp_norm_r0(const float* __restrict__ g0, float* __restrict__ cin_hat, float* __restrict__ gp_out,
-                             int per, int B, float gp_weight, int CP) {
+                             int per, int B, float gp_weight, int CP, int S, const float* __restrict__ part) {
   __shared__ float red[4];
   __shared__ float coef_s;
-  const long b = blockIdx.x;
+  const long b = blockIdx.x / S;
+  const int c = blockIdx.x - (int)b * S;
+  const int len = (per + S - 1) / S, i0 = c * len, i1 = min(per, i0 + len);
   float s = 0.f;
-  for (int i = threadIdx.x; i < per; i += blockDim.x) { float v = g0[b * per + i]; s += v * v; }
-  s = rd_block_sum(s, red);
+  if (S == 1) {
+    for (int i = threadIdx.x; i < per; i += blockDim.x) { float v = g0[b * per + i]; s += v * v; }
+    s = rd_block_sum(s, red);
+  } else if (threadIdx.x == 0) {
+    for (int k = 0; k < S; ++k) s += part[b * S + k];
+  }
   if (threadIdx.x == 0) {
     float n = sqrtf(s);
-    gp_out[b] = n - 1.0f;
+    if (c == 0) gp_out[b] = n - 1.0f;
     coef_s = (gp_weight / B) * 2.0f * (n - 1.0f) / n;
   }
   __syncthreads();
   const float coef = coef_s;
-  for (int i = threadIdx.x; i < per; i += blockDim.x) {
+  for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
     float* o = cin_hat + (long)CP * (b * per + i);
     o[0] = coef * g0[b * per + i];
     for (int k = 1; k < CP; ++k) o[k] = 0.f;
