@@ -135,6 +135,7 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * chunks of the tiled kernel; and in the bf16 storage mode the generator's last conv (64 -> 1) runs in its dedicated streaming
  * kernel (one pass over the block-3 output at HBM speed, same arithmetic and tap-sum format as "tapgather"); 2 = also with
  * fp32 storage (bit-identical to the tiled GEMM, not faster there); 0 = the tiled GEMM kernel everywhere.
+ * "dense_wgrad_slices" (default 0 = by batch size; tests): row slices of the critic Dense weight gradient (1..16).
  * "side_stream" (default 1): inside a call the weight-only kernels (generator weight forms, critic weight transposes and
  * bf16 images) and the bias-gradient column sums are issued on a second stream owned by the handle, beside the GEMMs on the
  * caller's stream and ordered against it by events (fork at entry, joins in front of the first reader / at the end of the

@@ -397,10 +397,12 @@ struct rdgan_handle {
   int sample_offset = 0;          // global index of this rank's first sample: RandomWeightedAverage's alpha of sample k is uniform(key, sample_offset + k)
   float* g9b_tmp;                 // 64 partial sums of the last conv's bias gradient
   float* gp_part;                 // [max_batch][64] partial sums of squares of the penalty's per-sample gradient norm
+  float* dw6_part;                // [16][F] row-slice partial sums of the critic Dense weight gradient
   // Side stream (option "side_stream", default on): weight-only kernels (generator weight forms, critic weight transposes /
   // bf16 images) and the bias-gradient column sums run beside the caller's stream, ordered by events: ~50 launches of 5-30 us
   // per iteration that would otherwise sit between the GEMMs.  Same kernels, same arithmetic: results are bit-identical.
   int side_on = 1;
+  int dense_slices = 0;           // tests: force the row-slice count of the critic Dense weight gradient (0 = by batch size)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cw = nullptr, ev_g[4] = {nullptr, nullptr, nullptr, nullptr};
   int* d_flag;
@@ -1172,6 +1174,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     { float* f = nullptr; carve(f, 64); if (pass == 1) h->d_flag = (int*)f; }
     carve(h->g9b_tmp, 64);
     carve(h->gp_part, (size_t)MB * 64);
+    carve(h->dw6_part, (size_t)16 * h->F);
     if (pass == 0) {
       h->ws_bytes = off + 256;
       e = hipMalloc((void**)&h->ws, h->ws_bytes);
@@ -1229,6 +1232,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value < 0 ? -1 : (value ? 1 : 0); return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "dense_wgrad_slices")) { h->dense_slices = value; return 0; }
   if (!strcmp(name, "side_stream")) { h->side_on = (value && h->side) ? 1 : 0; return 0; }
   if (!strcmp(name, "edge_kernels")) { h->edge_kernels = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   if (!strcmp(name, "sample_offset")) { if (value < 0) return bad_arg(h, "set_option: sample_offset < 0"); h->sample_offset = value; return 0; }
@@ -1714,10 +1718,12 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   RD_TRY(side_join(h, st, h->ev_join));                 // the bias-gradient sums issued on the side stream above
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    if (a16) hipLaunchKernelGGL(k_critic_dense_wgrad<rd_bf16_t>, dim3((h->F + 15) / 16), dim3(256), 0, st, (const rd_bf16_t*)h->dh[4],
-                                grad + h->doff[8], NBt, h->F, B);
-    else hipLaunchKernelGGL(k_critic_dense_wgrad<float>, dim3((h->F + 15) / 16), dim3(256), 0, st, (const float*)h->dh[4],
-                            grad + h->doff[8], NBt, h->F, B);
+    const int RS = h->dense_slices > 0 ? std::min(16, h->dense_slices) : std::max(1, std::min(16, NBt / 384));   // row slices of the Dense weight gradient
+    float* dwo = RS > 1 ? h->dw6_part : grad + h->doff[8];
+    const dim3 dg((h->F + 15) / 16, RS);
+    if (a16) hipLaunchKernelGGL(k_critic_dense_wgrad<rd_bf16_t>, dg, dim3(256), 0, st, (const rd_bf16_t*)h->dh[4], dwo, NBt, h->F, B);
+    else hipLaunchKernelGGL(k_critic_dense_wgrad<float>, dg, dim3(256), 0, st, (const float*)h->dh[4], dwo, NBt, h->F, B);
+    if (RS > 1) hipLaunchKernelGGL(k_reduce_partials, dim3((h->F + 15) / 16), dim3(256), 0, st, h->dw6_part, RS, h->F, grad + h->doff[8]);
     // (grad[doff[9]] = sum of dv over real|fake = 0, cleared by the loss kernel together with the unused loss slots)
     hipLaunchKernelGGL(k_critic_losses, dim3(1), dim3(256), 0, st, h->v, h->gpv, grad + h->n_critic, B, RD_GP_WEIGHT, h->d_flag,
                        grad + h->doff[9]);

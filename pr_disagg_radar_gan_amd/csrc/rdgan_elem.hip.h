@@ -502,27 +502,30 @@ __global__ void k_critic_top_bwd(const T* __restrict__ h4, const float* __restri
 }
 
 // dW6[i] = sum_b buf[b][i] * dv(b) over the 3B batch whose last third holds r4;
-// block = 16 columns x 16 sample groups (F / 16 workgroups: the matrix is short and wide)
+// block = 16 columns x 16 sample groups (F / 16 workgroups: the matrix is short and wide); gridDim.y = RS row slices, slice y
+// writes out[y][F] (RS == 1: the gradient itself; RS > 1 -- thousands of samples, where one slice is a 98-us chain of
+// dependent loads -- partial sums folded by k_reduce_partials)
 template <typename T = float>
 __global__ void __launch_bounds__(256)
-k_critic_dense_wgrad(const T* __restrict__ buf, float* __restrict__ dw, int NB, int F, int B) {
+k_critic_dense_wgrad(const T* __restrict__ buf, float* __restrict__ out, int NB, int F, int B) {
   __shared__ float red[256];
   const int i = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
+  const int per = (NB + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(NB, b0 + per);
   float s0 = 0.f, s1 = 0.f;
   if (i < F) {
-    int b = g;
-    for (; b + 16 < NB; b += 32) {
+    int b = b0 + g;
+    for (; b + 16 < b1; b += 32) {
       s0 += rd_ld1(buf + (long)b * F + i) * rd_dv(b, B, 0);
       s1 += rd_ld1(buf + (long)(b + 16) * F + i) * rd_dv(b + 16, B, 0);
     }
-    if (b < NB) s0 += rd_ld1(buf + (long)b * F + i) * rd_dv(b, B, 0);
+    if (b < b1) s0 += rd_ld1(buf + (long)b * F + i) * rd_dv(b, B, 0);
   }
   red[threadIdx.x] = s0 + s1;
   __syncthreads();
   if (g == 0 && i < F) {
     float s = red[threadIdx.x];
     for (int j = 1; j < 16; ++j) s += red[j * 16 + threadIdx.x];
-    dw[i] = s;
+    out[(long)blockIdx.y * F + i] = s;
   }
 }
 
