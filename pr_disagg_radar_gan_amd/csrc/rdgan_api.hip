@@ -1412,7 +1412,27 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // sums the in-tile taps itself and writes 3 (9) floats per grid point instead of 32.
   const int gq = 256 % (nd * nd) == 0 ? 3 : (256 % nd == 0 ? 9 : 0);
   const long ncol = (long)B * nd * nd;
-  if (gq && h->tapgather && (h->edge_kernels >= 2 || (h->edge_kernels && a16))) {
+  if (!a16 && h->tapgather && h->edge_kernels == 1 && g9w_mfma_ok(nd, (long)B * h->gpix[3])) {
+    // fp32 storage: pipelined streaming kernel on 128-pixel tiles (rdgan_edge.hip.h), nine kw-sums per grid point
+    ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
+    const long rows9 = (long)B * h->gpix[3];
+    h->flops_acc += 2.0 * rows9 * 64 * 27;
+    if (nd * nd <= 256) {       // whole (h,w) planes in a 256-pixel tile: three sums per grid point
+      const size_t lds9 = (size_t)(256 * 64 + 256 * 33) * sizeof(float);
+      RD_TRY(ensure_lds(h, (const void*)k_g9_fwd_mfma<256>, lds9));
+      hipLaunchKernelGGL(k_g9_fwd_mfma<256>, dim3((unsigned)std::min<long>((rows9 + 255) / 256, 256)), dim3(512), lds9, st,
+                         (const float*)h->h3, gp + h->goff[8], h->P9, rows9, nd, 2 * ilog2(nd));
+      hipLaunchKernelGGL((k_tapsum_softmax<RDGAN_NHOURS, 3>), dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, st, h->P9,
+                         gp + h->goff[9], out, B, nd, nd, h->d_flag);
+    } else {
+      const size_t lds9 = (size_t)(128 * 64 + 128 * 33) * sizeof(float);
+      RD_TRY(ensure_lds(h, (const void*)k_g9_fwd_mfma<128>, lds9));
+      hipLaunchKernelGGL(k_g9_fwd_mfma<128>, dim3((unsigned)std::min<long>((rows9 + 127) / 128, 768)), dim3(256), lds9, st,
+                         (const float*)h->h3, gp + h->goff[8], h->P9, rows9, nd, 2 * ilog2(nd));
+      hipLaunchKernelGGL((k_tapsum_softmax<RDGAN_NHOURS, 9>), dim3((unsigned)((ncol + 63) / 64)), dim3(256), 0, st, h->P9,
+                         gp + h->goff[9], out, B, nd, nd, h->d_flag);
+    }
+  } else if (gq && h->tapgather && (h->edge_kernels >= 2 || (h->edge_kernels && a16))) {
     // dedicated streaming kernel (rdgan_edge.hip.h): same tiles, same arithmetic and output as the tap-gathering GEMM below.
     // Default in the bf16 storage mode (one pass over h3 at 5.4 TB/s: 37 us against 153 us at bs 256); with fp32 storage its
     // one-tile-per-workgroup form (64 KB tiles, two workgroups per CU in lockstep) only matches the GEMM (159 vs 147 us),

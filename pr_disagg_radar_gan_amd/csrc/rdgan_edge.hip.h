@@ -141,6 +141,94 @@ k_g9_fwd(const T* __restrict__ h3, const float* __restrict__ w9 /* [27][64] */, 
 }
 
 // ------------------------------------------------------------------------------------
+// Last generator conv, forward, fp32 storage (T:345), pipelined: the same products as k_g9_fwd<float> / the tap-gathering GEMM
+// on 128-pixel tiles (R = 128 / W whole w rows, W a power of two <= 128) by persistent workgroups, three per CU.  A tile's
+// fragments are read into registers, then -- behind a barrier -- the DMA of the workgroup's next tile is issued, and only then
+// come the 32 MFMAs, the product tile P[128][32 taps] and the sums over kw (NQ = 9 sums per grid point in the tap-gather
+// format, whatever the domain size): the next 32 KB fly while this tile is worked on.  k_g9_fwd<float> (one 64 KB tile per
+// workgroup, nothing in flight while it computes) and the tiled GEMM both need ~150 us for the 403 MB at bs 256.
+// The kernel's 27 x 64 weights sit in registers (32 per lane) for the whole launch.
+// ------------------------------------------------------------------------------------
+// TP = 128 (256 threads, three workgroups per CU): any W; nine kw-sums per grid point.  TP = 256 (512 threads, one workgroup per
+// CU with 64 KB in flight): tiles of whole (h,w) planes (ndomain 8 / 16), three (kh,kw)-sums per grid point -- k_tapsum_softmax
+// then reads 3 instead of 9 values per tap plane (8 instead of 32 us at bs 256).
+template <int TP>
+__global__ void __launch_bounds__(TP * 2, TP == 128 ? 3 : 1)
+k_g9_fwd_mfma(const float* __restrict__ h3, const float* __restrict__ w9 /* [27][64] */, float* __restrict__ Q, long rows, int Wd,
+              int hwlog2) {
+  constexpr int CST = 33, NT = TP * 2, NQ = TP == 128 ? 9 : 3;
+  static_assert(TP == 128 || TP == 256, "pixels per tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;                                           // [TP][64], 16-byte chunk c of row r stored at c ^ (r & 15)
+  float* Pt = smem + TP * 64;                                 // [TP][CST] products
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  const int HW = 1 << hwlog2;
+  // B operand, constant: k-step s multiplies channel c = 32 lhalf + s; lane n = tap l31 (taps 27..31: zero)
+  float wv[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) wv[s] = l31 < 27 ? w9[l31 * 64 + 32 * lhalf + s] : 0.f;
+  auto issue = [&](unsigned m0) {         // 32 rows per wave by DMA, swizzled on the source side (rows beyond the tensor -> zeros)
+    const __amdgpu_buffer_rsrc_t rs = rd_make_rsrc(h3 + (long)m0 * 64);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = wave * 32 + k * 4 + (lane >> 4);
+      const int c_log = (lane & 15) ^ (r & 15);
+      unsigned voff = m0 + r < (unsigned)rows ? (unsigned)(r * 256 + c_log * 16) : RD_OOB;
+      asm volatile("" : "+v"(voff));
+      rd_lds_dma16(rs, Hs + (wave * 32 + k * 4) * 64, (int)voff, 0);
+    }
+  };
+  const long ntiles = (rows + TP - 1) / TP;
+  long tile = blockIdx.x;
+  if (tile < ntiles) issue((unsigned)(tile * TP));
+  for (; tile < ntiles; tile += gridDim.x) {
+    const unsigned m0 = (unsigned)(tile * TP);                // (the host keeps rows < 2^31)
+    __syncthreads();                                          // (vmcnt(0) in front of it) the tile has landed; the last tile's sums are out
+    const int i = wave * 32 + l31;                            // this lane's pixel (MFMA row)
+    f32x4 fa[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = *(const f32x4*)&Hs[i * 64 + (((8 * lhalf + j) ^ (i & 15)) * 4)];
+    __syncthreads();                                          // every wave holds its fragments: the tile's LDS is free
+    const long next = tile + gridDim.x;
+    if (next < ntiles) issue((unsigned)(next * TP));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s >> 2][s & 3], wv[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Pt[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * CST + l31] = acc[r];
+    __syncthreads();
+    // sums over the taps whose neighbours lie inside the tile (same arithmetic and order as RD_EPI_TAPGATHER)
+    const int Hd = HW / Wd;
+    for (int o = tid; o < TP * NQ; o += NT) {
+      const int r = o & (TP - 1), j = o / TP;
+      const unsigned m = m0 + (unsigned)r;
+      if (m >= (unsigned)rows) continue;
+      const unsigned pl = m >> hwlog2, hw = m & (unsigned)(HW - 1);
+      const int ww = (int)(hw & (unsigned)(Wd - 1)), hh = (int)(hw / (unsigned)Wd);
+      float sum = 0.f;
+      if constexpr (NQ == 9) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if ((unsigned)(ww + kw - 1) < (unsigned)Wd) sum += Pt[(r + kw - 1) * CST + j * 3 + kw];
+      } else {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          if ((unsigned)(hh + kh - 1) >= (unsigned)Hd) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            if ((unsigned)(ww + kw - 1) < (unsigned)Wd) sum += Pt[(r + (kh - 1) * Wd + kw - 1) * CST + (j * 3 + kh) * 3 + kw];
+        }
+      }
+      Q[((long)pl * NQ + j) * HW + hw] = sum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Last generator conv, weight gradient (T:345 backward): dW9[tap][c] = sum_u dl[u - off(tap)] * h3[u][c] as a GEMM on the matrix
 // pipe, C[32 taps][64 c] += A^T[32][128 pixels] x B[128][64] per 128-pixel tile (W a power of two <= 128: the tile is R = 128 / W
 // whole w rows).  B = the h3 rows of the tile, in by LDS-DMA: the 403 MB tensor is read once.  A is never materialised: for each

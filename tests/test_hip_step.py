@@ -291,6 +291,13 @@ def test_last_conv_streaming_kernel_equals_the_tiled_gemm(nd, B):
         assert torch.equal(a, b)
         ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
         assert rel_err(a.cpu().numpy(), ref) < 2e-5
+        # the default (1): the pipelined kernel on 128-pixel tiles -- another k order in the MFMAs, nine kw-sums per grid point
+        # whatever the domain size -- agrees with both to fp32 rounding
+        eng.set_option("edge_kernels", 1)
+        c = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+        assert rel_err(c, b.cpu().numpy()) < 2e-6
+        assert rel_err(c, ref) < 2e-5
+        np.testing.assert_allclose(c.sum(axis=1), 1.0, atol=3e-6)
     finally:
         eng.close()
 
