@@ -637,6 +637,9 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
     if (hp.N % 128 == 0) return launch_conv_ws_cfg<128, 128, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
     if (hp.N == 64) return launch_conv_ws_cfg<256, 64, 4, 1>(h, hp, dp, B, src, W, ldw, dst, epi, st);
   }
+  // at most 64 rows (the generator's Dense layer at ndomain 64 with 64 samples: 64 x 4196 against 4196 x 49152 weights): a
+  // 128-row tile would multiply 64 rows of zeros -- the launch streams its 825 MB of weights at 1.5 TB/s, the 64-row tile at 2.6
+  if (hp.nphases == 1 && (long)B * hp.ph[0].L <= 64 && hp.N % 64 == 0 && !shift) RD_CONV(64, 64, 2, 2);
   // phases of unequal length (stride-2 input gradients: 8 ... 1 taps): the 8-tap workgroups set the launch time, so a
   // mid-size launch takes the narrower tile (twice the workgroups, half the work each)
   int tmin = hp.ph[0].ntaps, tmax = tmin;
