@@ -299,7 +299,10 @@ def main():
         # difference part of the shared-centre form 4 (fp32 default); the bf16 storage mode defaults to the collapsed form
         fast_fwd = opts.get("fast_fwd", "0" if bf16 else "1")
         taps = 27 if opts.get("collapse") == "0" else (8 if fast_fwd == "0" else 4)
-        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+        # "split3" (optional data point, never the metric): fp32 storage, the conv GEMMs' products on the bf16 matrix pipe from
+        # operands split three ways in registers, six partial products per fp32 product -> priced against a sixth of the bf16 peak
+        split3 = int(opts.get("split3", 0)) != 0 and not bf16
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16 else (BF16_MFMA_PEAK_TFLOPS / 6 if split3 else FP32_MFMA_PEAK_TFLOPS)
         achieved = gconv3_flops(B, ND, taps) / (avg_ms * 1e-3) / 1e12 if kern_n else None
         med = float(np.median(it_ms))
         direct_equiv = None
@@ -307,17 +310,21 @@ def main():
             gf = n_critic * DIRECT_GF_PER_SAMPLE[ND]["critic_step"] + DIRECT_GF_PER_SAMPLE[ND]["gen_step"]
             direct_equiv = gf * 1e9 * B / (med * 1e-3) / 1e12          # per GPU
         it_tflops = flops_iter / (med * 1e-3) / 1e12
-        is_metric = (args.config, ND, B, n_critic, bf16) == (2, 16, 256, 1, False)
+        is_metric = (args.config, ND, B, n_critic, bf16, split3) == (2, 16, 256, 1, False, False)
         dtype = ("bf16 activations / gradients in HBM and bf16 MFMA operands, f32 accumulation, f32 master weights, "
                  "PixelNorm / softmax / penalty / Adam in f32") if bf16 else "f32"
+        if split3:
+            dtype = ("f32 storage and accumulation; forward / input-gradient conv GEMMs multiply f32 operands split into three bf16 "
+                     "parts on the bf16 matrix pipe (6 partial products per product; weight gradients on the f32 pipe) -- "
+                     "optional data point, not the BASELINE metric")
         out = {
             "metric": "cWGAN-GP train samples/sec, 24x16x16 tiles, bs=256" if is_metric
                       else f"cWGAN-GP train samples/sec, 24x{ND}x{ND} tiles, bs={B} per GPU (config {args.config})",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": cfg["name"] if (ND, n_critic, bf16) == (cfg["nd"], cfg["n_critic"], bool(cfg["bf16"])) and args.batch is None
-                                   else f"ndomain={ND}, 24h, bs={B} per GPU, {'bf16 storage' if bf16 else 'fp32'}, n_critic={n_critic}",
+            "config": {"workload": cfg["name"] if (ND, n_critic, bf16) == (cfg["nd"], cfg["n_critic"], bool(cfg["bf16"])) and args.batch is None and not split3
+                                   else f"ndomain={ND}, 24h, bs={B} per GPU, {'bf16 storage' if bf16 else ('fp32, split3 GEMMs' if split3 else 'fp32')}, n_critic={n_critic}",
                        "batch_per_gpu": B, "global_batch": world * B, "n_critic": n_critic, "parallelism": f"dp{world}",
                        "world": world, "rccl_ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
                        "exchange": None if world == 1 else ("one all-reduce of the flat gradient slab per optimizer update"

@@ -136,6 +136,11 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * kernel (one pass over the block-3 output at HBM speed, same arithmetic and tap-sum format as "tapgather"); 2 = also with
  * fp32 storage (bit-identical to the tiled GEMM, not faster there); 0 = the tiled GEMM kernel everywhere.
  * "dense_wgrad_slices" (default 0 = by batch size; tests): row slices of the critic Dense weight gradient (1..16).
+ * "split3" (default 0; optional data point, not the BASELINE metric): with fp32 storage, the forward / input-gradient conv GEMMs
+ * of the producer/consumer kernel multiply on the bf16 matrix pipe -- every fp32 operand is split in registers into three bf16
+ * parts (x = x1 + x2 + x3, 24 significant bits) and a product is the sum of six partial products, accumulated in fp32.  Memory,
+ * LDS images, epilogues and the weight-gradient kernels are those of the fp32 path; errors against the fp64 oracle stay within
+ * the fp32 path's tolerances (observed 1-3x its error).
  * "side_stream" (default 1): inside a call the weight-only kernels (generator weight forms, critic weight transposes and
  * bf16 images) and the bias-gradient column sums are issued on a second stream owned by the handle, beside the GEMMs on the
  * caller's stream and ordered against it by events (fork at entry, joins in front of the first reader / at the end of the

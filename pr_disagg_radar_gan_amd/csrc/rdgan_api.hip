@@ -402,6 +402,7 @@ struct rdgan_handle {
   // bf16 images) and the bias-gradient column sums run beside the caller's stream, ordered by events: ~50 launches of 5-30 us
   // per iteration that would otherwise sit between the GEMMs.  Same kernels, same arithmetic: results are bit-identical.
   int side_on = 1;
+  int split3 = 0;                 // 1: fp32 conv GEMMs of the producer/consumer kernel multiply on the bf16 matrix pipe from 3-way split operands (optional data point)
   int dense_slices = 0;           // tests: force the row-slice count of the critic Dense weight gradient (0 = by batch size)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cw = nullptr, ev_g[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -578,6 +579,10 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
       if (res) kern = epi.nametag == 1 ? k_conv_gemm_ws<BM, BN, WM, WN, TG, true, 1, true> : k_conv_gemm_ws<BM, BN, WM, WN, TG, true, 0, true>;
     } else res = false;
   } else res = false;
+  if constexpr (!BF) {
+    // "split3": the same launch on the bf16 matrix pipe from operands split three ways in registers (rdgan_gemm_ws.hip.h)
+    if (h && h->split3) kern = k_conv_gemm_ws<BM, BN, WM, WN, TG, false, 0, false, true>;
+  }
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
   constexpr int KCH = BF ? 64 : 32;                    // K elements per chunk
   if (BF && hp.SC % 64) return bad_arg(h, "conv: bf16 operands need a multiple of 64 channels per tap");
@@ -1236,6 +1241,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "dense_wgrad_slices")) { h->dense_slices = value; return 0; }
+  if (!strcmp(name, "split3")) { h->split3 = value ? 1 : 0; return 0; }
   if (!strcmp(name, "side_stream")) { h->side_on = (value && h->side) ? 1 : 0; return 0; }
   if (!strcmp(name, "edge_kernels")) { h->edge_kernels = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   if (!strcmp(name, "sample_offset")) { if (value < 0) return bad_arg(h, "set_option: sample_offset < 0"); h->sample_offset = value; return 0; }

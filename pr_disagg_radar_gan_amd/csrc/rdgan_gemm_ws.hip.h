@@ -32,6 +32,26 @@ __device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float*
 // LeakyReLU, dropout, gating); split-K partial slabs stay fp32.  out16 = 0 (fp32 destination) serves the op-level parity
 // tests and the column GEMM of the critic's input gradient.
 typedef __bf16 rd_bf16x8 __attribute__((ext_vector_type(8)));
+// S3 ("split3", optional data point, never the headline): fp32 operands in memory and LDS exactly as in the fp32 kernel, but the
+// products run on the bf16 matrix pipe: each fp32 value is split in registers into three bf16 parts x = x1 + x2 + x3 (round to
+// nearest even at each step: 3 x 8 significant bits, the whole fp32 mantissa) and a product x*y is summed from the six partial
+// products x1y1 + x1y2 + x2y1 + x1y3 + x2y2 + x3y1 (each exact in fp32; the dropped ones are below 2^-24 of the product), fp32
+// accumulation: 6 x 32 matrix-pipe cycles per 16 k instead of 8 x 64.  Loader waves, LDS images, tap masks, epilogue: unchanged.
+typedef float rd_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rd_bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rd_split3(const float* x, u32x4_t& p1, u32x4_t& p2, u32x4_t& p3) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const rd_f32x2 v = {x[2 * i], x[2 * i + 1]};
+    const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rd_bf16x2v));
+    const rd_f32x2 v1 = {__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xFFFF0000u)};
+    const rd_f32x2 r = v - v1;
+    const unsigned u2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rd_bf16x2v));
+    const rd_f32x2 v2 = {__builtin_bit_cast(float, u2 << 16), __builtin_bit_cast(float, u2 & 0xFFFF0000u)};
+    const rd_f32x2 t = r - v2;
+    p1[i] = u1; p2[i] = u2; p3[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, rd_bf16x2v));
+  }
+}
 // NAMETAG only gives a launch its own kernel symbol (the dominant launch, so that per-name profiler statistics
 // describe exactly that launch); it does not change the code.
 // RES (bf16 kernels, plans whose taps of a phase are (h,w)-shifted views of the same source planes: the forward GEMMs of the
@@ -40,12 +60,13 @@ typedef __bf16 rd_bf16x8 __attribute__((ext_vector_type(8)));
 // weights stream through the two stages.  A compute lane reads its fragment for tap t from LDS row r + dh*SW + dw (the
 // source planes hold whole (h,w) planes, H*W divides BM) and zeroes it where the tap falls outside the image.  With the K loop
 // down to 8 chunks the streaming form is bound by what a CU can pull from L2 into LDS; this one is not.
-template <int BM, int BN, int WM, int WN, int TG, bool BF = false, int NAMETAG = 0, bool RES = false>
+template <int BM, int BN, int WM, int WN, int TG, bool BF = false, int NAMETAG = 0, bool RES = false, bool S3 = false>
 __global__ void __launch_bounds__(512, 4)
 k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__ src,
                const float* __restrict__ W, int ldw, float* dst, RdEpi epi) {
   static_assert(WM * WN == 4, "4 compute waves");
   static_assert(!RES || BF, "resident-tile mode: bf16 kernels only");
+  static_assert(!S3 || (!BF && !RES), "split mode: fp32 operands in memory and in LDS");
   constexpr int BK = 32;
   static_assert(TG == 4 || TG == 8, "taps per register group");
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -374,6 +395,39 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, fa[cur][i]),
                                                                   __builtin_bit_cast(rd_bf16x8, fb[cur][j]), acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    } else if constexpr (S3) {
+      for (int q = 0; q < nchunks; ++q) {
+        const int buf = q & 1;
+        const float* As = smem + buf * STAGE + (wm * WTM + l31) * BK;
+        const float* Bs = smem + buf * STAGE + BM * BK + wn * WTN + l31;
+#pragma unroll
+        for (int k16 = 0; k16 < 2; ++k16) {
+          // this lane's 8 k of the 16: k16*16 + lhalf*8 .. +7 (A: two 16-byte chunks of the row; B: eight rows of the [k][BN] image)
+          u32x4_t b1[TN], b2[TN], b3[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = Bs[(k16 * 16 + lhalf * 8 + e) * BN + j * 32];
+            rd_split3(x, b1[j], b2[j], b3[j]);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const f32x4 lo = *(const f32x4*)&As[i * 32 * BK + (((k16 * 4 + lhalf * 2) ^ a_sw) * 4)];
+            const f32x4 hi = *(const f32x4*)&As[i * 32 * BK + (((k16 * 4 + lhalf * 2 + 1) ^ a_sw) * 4)];
+            const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            u32x4_t a1, a2, a3;
+            rd_split3(x, a1, a2, a3);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#define RD_MF3(A_, B_) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, A_), __builtin_bit_cast(rd_bf16x8, B_), acc[i][j], 0, 0, 0)
+              RD_MF3(a3, b1[j]); RD_MF3(a2, b2[j]); RD_MF3(a1, b3[j]); RD_MF3(a2, b1[j]); RD_MF3(a1, b2[j]); RD_MF3(a1, b1[j]);
+#undef RD_MF3
+            }
+          }
         }
         __syncthreads();
       }
