@@ -31,7 +31,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-L2_TO_LDS_PEAK_TBPS = 17.8         # rows gathered from L2 into LDS, chip-wide: 16.8-18.8 TB/s measured (MI355X_MICROARCH.md, "Indexed rows")
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # dense bf16 (v_mfma_f32_32x32x16_bf16, 32 cycles): 16x the fp32 rate
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable with a float4 copy)
 
@@ -140,12 +139,37 @@ def launch_children(args, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
+    # rank 0's stdout is drained by a thread while every rank is polled: as soon as one rank exits non-zero (a crash at start-up,
+    # a failed rendezvous) the others are terminated and that code is returned -- rank 0 must not sit in a collective until
+    # the RCCL watchdog fires, holding the GPUs
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = 0
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [rc for rc in rcs if rc not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=30)
+    out0 = (chunks[0] if chunks else b"").decode()
     for line in out0.splitlines():             # (the gloo rehearsal backend prints a connection banner on stdout)
-        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+        (sys.stdout if line.startswith("{") and not failed else sys.stderr).write(line + "\n")
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return abs(failed) if failed else 0
 
 
 def main():
@@ -161,6 +185,9 @@ def main():
                     help="weak: --batch per GPU; strong: the configuration's global batch divided over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="exchange + Adam on the compute stream (A/B)")
+    ap.add_argument("--exchange", choices=("auto", "allreduce", "sharded"), default="auto",
+                    help="gradient exchange per slab: one all-reduce, or reduce-scatter + Adam on the owned 1/N + all-gather; "
+                         "auto = sharded for slabs of at least 128 MB (the ndomain-64 generator)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -180,6 +207,8 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("RDGAN_BENCH_FAIL_RANK") == str(rank) and world > 1:      # test hook (tests/test_hip_dp.py): a rank that dies at start-up
+        raise SystemExit(3)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
@@ -225,7 +254,7 @@ def main():
     rng = np.random.default_rng(0)                  # identical initial weights on every rank
     trainer = WGANGPTrainer(eng, W.init_generator(rng, ND), W.init_critic(rng, ND), n_disc=n_critic,
                             process_group=pg, world_size=world, rank=rank, base_seed=1234 + 1000 * args.config,
-                            overlap=False if args.no_overlap else None)
+                            overlap=False if args.no_overlap else None, exchange=args.exchange)
     # synthetic inputs resident in HBM; per-rank seeds 1234 + 1000*config + rank
     nbuf = 4 if B * ND * ND <= 256 * 16 * 16 * 8 else 2
     data = []
@@ -327,9 +356,15 @@ def main():
                                    else f"ndomain={ND}, 24h, bs={B} per GPU, {'bf16 storage' if bf16 else ('fp32, split3 GEMMs' if split3 else 'fp32')}, n_critic={n_critic}",
                        "batch_per_gpu": B, "global_batch": world * B, "n_critic": n_critic, "parallelism": f"dp{world}",
                        "world": world, "rccl_ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
-                       "exchange": None if world == 1 else ("one all-reduce of the flat gradient slab per optimizer update"
-                                                            + (", on a side stream beside the next generator forward"
-                                                               if trainer.overlap else ", on the compute stream")),
+                       "exchange": None if world == 1 else
+                                   ("per optimizer update: " + "; ".join(
+                                       ("generator" if k == "g" else "critic") + " slab: "
+                                       + ("one all-reduce of the flat gradient slab" if v == "allreduce" else
+                                          "reduce-scatter, Adam on the owned 1/%d, all-gather of the updated weights" % world)
+                                       for k, v in sorted(trainer.exchange.items()))
+                                    + (", on a side stream beside the next generator forward" if trainer.overlap else ", on the compute stream")),
+                       "exchange_by_slab": None if world == 1 else dict(trainer.exchange),
+                       "rccl_verified": None if world == 1 else (args.backend == "nccl"),
                        "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
             "iteration_ms": {"median": round(med, 4), "p10": round(float(np.percentile(it_ms, 10)), 4),
                              "p90": round(float(np.percentile(it_ms, 90)), 4), "n": int(args.steps),
@@ -354,16 +389,6 @@ def main():
                          "iteration_direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2),
                          "kernel_classes": classes},
         }
-        if bf16 and taps == 8 and ND == 16 and B >= 22 and kern_n:
-            # what binds the bf16 launch: every K chunk of a 256x64 tile is a 40 KB stage pulled from L2 into LDS (32 KB of rows +
-            # 8 KB of weights, 16 chunks per tile, 24 tiles per sample; PMC TCC_REQ x 128 B per launch agrees within 5 %,
-            # profiles/r02_l2_requests_bf16_bs256.csv) and LDS holds one stage in flight per workgroup, two workgroups per CU.
-            # Ceiling of that path: the guide's measured L2 -> LDS gather rate, 16.8-18.8 TB/s chip-wide.
-            fill = B * 24 * 16 * (32768 + 8192)
-            out["roofline"]["lds_fill"] = {"bytes_per_launch": fill, "achieved_TBps": round(fill / (avg_ms * 1e-3) / 1e12, 2),
-                                           "peak_TBps": L2_TO_LDS_PEAK_TBPS, "frac": round(fill / (avg_ms * 1e-3) / 1e12 / L2_TO_LDS_PEAK_TBPS, 3),
-                                           "note": "L2 -> LDS fill of the streaming tiles: the resource this launch runs closest to "
-                                                   "(MFMA 0.32, HBM 0.13 of their roofs)"}
         out.update({
             "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},
         })

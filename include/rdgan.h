@@ -149,6 +149,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "sample_offset" (default 0): global index of this rank's first sample.  RandomWeightedAverage's alpha (T:222-223) of
  * local sample k is uniform(key(seed, ALPHA), sample_offset + k), so ranks that share a seed draw the alphas of the
  * global batch (used by the data-parallel equivalence tests; the dropout masks stay keyed by the local element index).
+ * "keep_gates" (default 0; test hook): a critic step keeps a copy of the interpolated third of its activations before the
+ * penalty's second sweep overwrites it in place, so that rdgan_debug_activation returns the LeakyReLU / dropout pattern of all
+ * 3B samples; allocates its buffers when set (not inside a step).
  * "tapgather" (default 1): the last generator conv (64 -> 1, T:345) runs as a column GEMM over its 27 taps whose
  * epilogue already sums the taps that fall inside the 256-row tile (ndomain 8/16: whole planes, 32/64/128: whole
  * rows), writing 3 or 9 floats per grid point instead of 32; 0 (and every other ndomain) = full column matrix +
@@ -240,7 +243,9 @@ int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* r
                                  long npix, int C, void* stream);
 /* Test hook: copies the first n floats of an activation tensor the last forward pass left in the workspace into `out`
  * (device, fp32): which = 0..3 generator h0..h3 [B, D, H, W, C] after LeakyReLU; 4..7 critic layers 1..4 after LeakyReLU
- * and dropout.  The gradient parity tests take the LeakyReLU slope pattern of the fp32 run from here, so that the fp64
+ * and dropout ([B] samples after a generator step or a critic forward; [3B] = real | fake | interpolated after a critic step,
+ * whose interpolated third is only meaningful with the option "keep_gates": without it the second sweep of the gradient penalty
+ * has overwritten it).  The gradient parity tests take the LeakyReLU slope pattern of the run from here, so that the fp64
  * oracle differentiates the same piecewise-linear branch. */
 int rdgan_debug_activation(rdgan_handle* h, int which, float* out, long n, void* stream);
 /* dropout keep-scale mask (0 or 1/0.75) and uniforms of the counter RNG, for pinning it to oracle/rng.py */

@@ -110,24 +110,33 @@ def critic_masks(seed, batch, ndomain, dtype=torch.float32):
     return out
 
 
-def critic_step_grads(dp, gp, x_real, cond, z, seed, alpha_offset=0):
+def critic_step_grads(dp, gp, x_real, cond, z, seed, alpha_offset=0, gates=None, fake=None, return_intermediates=False):
     """One critic ``train_on_batch`` graph (T:363-392,472) up to the gradients.
 
     The three critic passes of the reference (T:372,373,379) are evaluated as ONE batch
     [real; fake; interpolated] of 3B samples so that dropout-mask element indices match the
     HIP path; alpha of sample k comes from stream ALPHA at index alpha_offset + k (alpha_offset = the global index of
     this shard's first sample, the HIP option "sample_offset").  Returns (losses[4] = total, valid, fake, gp
-    as Keras reports them, grads list in critic weight order)."""
+    as Keras reports them, grads list in critic weight order).
+
+    gates: optional 4 slope patterns (3B samples each, [real; fake; interpolated]) for the critic's LeakyReLUs, so that this
+    oracle differentiates -- twice, for the penalty -- the piecewise-linear branch an external run took (see _lrelu).
+    fake: optional generator output to use instead of this oracle's own forward pass: the generator is frozen in this
+    step (T:363), its output is a constant input of the graph; a reduced-precision run passes what IT fed its critic.
+    return_intermediates: also return the critic's four post-dropout activations of the 3B batch (for check_gates)."""
     B = x_real.shape[0]
     nd = cond.shape[1]
     dt = x_real.dtype
     dp = [t.detach().clone().requires_grad_(True) for t in dp]
-    with torch.no_grad():
-        fake = generator_forward(gp, z, cond)                        # generator frozen, T:363
+    if fake is None:
+        with torch.no_grad():
+            fake = generator_forward(gp, z, cond)                    # generator frozen, T:363
+    else:
+        fake = fake.detach().to(dt)
     alpha = torch.from_numpy(orng.uniform(seed, orng.STREAM_ALPHA, B, start=alpha_offset)).to(dt).reshape(B, 1, 1, 1, 1)
     xhat = (alpha * x_real + (1 - alpha) * fake).detach().requires_grad_(True)   # T:221-224
     masks = critic_masks(seed, 3 * B, nd, dt)
-    v = critic_forward(dp, torch.cat([x_real, fake, xhat], 0), torch.cat([cond, cond, cond], 0), masks)
+    v, inter = critic_forward(dp, torch.cat([x_real, fake, xhat], 0), torch.cat([cond, cond, cond], 0), masks, True, gates=gates)
     v_real, v_fake, v_hat = v[:B], v[B:2 * B], v[2 * B:]
     g, = torch.autograd.grad(v_hat.sum(), xhat, create_graph=True)   # K.gradients, T:240
     gpen = torch.sqrt((g * g).reshape(B, -1).sum(1, keepdim=True)) - 1   # T:241
@@ -138,21 +147,54 @@ def critic_step_grads(dp, gp, x_real, cond, z, seed, alpha_offset=0):
     grads = torch.autograd.grad(total, dp, allow_unused=True)
     grads = [torch.zeros_like(p) if gg is None else gg for p, gg in zip(dp, grads)]
     losses = torch.stack([total, l_valid, l_fake, l_gp]).detach()
+    if return_intermediates:
+        return losses, [gg.detach() for gg in grads], [hh.detach() for hh in inter["h"]]
     return losses, [gg.detach() for gg in grads]
 
 
-def gen_step_grads(dp, gp, z, cond, seed, gates=None):
+def gen_step_grads(dp, gp, z, cond, seed, gates=None, return_intermediates=False):
     """One generator ``train_on_batch`` graph (T:395-408,482): loss = mean(-D(G(z,c))),
-    critic frozen but dropout active.  gates: optional (generator [h0..h3], critic [4 layers]) slope patterns."""
+    critic frozen but dropout active.  gates: optional (generator [h0..h3], critic [4 layers]) slope patterns.
+    return_intermediates: also return (generator h0..h3, critic post-dropout activations) for check_gates."""
     B = z.shape[0]
     nd = cond.shape[1]
     gp = [t.detach().clone().requires_grad_(True) for t in gp]
-    img = generator_forward(gp, z, cond, gates=None if gates is None else gates[0])
+    img, gi = generator_forward(gp, z, cond, True, gates=None if gates is None else gates[0])
     masks = critic_masks(seed, B, nd, z.dtype)
-    v = critic_forward(dp, img, cond, masks, gates=None if gates is None else gates[1])
+    v, di = critic_forward(dp, img, cond, masks, True, gates=None if gates is None else gates[1])
     loss = torch.mean(-1.0 * v)
     grads = torch.autograd.grad(loss, gp)
+    if return_intermediates:
+        return loss.detach(), [gg.detach() for gg in grads], ([gi[k].detach() for k in ("h0", "h1", "h2", "h3")],
+                                                              [hh.detach() for hh in di["h"]])
     return loss.detach(), [gg.detach() for gg in grads]
+
+
+def check_gates(gates, acts, masks=None, max_margin=1e-3, max_fraction=1e-3):
+    """Guard for the ``gates=`` mechanism: an externally supplied slope pattern may differ from this oracle's own decision
+    only where the oracle's LeakyReLU input is within rounding of zero.  gates / acts: matching lists of bool patterns and of
+    the post-activation tensors this oracle computed WITH those patterns (x * slope(gate), so sign(x) = sign(act) is the
+    oracle's own decision for the inputs it saw); masks: optional dropout masks (elements dropped by the mask are ignored:
+    their gradient is zero whatever the slope, and an external run reads them back as 0).  Asserts that disagreements are
+    rare (max_fraction of the layer) and all sit within max_margin of the kink, measured as |LeakyReLU input| / RMS of the
+    layer.  Returns the worst margin met."""
+    worst = 0.0
+    for li, (g, a) in enumerate(zip(gates, acts)):
+        live = torch.ones_like(g) if masks is None else (masks[li] != 0)
+        pre = a / torch.where(g, torch.ones((), dtype=a.dtype), torch.full((), LRELU, dtype=a.dtype))
+        if masks is not None:
+            pre = pre / torch.where(live, masks[li], torch.ones((), dtype=a.dtype))
+        own = pre > 0
+        rms = float(pre[live].pow(2).mean().sqrt())
+        bad = (g != own) & live
+        nbad = int(bad.sum())
+        if nbad:
+            frac = nbad / max(1, int(live.sum()))
+            margin = float(pre[bad].abs().max()) / rms
+            worst = max(worst, margin)
+            assert frac <= max_fraction, f"layer {li}: {nbad} slope disagreements ({frac:.2e} of the layer)"
+            assert margin <= max_margin, f"layer {li}: slope disagreement {margin:.2e} RMS away from the kink"
+    return worst
 
 
 def adam_update(params, grads, vs, t, lr=1e-4, beta2=0.9, eps=1e-7):

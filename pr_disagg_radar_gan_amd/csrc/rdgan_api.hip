@@ -404,6 +404,12 @@ struct rdgan_handle {
   int side_on = 1;
   int split3 = 0;                 // 1: fp32 conv GEMMs of the producer/consumer kernel multiply on the bf16 matrix pipe from 3-way split operands (optional data point)
   int dense_slices = 0;           // tests: force the row-slice count of the critic Dense weight gradient (0 = by batch size)
+  // test hook "keep_gates": the critic step's second sweep overwrites the x_hat third of h_l in place; with the option on, that
+  // third is copied here first, so that rdgan_debug_activation can return the activations (= LeakyReLU / dropout pattern) of
+  // all 3B samples of the last critic step.  Allocated when the option is set, never inside a step.
+  int keep_gates = 0;
+  void* gate_keep[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int gate_keep_B = 0;            // samples held (0: the last call was not a critic step)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cw = nullptr, ev_g[4] = {nullptr, nullptr, nullptr, nullptr};
   int* d_flag;
@@ -1097,6 +1103,8 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     const int wd[] = {PL_D1F, PL_D2F, PL_D3F, PL_D4F};
     for (int id : wd) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)NB));
     wneed = std::max(wneed, (size_t)MB * (RDGAN_NHOURS / 2) * 1728);      // k_g9_wgrad_pairs: [27][64] per (sample, plane pair)
+    if (g9w_mfma_ok(nd, (long)MB * h->gpix[3]))                            // k_g9_wgrad_mfma: [27][64] per persistent workgroup
+      wneed = std::max(wneed, (size_t)std::min<long>(((long)MB * h->gpix[3] + 127) / 128, 768) * 1728);
   }
   h->wpartial_cap = wneed;
   h->cpartial_cap = (size_t)1024 * std::max(h->n_nodes, 256);
@@ -1209,6 +1217,7 @@ extern "C" void rdgan_destroy(rdgan_handle* h) {
     for (auto e : h->ev_start[t]) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop[t]) (void)hipEventDestroy(e);
   }
+  for (void* g : h->gate_keep) if (g) (void)hipFree(g);
   if (h->ws) (void)hipFree(h->ws);
   if (h->d_plans) (void)hipFree(h->d_plans);
   if (h->d_tab) (void)hipFree(h->d_tab);
@@ -1241,6 +1250,13 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "dense_wgrad_slices")) { h->dense_slices = value; return 0; }
+  if (!strcmp(name, "keep_gates")) {
+    h->keep_gates = value ? 1 : 0;
+    h->gate_keep_B = 0;
+    for (int l = 1; l <= 4 && h->keep_gates; ++l)
+      if (!h->gate_keep[l]) RD_CHECK(h, hipMalloc(&h->gate_keep[l], (size_t)h->MB * h->dL[l] * h->dch[l] * sizeof(float)));
+    return 0;
+  }
   if (!strcmp(name, "split3")) { h->split3 = value ? 1 : 0; return 0; }
   if (!strcmp(name, "side_stream")) { h->side_on = (value && h->side) ? 1 : 0; return 0; }
   if (!strcmp(name, "edge_kernels")) { h->edge_kernels = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
@@ -1644,6 +1660,7 @@ extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params,
   if (!h || !critic_params || !sample || !cond || !out) return bad_arg(h, "critic_forward: null pointer");
   if (B < 1 || B > h->NB) return bad_arg(h, "critic_forward: B outside [1, 3*max_batch]");
   hipStream_t st = (hipStream_t)stream;
+  h->gate_keep_B = 0;
   RD_TRY(a16_check(h));
   if (h->a16) RD_TRY(prep_critic_weights(h, critic_params, st));      // (also makes the bf16 kernels of layers 2-4)
   else if (h->CP != h->Cin)
@@ -1707,6 +1724,15 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
     hipLaunchKernelGGL(k_gp_norm_r0, dim3(B * S), dim3(256), 0, st, h->g0, cin_hat, h->gpv, per, B, RD_GP_WEIGHT, h->CP, S, h->gp_part);
   }
   // second forward sweep of the double backward: r_l = gate_l * conv_l(r_{l-1}), in place over the x_hat third
+  h->gate_keep_B = 0;
+  if (h->keep_gates) {       // test hook: keep the x_hat third of every h_l (see rdgan_debug_activation)
+    for (int l = 1; l <= 4; ++l) {
+      const long third = (long)2 * B * h->dL[l] * h->dch[l];
+      RD_CHECK(h, hipMemcpyAsync(h->gate_keep[l], act_off(h, h->dh[l], third), (size_t)(third / 2) * (a16 ? 2 : 4),
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    h->gate_keep_B = B;
+  }
   {
     const float* in = cin_hat;
     for (int l = 1; l <= 4; ++l) {
@@ -1775,6 +1801,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   if (B < 1 || B > h->MB) return bad_arg(h, "gen_grad: B outside [1, max_batch]");
   hipStream_t st = (hipStream_t)stream;
   const int nd = h->nd;
+  h->gate_keep_B = 0;
   if (!h->collapse)
     for (int l = 1; l <= 3; ++l)
       RD_TRY(launch_transpose(h, gp + h->goff[2 * l], h->GWT[l], 27, h->gch[l - 1], h->gch[l], h->gch[l - 1], st));
@@ -1813,7 +1840,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
     const size_t lds = std::max<size_t>(g9_lds, 4 * 27 * 16 * sizeof(f32x4));
     RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_bwd_pairs<rd_bf16_t> : (const void*)k_g9_bwd_pairs<float>, 96 * 1024));
     int nwg;
-    if (h->edge_kernels && g9w_mfma_ok(nd, npix3)) {
+    if (h->edge_kernels && g9w_mfma_ok(nd, npix3) && (size_t)std::min<long>((npix3 + 127) / 128, 768) * 1728 <= h->wpartial_cap) {
       // weight gradient on the matrix pipe, the h3 tensor streamed once (rdgan_edge.hip.h)
       const size_t lds_m = g9w_mfma_lds(a16);
       RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_wgrad_mfma<rd_bf16_t> : (const void*)k_g9_wgrad_mfma<float>, lds_m));
@@ -2290,11 +2317,23 @@ extern "C" int rdgan_debug_activation(rdgan_handle* h, int which, float* out, lo
     src = h->dh[l]; cap = (long)h->NB * h->dL[l] * h->dch[l];
   }
   if (n > cap) return bad_arg(h, "debug_activation: n exceeds the tensor");
-  if (h->a16) {
-    hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const rd_bf16_t*)src, out, n);
-    RD_CHECK(h, hipGetLastError());
-  } else
-  RD_CHECK(h, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  hipStream_t st = (hipStream_t)stream;
+  auto copy = [&](const void* from, long first, long cnt) -> int {     // `cnt` elements of `from` -> out[first ..)
+    if (cnt <= 0) return 0;
+    if (h->a16) {
+      hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(cnt)), dim3(256), 0, st, (const rd_bf16_t*)from, out + first, cnt);
+      RD_CHECK(h, hipGetLastError());
+    } else
+      RD_CHECK(h, hipMemcpyAsync(out + first, from, sizeof(float) * cnt, hipMemcpyDeviceToDevice, st));
+    return 0;
+  };
+  RD_TRY(copy(src, 0, n));
+  if (which >= 4 && h->keep_gates && h->gate_keep_B > 0) {
+    // the last call was a critic step: the x_hat third of this layer as it was before the second sweep overwrote it
+    const int l = which - 3;
+    const long per = h->dL[l] * h->dch[l], first = 2L * h->gate_keep_B * per;
+    RD_TRY(copy(h->gate_keep[l], first, std::min<long>(n, first + h->gate_keep_B * per) - first));
+  }
   return 0;
 }
 

@@ -15,27 +15,61 @@ import torch
 LOSS_SLOTS = 8
 
 
+SHARD_THRESHOLD_BYTES = 128 << 20      # slabs above this take the sharded exchange by default (ndomain 64 generator: 837 MB)
+
+
 class WGANGPTrainer:
-    """overlap (default: world_size > 1 on a GPU engine): the gradient all-reduce and the Adam update of an optimizer step
+    """overlap (default: world_size > 1 on a GPU engine): the gradient exchange and the Adam update of an optimizer step
     run on a separate communication stream.  The next gradient call starts right away on the compute stream: its generator
     forward reads no critic weight, so it runs beside the critic's exchange + update, and the compute stream only waits for
     the `critic ready` event in front of the first kernel that reads critic weights (rdgan_*_grad_after).  Per iteration the
     n_disc critic exchanges hide behind generator forwards; the generator's own exchange is exposed (the next critic step's
     first kernel needs the new generator weights).  comm_hook(slab): called on the communication stream in place of / in
-    front of the all-reduce (tests: a delay kernel that would expose a missing dependency)."""
+    front of the exchange (tests: a delay kernel that would expose a missing dependency).
+
+    exchange: how a gradient slab is exchanged, per network.
+      "allreduce"  ONE all-reduce(sum) of the flat slab (losses in its tail), then Adam on the whole slab on every rank.
+      "sharded"    reduce-scatter(sum) of the slab, Adam on the 1/world this rank owns (its share of the weights and of the
+                   second-moment slab), all-gather of the updated weights; the loss sums ride in 8 spare floats behind the
+                   weights.  Same bytes on the wire as a ring all-reduce, Adam over n/world instead of n parameters, and the
+                   second-moment slab is only kept current where it is owned (sync_state() gathers it for checkpoints).
+      None/"auto"  "sharded" for a slab of at least SHARD_THRESHOLD_BYTES (the 837 MB generator of ndomain 64, whose Dense
+                   kernel is 99.6 % of it), else "allreduce" (the 11-16 MB slabs of ndomain 16 are latency-bound: one
+                   collective beats two).
+    Replicas stay bit-identical either way (every rank receives the same bytes)."""
 
     def __init__(self, engine, gen_arrays, critic_arrays, n_disc=5, lr=1e-4, beta2=0.9, eps=1e-7,
-                 process_group=None, world_size=1, rank=0, base_seed=1234, overlap=None, comm_hook=None):
+                 process_group=None, world_size=1, rank=0, base_seed=1234, overlap=None, comm_hook=None, exchange=None):
         self.eng = engine
         self.n_disc = int(n_disc)
         self.lr, self.beta2, self.eps = lr, beta2, eps
         self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
-        self.gparams = engine.to_slab(gen_arrays)
-        self.dparams = engine.to_slab(critic_arrays)
-        self.gv = torch.zeros_like(self.gparams)
-        self.dv = torch.zeros_like(self.dparams)
-        self.ggrad = torch.zeros(self.gparams.numel() + LOSS_SLOTS, dtype=torch.float32, device=self.gparams.device)
-        self.dgrad = torch.zeros(self.dparams.numel() + LOSS_SLOTS, dtype=torch.float32, device=self.dparams.device)
+        if exchange not in (None, "auto", "allreduce", "sharded"):
+            raise ValueError(f"exchange must be 'allreduce', 'sharded' or None, not {exchange!r}")
+        g0, d0 = engine.to_slab(gen_arrays), engine.to_slab(critic_arrays)
+        self.exchange = {}
+        self._pad = {}
+        for which, p0 in (("g", g0), ("d", d0)):
+            n = p0.numel()
+            sharded = self.world > 1 and (exchange == "sharded" or
+                                          (exchange in (None, "auto") and 4 * n >= SHARD_THRESHOLD_BYTES))
+            self.exchange[which] = "sharded" if sharded else "allreduce"
+            # sharded: every slab is padded to `world` equal shards of a multiple of 4 floats that also cover the loss tail
+            per = -(-(n + LOSS_SLOTS) // (4 * self.world)) * 4 if sharded else 0
+            P = per * self.world if sharded else n
+            self._pad[which] = (n, per, P)
+            pbuf = torch.zeros(max(P, n), dtype=torch.float32, device=p0.device)
+            pbuf[:n].copy_(p0)
+            vbuf = torch.zeros_like(pbuf)
+            grad = torch.zeros(max(P, n + LOSS_SLOTS), dtype=torch.float32, device=p0.device)
+            setattr(self, which + "_pbuf", pbuf)
+            setattr(self, which + "_vbuf", vbuf)
+            setattr(self, which + "params", pbuf[:n])           # what the engine reads: the first n floats
+            setattr(self, which + "v", vbuf[:n])
+            setattr(self, which + "grad", grad[:n + LOSS_SLOTS] if not sharded else grad)
+            if sharded:
+                setattr(self, which + "_gshard", torch.zeros(per, dtype=torch.float32, device=p0.device))
+                setattr(self, which + "_pshard", torch.zeros(per, dtype=torch.float32, device=p0.device))
         self.t = 0                      # shared optimizer.iterations
         self.base_seed = int(base_seed)
         self.calls = 0
@@ -45,6 +79,7 @@ class WGANGPTrainer:
         self.comm = torch.cuda.Stream(device=self.gparams.device) if self.overlap else None
         self.d_ready = None             # events recorded on the communication stream behind the last critic / generator update
         self.g_ready = None
+        self._native_collectives = None
 
     # every stochastic draw inside a step (dropout masks, alpha) is keyed by (base_seed, call index, rank)
     def _next_seed(self):
@@ -60,54 +95,133 @@ class WGANGPTrainer:
             import torch.distributed as dist
             dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=self.pg)
 
-    def _update(self, params, grad, v):
-        """exchange + optimizer half of a train_on_batch call: ONE all-reduce of the flat gradient slab (losses in its
-        tail), then the fused Adam kernel with 1/world folded in.  Returns [total, valid, fake, gp, nonfinite] averaged
-        over ranks.  Runs on the current stream."""
-        self._allreduce(grad)
-        self.t += 1
-        self.eng.adam(params, grad, v, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
-        tail = grad[-LOSS_SLOTS:-LOSS_SLOTS + 5]
-        return tail if self.world == 1 else tail / self.world      # (a view at world 1: no extra kernel on the step path)
+    # ---- collectives of the sharded exchange.  RCCL (backend "nccl") has both natively; gloo -- only used to rehearse the
+    # data-parallel path on CPU or on one GPU -- has neither for device tensors, so there the same data movement is spelled
+    # with what it has: all-reduce + keep the own shard, and one broadcast per shard.
+    def _native(self):
+        if self._native_collectives is None:
+            import torch.distributed as dist
+            self._native_collectives = dist.get_backend(self.pg) == "nccl"
+        return self._native_collectives
 
-    def _update_overlapped(self, params, grad, v, which):
+    def _global_rank(self, r):
+        import torch.distributed as dist
+        return r if self.pg is None or self.pg is dist.group.WORLD else dist.get_global_rank(self.pg, r)
+
+    def _reduce_scatter(self, out, inp):
+        import torch.distributed as dist
+        if self.comm_hook is not None:
+            self.comm_hook(inp)
+        if self._native():
+            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=self.pg)
+            per = out.numel()
+            out.copy_(inp[self.rank * per:(self.rank + 1) * per])
+
+    def _all_gather(self, out, shard):
+        import torch.distributed as dist
+        if self._native():
+            dist.all_gather_into_tensor(out, shard, group=self.pg)
+        else:
+            per = shard.numel()
+            out[self.rank * per:(self.rank + 1) * per].copy_(shard)
+            for r in range(self.world):
+                dist.broadcast(out[r * per:(r + 1) * per], src=self._global_rank(r), group=self.pg)
+
+    def _update(self, which):
+        """exchange + optimizer half of a train_on_batch call for network `which` ("d" / "g").  Returns [total, valid, fake,
+        gp, nonfinite] averaged over ranks.  Runs on the current stream."""
+        params, grad, v = getattr(self, which + "params"), getattr(self, which + "grad"), getattr(self, which + "v")
+        n, per, P = self._pad[which]
+        if self.exchange[which] == "allreduce":
+            # ONE all-reduce of the flat gradient slab (losses in its tail), then the fused Adam kernel with 1/world folded in
+            self._allreduce(grad)
+            self.t += 1
+            self.eng.adam(params, grad, v, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
+            tail = grad[n:n + 5]
+            return tail if self.world == 1 else tail / self.world      # (a view at world 1: no extra kernel on the step path)
+        pbuf, vbuf = getattr(self, which + "_pbuf"), getattr(self, which + "_vbuf")
+        gsh, psh = getattr(self, which + "_gshard"), getattr(self, which + "_pshard")
+        self._reduce_scatter(gsh, grad[:P])                # this rank's 1/world of the summed slab (loss tail included)
+        self.t += 1
+        lo = self.rank * per
+        hi = min(lo + per, n)
+        if hi > lo:                                        # Adam on the owned parameters only
+            self.eng.adam(pbuf[lo:hi], gsh[:hi - lo], vbuf[lo:hi], self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
+        a, b = max(lo, n), min(lo + per, n + LOSS_SLOTS)   # the part of the loss tail that fell into this shard ...
+        if b > a:
+            pbuf[a:b].copy_(gsh[a - lo:b - lo])            # ... rides behind the weights in the all-gather
+        psh.copy_(pbuf[lo:lo + per])
+        self._all_gather(pbuf[:P], psh)                    # every rank: the updated weights + the loss sums
+        return pbuf[n:n + 5] / self.world
+
+    def _update_overlapped(self, which):
+        params = getattr(self, which + "params")
         cur = torch.cuda.current_stream(params.device)
         done = torch.cuda.Event()
         done.record(cur)                               # the gradient slab is complete
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(done)
-            losses = self._update(params, grad, v)
+            losses = self._update(which)
             ready = torch.cuda.Event()
             ready.record(self.comm)
         losses.record_stream(cur)
-        setattr(self, which, ready)
+        setattr(self, which + "_ready", ready)
         return losses
+
+    def reduced_grad(self, which):
+        """The summed gradient slab of the last update of network `which` times 1/world -- what Adam consumed -- as one
+        tensor of at least n floats on every rank (tests).  Sharded exchange: gathered from the owners (a collective)."""
+        n, per, P = self._pad[which]
+        grad = getattr(self, which + "grad")
+        self.join()
+        if self.exchange[which] == "allreduce":
+            return grad / self.world
+        full = torch.empty(P, dtype=torch.float32, device=grad.device)
+        self._all_gather(full, getattr(self, which + "_gshard"))
+        return full / self.world
+
+    def sync_state(self):
+        """Sharded exchange: a rank keeps the Adam second moments current only for the parameters it owns; this gathers the
+        slabs so that every rank holds all of them (checkpoints, tests).  A collective: call it on every rank."""
+        self.join()
+        for which in ("g", "d"):
+            if self.exchange[which] == "sharded":
+                n, per, P = self._pad[which]
+                vbuf, psh = getattr(self, which + "_vbuf"), getattr(self, which + "_pshard")
+                psh.copy_(vbuf[self.rank * per:(self.rank + 1) * per])
+                self._all_gather(vbuf[:P], psh)
+
+    def _slab(self, which):
+        """the gradient slab the engine writes: n gradients + 8 loss slots (the first n + 8 floats of the padded buffer)"""
+        return getattr(self, which + "grad")[:self._pad[which][0] + LOSS_SLOTS]
 
     def critic_step(self, x_real, cond, z, seed=None):
         """critic_model.train_on_batch([X_real, cond_real, latent], [valid, fake, dummy]) (reference :472).
         Returns the device tensor [total, valid, fake, gp, nonfinite] averaged over ranks."""
         seed = self._next_seed() if seed is None else seed
         if not self.overlap:
-            self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self.dgrad)
-            return self._update(self.dparams, self.dgrad, self.dv)
+            self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self._slab("d"))
+            return self._update("d")
         cur = torch.cuda.current_stream(self.dparams.device)
         if self.g_ready is not None:
             cur.wait_event(self.g_ready)               # the generator forward reads the generator weights at once
         # critic weights, their Adam state and the gradient slab are touched only behind the wait for d_ready
-        self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self.dgrad, critic_ready=self.d_ready)
-        return self._update_overlapped(self.dparams, self.dgrad, self.dv, "d_ready")
+        self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self._slab("d"), critic_ready=self.d_ready)
+        return self._update_overlapped("d")
 
     def gen_step(self, z, cond, seed=None):
         """generator_model.train_on_batch([latent, cond], valid) (reference :482)."""
         seed = self._next_seed() if seed is None else seed
         if not self.overlap:
-            self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self.ggrad)
-            return self._update(self.gparams, self.ggrad, self.gv)
+            self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self._slab("g"))
+            return self._update("g")
         cur = torch.cuda.current_stream(self.gparams.device)
         if self.g_ready is not None:
             cur.wait_event(self.g_ready)
-        self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self.ggrad, critic_ready=self.d_ready)
-        return self._update_overlapped(self.gparams, self.ggrad, self.gv, "g_ready")
+        self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self._slab("g"), critic_ready=self.d_ready)
+        return self._update_overlapped("g")
 
     def join(self):
         """Make the current stream wait for the updates still running on the communication stream (no host sync)."""
@@ -154,7 +268,7 @@ class WGANGPTrainer:
         shared Adam iteration counter, the step-RNG position (base_seed, calls) and numpy's global RNG state (the
         reference draws batches and latents from it, T:150,179).  One .npz; rank 0 writes (replicas are identical)."""
         st = np.random.get_state()
-        self.join()
+        self.sync_state()                   # (sharded exchange: gather the second-moment slabs; a collective)
         np.savez(path, format=np.array("rdgan-checkpoint-1"), ndomain=self.eng.ndomain,
                  n_cond_channels=getattr(self.eng, "n_cond_channels", 1),
                  gparams=self.gparams.cpu().numpy(), dparams=self.dparams.cpu().numpy(),

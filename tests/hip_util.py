@@ -43,3 +43,53 @@ def hip_gates(eng, B):
     g = [eng.debug_activation(i, shp).cpu() > 0 for i, shp in enumerate(gshape)]
     d = [eng.debug_activation(4 + li, (B,) + tuple(geo[li][1]) + (chans[li],)).cpu() > 0 for li in range(4)]
     return g, d
+
+
+def hip_critic_gates(eng, B):
+    """The same for the engine's last CRITIC step: the four critic layers over the 3B batch [real; fake; interpolated].
+    Needs the option "keep_gates" set before the step (the penalty's second sweep overwrites the interpolated third of the
+    activations in place; the option keeps a copy)."""
+    from oracle import rdgan_np as onp
+    geo = onp.critic_geometry(eng.ndomain)
+    chans = (64, 128, 256, 256)
+    return [eng.debug_activation(4 + li, (3 * B,) + tuple(geo[li][1]) + (chans[li],)).cpu() > 0 for li in range(4)]
+
+
+# how far from a LeakyReLU kink (in RMS of the layer's inputs) the engine's slope decision may differ from the fp64 oracle's,
+# and for what share of a layer: fp32 rounding of sums of ~1e3..1e4 terms; bf16 storage: every stored tensor rounded to 2^-9
+GATE_TOL = {"f32": dict(max_margin=2e-4, max_fraction=1e-4), "bf16": dict(max_margin=0.15, max_fraction=3e-2)}
+
+
+def gen_step_on_engine_branch(eng, ds, gs, d, g, z, cond, seed, mode="f32"):
+    """Generator-step gradient slab of the engine and the fp64 oracle's (loss, grads) on the LeakyReLU branch the engine
+    took, after checking that the engine's branch differs from the oracle's own only at the kinks."""
+    from oracle import rdgan_torch as ot
+    B = z.shape[0]
+    slab = eng.gen_grad(ds, gs, dev(z), dev(cond), seed).cpu().numpy()
+    gates = hip_gates(eng, B)
+    t64 = lambda arrs: [torch.from_numpy(a).double() for a in arrs]
+    loss, grads, (gh, dh) = ot.gen_step_grads(t64(d), t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(),
+                                              seed, gates=gates, return_intermediates=True)
+    ot.check_gates(gates[0], gh, None, **GATE_TOL[mode])
+    ot.check_gates(gates[1], dh, ot.critic_masks(seed, B, eng.ndomain, torch.float64), **GATE_TOL[mode])
+    return slab, loss, grads
+
+
+def critic_step_on_engine_branch(eng, ds, gs, d, g, x, cond, z, seed, mode="f32", fake=None, alpha_offset=0):
+    """The same for the critic step (gradient penalty double backward included): needs "keep_gates"; `fake` = the generator
+    output the engine fed its critic (a constant of this step), for runs whose forward pass is not fp32-exact."""
+    from oracle import rdgan_torch as ot
+    B = x.shape[0]
+    eng.set_option("keep_gates", 1)
+    try:
+        slab = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), seed).cpu().numpy()
+        gates = hip_critic_gates(eng, B)
+    finally:
+        eng.set_option("keep_gates", 0)
+    t64 = lambda arrs: [torch.from_numpy(a).double() for a in arrs]
+    losses, grads, dh = ot.critic_step_grads(t64(d), t64(g), torch.from_numpy(x).double(), torch.from_numpy(cond).double(),
+                                             torch.from_numpy(z).double(), seed, alpha_offset=alpha_offset, gates=gates,
+                                             fake=None if fake is None else torch.from_numpy(np.asarray(fake)).double(),
+                                             return_intermediates=True)
+    ot.check_gates(gates, dh, ot.critic_masks(seed, 3 * B, eng.ndomain, torch.float64), **GATE_TOL[mode])
+    return slab, losses, grads

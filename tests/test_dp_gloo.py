@@ -55,7 +55,7 @@ def test_two_ranks_identical_shards_equal_single_process(tmp_path):
     assert not torch.equal(gp, torch.from_numpy(np.zeros(1, np.float32)).expand_as(gp))
 
 
-def _worker_shards(rank, world, port, out_dir):
+def _worker_shards(rank, world, port, out_dir, exchange=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -63,7 +63,8 @@ def _worker_shards(rank, world, port, out_dir):
     from tests import dp_case
     from tests.fake_engine import FakeEngine
     torch.set_num_threads(3)
-    res = dp_case.run_iteration(FakeEngine(dp_case.NDOMAIN, dtype=torch.float64), world, rank, dist.group.WORLD)
+    res = dp_case.run_iteration(FakeEngine(dp_case.NDOMAIN, dtype=torch.float64), world, rank, dist.group.WORLD,
+                                exchange=exchange)
     torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -96,6 +97,58 @@ def test_two_ranks_different_shards_equal_the_global_batch(tmp_path):
     assert float((r0["dparams"] - one["dparams"]).abs().max()) <= 2.1e-4
     assert float((r0["dparams"] - one["dparams"]).abs().mean()) < 1e-8
     assert float((r0["gparams"] - one["gparams"]).abs().mean()) < 1e-8
+
+
+def test_sharded_exchange_equals_the_allreduce_exchange(tmp_path):
+    """WGANGPTrainer(exchange="sharded"): reduce-scatter of the gradient slab, Adam on the owned 1/world, all-gather of the
+    updated weights with the loss sums riding behind them (the exchange meant for the 837 MB generator slab of ndomain 64).
+    World 2 over gloo with different shards: against the all-reduce exchange of the same run the summed gradients, the
+    reported losses, the updated weights and the Adam second moments (gathered from their owners) are identical -- at world
+    2 there is only one summation order -- and the replicas are bit-identical."""
+    runs = {}
+    for i, ex in enumerate(("sharded", "allreduce")):
+        out = tmp_path / ex
+        out.mkdir()
+        port = 33500 + (os.getpid() % 2000) + i
+        mp.spawn(_worker_shards, args=(2, port, str(out), ex), nprocs=2, join=True)
+        r0, r1 = torch.load(out / "rank0.pt"), torch.load(out / "rank1.pt")
+        assert r0["exchange"] == {"g": ex, "d": ex}
+        for k in ("dgrad", "ggrad", "dl", "gl", "dparams", "gparams", "dv", "gv"):
+            assert torch.equal(r0[k], r1[k]), (ex, k)      # replicas bit-identical
+        runs[ex] = r0
+    a, b = runs["sharded"], runs["allreduce"]
+    nd_, ng_ = a["dparams"].numel(), a["gparams"].numel()
+    assert torch.equal(a["dgrad"][:nd_], b["dgrad"][:nd_]) and torch.equal(a["ggrad"][:ng_], b["ggrad"][:ng_])
+    for k in ("dl", "gl", "dparams", "gparams", "dv", "gv"):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["dv"].abs().max()) > 0 and float(a["gv"].abs().max()) > 0
+    assert float(a["dl"][:4].abs().max()) > 0
+
+
+def test_exchange_defaults_by_slab_size():
+    """None / "auto": only a slab of at least SHARD_THRESHOLD_BYTES is sharded (the generator of ndomain 64), and never at
+    world 1; padded shards are whole float4s and cover the 8 loss slots"""
+    from pr_disagg_radar_gan_amd import trainer as T
+    from pr_disagg_radar_gan_amd import weights as W
+    from tests.fake_engine import FakeEngine
+    rng = np.random.default_rng(0)
+    g, d = W.init_generator(rng, 16), W.init_critic(rng, 16)
+    tr = T.WGANGPTrainer(FakeEngine(16), g, d, world_size=8, rank=3)
+    assert tr.exchange == {"g": "allreduce", "d": "allreduce"}
+    tr = T.WGANGPTrainer(FakeEngine(16), g, d, world_size=1, exchange="sharded")
+    assert tr.exchange == {"g": "allreduce", "d": "allreduce"}
+    old = T.SHARD_THRESHOLD_BYTES
+    try:
+        T.SHARD_THRESHOLD_BYTES = 12 << 20            # between the critic (11.5 MB) and the generator (15.9 MB) of ndomain 16
+        tr = T.WGANGPTrainer(FakeEngine(16), g, d, world_size=8, rank=3)
+        assert tr.exchange == {"g": "sharded", "d": "allreduce"}
+        n, per, P = tr._pad["g"]
+        assert per % 4 == 0 and P == 8 * per and P >= n + T.LOSS_SLOTS and tr.g_pbuf.numel() == P
+        assert tr.gparams.numel() == n and tr.gparams.data_ptr() == tr.g_pbuf.data_ptr()
+    finally:
+        T.SHARD_THRESHOLD_BYTES = old
+    with pytest.raises(ValueError):
+        T.WGANGPTrainer(FakeEngine(16), g, d, exchange="ring")
 
 
 def test_shard_slice():

@@ -44,7 +44,7 @@ def test_hip_matches_golden():
         np.testing.assert_allclose(cs[eng.n_critic:eng.n_critic + 4], GOLD["critic_losses"], rtol=2e-4, atol=1e-6)
         gsl = eng.gen_grad(ds, gs, dev(z), dev(cond), seed).cpu().numpy()
         np.testing.assert_allclose(gsl[eng.n_gen], float(GOLD["gen_loss"]), rtol=2e-4, atol=1e-6)
-        # gradient digests; a LeakyReLU kink flip (see test_hip_step._parity_over_batches) moves these by ~1e-3
+        # gradient digests; a LeakyReLU kink flip (see the note above test_hip_step.test_critic_step_grads_parity) moves these by ~1e-3
         tol = 2e-2 if float(GOLD["kink_margin"]) < 2e-6 else 2e-4
         for slab, shapes, tag in ((cs, eng.critic_shapes, "cgrad"), (gsl, eng.gen_shapes, "ggrad")):
             off = 0

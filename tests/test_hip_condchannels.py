@@ -9,8 +9,8 @@ import torch
 from oracle import rdgan_torch as ot
 from pr_disagg_radar_gan_amd import Engine
 from pr_disagg_radar_gan_amd import weights as W
-from tests.hip_util import dev, rel_err
-from tests.test_hip_step import TIGHT, _grad_errors, _parity_over_batches, _t64
+from tests.hip_util import dev, rel_err, gen_step_on_engine_branch, critic_step_on_engine_branch
+from tests.test_hip_step import TIGHT, _grad_errors, _t64
 
 pytestmark = pytest.mark.gpu
 
@@ -76,37 +76,56 @@ def test_critic_forward(eng, seed):
 
 
 def test_critic_step_grads(eng):
+    """one seeded batch against the fp64 oracle on the engine's own LeakyReLU branch (tests/test_hip_step.py)"""
     nc = eng.n_cond_channels
     g, d = _params(16, nc, 23)
     B, seed = 3, 1234
-
-    def run_case(data_seed):
-        x, cond, z = _batch(B, 16, nc, data_seed)
-        losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
-                                             torch.from_numpy(cond).double(), torch.from_numpy(z).double(), seed)
-        slab = eng.critic_grad(eng.to_slab(d), eng.to_slab(g), dev(x), dev(cond), dev(z), seed).cpu().numpy()
-        n = eng.n_critic
-        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
-        assert slab[n + 4] == 0.0
-        return _grad_errors(slab[:n], grads, eng.critic_shapes)
-
-    _parity_over_batches(run_case)
+    x, cond, z = _batch(B, 16, nc, 100)
+    slab, losses, grads = critic_step_on_engine_branch(eng, eng.to_slab(d), eng.to_slab(g), d, g, x, cond, z, seed)
+    n = eng.n_critic
+    np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+    assert slab[n + 4] == 0.0
+    errs = _grad_errors(slab[:n], grads, eng.critic_shapes)
+    assert max(errs.values()) < TIGHT, errs
 
 
 def test_gen_step_grads(eng):
     nc = eng.n_cond_channels
     g, d = _params(16, nc, 24)
     B, seed = 2, 4321
+    x, cond, z = _batch(B, 16, nc, 100)
+    slab, loss, grads = gen_step_on_engine_branch(eng, eng.to_slab(d), eng.to_slab(g), d, g, z, cond, seed)
+    n = eng.n_gen
+    np.testing.assert_allclose(slab[n], float(loss), rtol=2e-4, atol=1e-6)
+    errs = _grad_errors(slab[:n], grads, eng.gen_shapes)
+    assert max(errs.values()) < TIGHT, errs
 
-    def run_case(data_seed):
-        x, cond, z = _batch(B, 16, nc, data_seed)
-        loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), seed)
-        slab = eng.gen_grad(eng.to_slab(d), eng.to_slab(g), dev(z), dev(cond), seed).cpu().numpy()
-        n = eng.n_gen
-        np.testing.assert_allclose(slab[n], float(loss), rtol=2e-4, atol=1e-6)
-        return _grad_errors(slab[:n], grads, eng.gen_shapes)
 
-    _parity_over_batches(run_case)
+def test_bf16_storage_step_grads(eng):
+    """The bf16 storage mode with extra condition channels: the first critic layer then runs through the tiled kernels
+    (k_conv_gemm<..., BK = 8, OUT16> forward / second sweep on 4 floats per voxel, k_wgrad_gemm<..., DY16> weight gradient)
+    instead of the K = 64 edge kernels.  Both step gradients against the fp64 oracle on the run's own branch, at the
+    tolerances of tests/test_hip_bf16.py."""
+    from tests.test_hip_bf16 import GRAD_TOL
+    nc = eng.n_cond_channels
+    g, d = _params(16, nc, 26)
+    B = 5
+    x, cond, z = _batch(B, 16, nc, 101)
+    gs, ds = eng.to_slab(g), eng.to_slab(d)
+    eng.set_option("bf16", 1)
+    try:
+        fake = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
+        slab, losses, grads = critic_step_on_engine_branch(eng, ds, gs, d, g, x, cond, z, 77, mode="bf16", fake=fake)
+        n = eng.n_critic
+        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=5e-2, atol=5e-3)
+        errs = _grad_errors(slab[:n], grads, eng.critic_shapes)
+        print(f"nc {nc} bf16 critic-step grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
+        assert max(errs.values()) < GRAD_TOL, errs
+        slab, loss, grads = gen_step_on_engine_branch(eng, ds, gs, d, g, z, cond, 78, mode="bf16")
+        errs = _grad_errors(slab[:eng.n_gen], grads, eng.gen_shapes)
+        assert max(errs.values()) < GRAD_TOL, errs
+    finally:
+        eng.set_option("bf16", 0)
 
 
 def test_cond_shape_checked(eng):

@@ -8,7 +8,7 @@ from oracle import rdgan_np as onp
 from oracle import rdgan_torch as ot
 from pr_disagg_radar_gan_amd import Engine
 from pr_disagg_radar_gan_amd import weights as W
-from tests.hip_util import dev, rel_err, hip_gates
+from tests.hip_util import dev, rel_err, hip_gates, gen_step_on_engine_branch, critic_step_on_engine_branch
 
 pytestmark = pytest.mark.gpu
 
@@ -93,46 +93,28 @@ def _grad_errors(got, ref_list, shapes):
     return errs
 
 
-TIGHT, LOOSE = 5e-5, 5e-2
+TIGHT = 5e-5      # per-tensor gradient error relative to the tensor's largest entry, observed 1e-7 ... 5e-6
 
 
-def _parity_over_batches(run_case):
-    """The loss is only piecewise smooth: a LeakyReLU input within fp32 rounding of zero takes
-    slope 1 in one precision and 0.2 in the other (the fp32 torch oracle shows the same ~1e-3
-    jumps against the fp64 one; see oracle.rdgan_torch.kink_margin).  With ~2e6 activations per
-    step that happens for a fraction of random batches.  So: every batch must agree loosely
-    (a real indexing/algebra bug gives O(1) errors), and the first batch without such a flip must
-    agree to TIGHT.  HIP results are run-to-run deterministic (no atomics), so this is not flaky."""
-    history = []
-    for data_seed in range(100, 106):
-        errs = run_case(data_seed)
-        worst = max(errs.values())
-        history.append((data_seed, float(f"{worst:.2e}")))
-        assert worst < LOOSE, (data_seed, errs)
-        if worst < TIGHT:
-            print("grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()}, "history", history)
-            return
-    raise AssertionError(f"no batch reached the tight tolerance: {history}")
-
-
+# Gradient parity.  The loss is only piecewise smooth: a LeakyReLU input within fp32 rounding of zero takes slope 1 in one
+# precision and 0.2 in the other, which moves gradients by ~1e-3 (the fp32 torch oracle shows the same jumps against the fp64
+# one).  Every gradient test therefore lets the fp64 oracle differentiate the branch the engine took -- the engine's slope
+# pattern, read back through rdgan_debug_activation (critic steps: option "keep_gates") and first checked against the oracle's
+# own decisions away from the kinks (tests/hip_util.py) -- so ONE seeded batch is compared, tightly.
 @pytest.mark.parametrize("B,seed", [(2, 1234), (3, 0), (4, 99)])
 @pytest.mark.parametrize("ws", [1, 2])
 def test_critic_step_grads_parity(eng16, B, seed, ws):
     eng16.set_option("collapse", 1)
     eng16.set_option("wave_specialized", ws)
     g, d = _params(16, 13)
-
-    def run_case(data_seed):
-        x, cond, z = ot.synthetic_batch(B, 16, data_seed)
-        losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
-                                             torch.from_numpy(cond).double(), torch.from_numpy(z).double(), seed)
-        slab = eng16.critic_grad(eng16.to_slab(d), eng16.to_slab(g), dev(x), dev(cond), dev(z), seed).cpu().numpy()
-        n = eng16.n_critic
-        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
-        assert slab[n + 4] == 0.0
-        return _grad_errors(slab[:n], grads, eng16.critic_shapes)
-
-    _parity_over_batches(run_case)
+    x, cond, z = ot.synthetic_batch(B, 16, 100)
+    slab, losses, grads = critic_step_on_engine_branch(eng16, eng16.to_slab(d), eng16.to_slab(g), d, g, x, cond, z, seed)
+    n = eng16.n_critic
+    np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+    assert slab[n + 4] == 0.0
+    errs = _grad_errors(slab[:n], grads, eng16.critic_shapes)
+    print("critic grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
+    assert max(errs.values()) < TIGHT, errs
 
 
 @pytest.mark.parametrize("collapse,ws,fast", [(1, 1, 1), (0, 1, 0), (1, 2, 1), (1, 1, 0), (1, 2, 0)])
@@ -144,16 +126,13 @@ def test_gen_step_grads_parity(eng16, B, seed, collapse, ws, fast):
     eng16.set_option("fast_fwd", (fast + B) % 2)   # every forward/backward combination occurs
     eng16.set_option("g9_direct", (B + ws) % 2)    # last conv's backward: direct from the dlogits / im2col + column GEMMs
     g, d = _params(16, 14)
-
-    def run_case(data_seed):
-        x, cond, z = ot.synthetic_batch(B, 16, data_seed)
-        loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), seed)
-        slab = eng16.gen_grad(eng16.to_slab(d), eng16.to_slab(g), dev(z), dev(cond), seed).cpu().numpy()
-        n = eng16.n_gen
-        np.testing.assert_allclose(slab[n], loss.item(), rtol=2e-4, atol=1e-6)
-        return _grad_errors(slab[:n], grads, eng16.gen_shapes)
-
-    _parity_over_batches(run_case)
+    x, cond, z = ot.synthetic_batch(B, 16, 100)
+    slab, loss, grads = gen_step_on_engine_branch(eng16, eng16.to_slab(d), eng16.to_slab(g), d, g, z, cond, seed)
+    n = eng16.n_gen
+    np.testing.assert_allclose(slab[n], loss.item(), rtol=2e-4, atol=1e-6)
+    errs = _grad_errors(slab[:n], grads, eng16.gen_shapes)
+    print("gen grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
+    assert max(errs.values()) < TIGHT, errs
 
 
 def test_adam_parity(eng16):
@@ -214,7 +193,7 @@ def test_full_size_properties():
         gb = eng.gen_grad(ds, gs, dev(z[:128]), dev(cond[:128]), 0).cpu().numpy()
         n = eng.n_gen
         # the two runs pick different split-K / tile configurations (different batch), so their fp32 sums round
-        # differently and a few of the ~1e8 LeakyReLU inputs flip slope (see _parity_over_batches): 2e-3, not 1e-6
+        # differently and a few of the ~1e8 LeakyReLU inputs flip slope (see the note above test_critic_step_grads_parity): 2e-3, not 1e-6
         assert rel_err(ga[:n], gb[:n]) < 2e-3
         np.testing.assert_allclose(ga[n], gb[n], rtol=1e-5)
         sl = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 31337).cpu().numpy()
@@ -237,22 +216,15 @@ def test_forced_split_k_in_producer_consumer_kernels(eng16):
             out = eng16.gen_forward(eng16.to_slab(g), dev(z), dev(cond)).cpu().numpy()
             np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-7)
 
-            def run_critic(data_seed):
-                x, cond, z = ot.synthetic_batch(3, 16, data_seed)
-                losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
-                                                     torch.from_numpy(cond).double(), torch.from_numpy(z).double(), 5)
-                slab = eng16.critic_grad(eng16.to_slab(d), eng16.to_slab(g), dev(x), dev(cond), dev(z), 5).cpu().numpy()
-                np.testing.assert_allclose(slab[eng16.n_critic:eng16.n_critic + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
-                return _grad_errors(slab[:eng16.n_critic], grads, eng16.critic_shapes)
-
-            def run_gen(data_seed):
-                x, cond, z = ot.synthetic_batch(2, 16, data_seed)
-                loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 6)
-                slab = eng16.gen_grad(eng16.to_slab(d), eng16.to_slab(g), dev(z), dev(cond), 6).cpu().numpy()
-                return _grad_errors(slab[:eng16.n_gen], grads, eng16.gen_shapes)
-
-            _parity_over_batches(run_critic)
-            _parity_over_batches(run_gen)
+            x, cond, z = ot.synthetic_batch(3, 16, 100)
+            slab, losses, grads = critic_step_on_engine_branch(eng16, eng16.to_slab(d), eng16.to_slab(g), d, g, x, cond, z, 5)
+            np.testing.assert_allclose(slab[eng16.n_critic:eng16.n_critic + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+            errs = _grad_errors(slab[:eng16.n_critic], grads, eng16.critic_shapes)
+            assert max(errs.values()) < TIGHT, (ks, errs)
+            x, cond, z = ot.synthetic_batch(2, 16, 101)
+            slab, loss, grads = gen_step_on_engine_branch(eng16, eng16.to_slab(d), eng16.to_slab(g), d, g, z, cond, 6)
+            errs = _grad_errors(slab[:eng16.n_gen], grads, eng16.gen_shapes)
+            assert max(errs.values()) < TIGHT, (ks, errs)
     finally:
         eng16.set_option("ws_ksplit", 1)
         eng16.set_option("wave_specialized", 1)
@@ -478,22 +450,14 @@ def test_odd_batches_default_options(B):
         if B > 9:
             return
 
-        def run_critic(data_seed):
-            x, cond, z = ot.synthetic_batch(B, 16, data_seed)
-            losses, grads = ot.critic_step_grads(_t64(d), _t64(g), torch.from_numpy(x).double(),
-                                                 torch.from_numpy(cond).double(), torch.from_numpy(z).double(), 11)
-            slab = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 11).cpu().numpy()
-            np.testing.assert_allclose(slab[eng.n_critic:eng.n_critic + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
-            return _grad_errors(slab[:eng.n_critic], grads, eng.critic_shapes)
-
-        def run_gen(data_seed):
-            x, cond, z = ot.synthetic_batch(B, 16, data_seed)
-            loss, grads = ot.gen_step_grads(_t64(d), _t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(), 12)
-            slab = eng.gen_grad(ds, gs, dev(z), dev(cond), 12).cpu().numpy()
-            return _grad_errors(slab[:eng.n_gen], grads, eng.gen_shapes)
-
-        _parity_over_batches(run_critic)
-        _parity_over_batches(run_gen)
+        x, cond, z = ot.synthetic_batch(B, 16, 100)
+        slab, losses, grads = critic_step_on_engine_branch(eng, ds, gs, d, g, x, cond, z, 11)
+        np.testing.assert_allclose(slab[eng.n_critic:eng.n_critic + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+        errs = _grad_errors(slab[:eng.n_critic], grads, eng.critic_shapes)
+        assert max(errs.values()) < TIGHT, errs
+        slab, loss, grads = gen_step_on_engine_branch(eng, ds, gs, d, g, z, cond, 12)
+        errs = _grad_errors(slab[:eng.n_gen], grads, eng.gen_shapes)
+        assert max(errs.values()) < TIGHT, errs
     finally:
         eng.close()
 
