@@ -54,12 +54,21 @@ def gconv3_flops(batch, nd, taps=4):
     return 2.0 * batch * 24 * nd * nd * taps * 128 * 64
 
 
-# HBM traffic of ONE launch of the dominant kernel, from separate rocprofv3 --pmc passes (scripts/gpu_profile_r02.sh ->
-# profiles/r02_hbm_traffic_{fp32,bf16}_bs256.csv): FETCH_SIZE x 2 (gfx950 counts half the bytes of wide streaming reads,
-# MI355X_MICROARCH.md) + WRITE_SIZE.  fp32 (difference part of block 3): 495.4 MB + 409.0 MB; algorithmic: E 109 MB + T 2 x 201 MB
-# read, 403 MB output + 6 MB 1/l2 written.  bf16 storage mode (collapsed block 3): 62.8 MB + 207.6 MB; algorithmic: h2 50 MB read,
-# 201 MB output + 6 MB 1/l2 written.  Not measurable inside this process, hence recorded constants (bs 256 only).
-DOMINANT_TRAFFIC_BYTES = {False: 495.36e6 + 408.95e6, True: 62.81e6 + 207.62e6}
+def dominant_traffic(bf16, nd, batch):
+    """HBM bytes of ONE launch of the dominant kernel from the PMC passes kept under profiles/ (FETCH_SIZE x 2 -- gfx950 counts
+    half the bytes of wide streaming reads, MI355X_MICROARCH.md -- plus WRITE_SIZE, separate `rocprofv3 --pmc` passes): read from
+    profiles/hbm_traffic_dominant.json, which scripts/summarize_profile.py writes from the counter CSVs of the newest profile
+    run (not measurable inside this process).  None when no entry matches this configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic_dominant.json")) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    for e in table.get("entries", []):
+        if (bool(e.get("bf16")), e.get("ndomain"), e.get("batch")) == (bool(bf16), nd, batch):
+            return e.get("bytes_per_launch"), e.get("source")
+    return None, None
+
 
 # SURVEY 8d: FLOPs of one critic / generator step per sample in the reference's direct 27-tap form, by ndomain; prices
 # the measured iteration as "direct-equivalent" TFLOP/s
@@ -321,6 +330,29 @@ def main():
             classes[nm] = {"ms_per_iteration": round(ms / nprof, 4), "launches_per_iteration": n // nprof}
     eng.profile(0)
 
+    # per-launch table: HIP events around every GEMM launch of a few more iterations (outside the timed region)
+    launches = None
+    sync()
+    eng.profile_launches(True)
+    for k in range(nprof):
+        crit, gen = data[k % nbuf]
+        trainer.iteration_raw(crit, gen)
+    sync()
+    if rank == 0:
+        rows = eng.launch_table()
+        pk = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+        launches = []
+        for r in sorted(rows, key=lambda r: -r["ms"]):
+            n = max(r["launches"], 1)
+            # the fp32-pipe GEMMs of the bf16 storage mode (Dense, first critic layer, 64 -> 1 conv) are priced against the fp32 peak
+            peak_r = FP32_MFMA_PEAK_TFLOPS if (not bf16 or "bf16" not in r["kernel"] and "ws16" not in r["kernel"]) else pk
+            tf = r["gflop"] / max(r["ms"], 1e-9)
+            launches.append({"what": r["name"], "kind": r["kind"], "kernel": r["kernel"], "samples": r["batch"],
+                             "launches_per_iteration": round(r["launches"] / nprof, 2), "gflop_per_launch": round(r["gflop"] / n, 3),
+                             "ms_per_launch": round(r["ms"] / n, 4), "ms_per_iteration": round(r["ms"] / nprof, 4),
+                             "tflops": round(tf, 1), "peak": peak_r, "frac": round(tf / peak_r, 4)})
+    eng.profile_launches(False)
+
     if rank == 0:
         value = world * B * args.steps / dt
         avg_ms = kern_ms / max(kern_n, 1)
@@ -339,6 +371,7 @@ def main():
             gf = n_critic * DIRECT_GF_PER_SAMPLE[ND]["critic_step"] + DIRECT_GF_PER_SAMPLE[ND]["gen_step"]
             direct_equiv = gf * 1e9 * B / (med * 1e-3) / 1e12          # per GPU
         it_tflops = flops_iter / (med * 1e-3) / 1e12
+        traffic, traffic_src = dominant_traffic(bf16, ND, B) if taps == (8 if bf16 else 4) else (None, None)
         is_metric = (args.config, ND, B, n_critic, bf16, split3) == (2, 16, 256, 1, False, False)
         dtype = ("bf16 activations / gradients in HBM and bf16 MFMA operands, f32 accumulation, f32 master weights, "
                  "PixelNorm / softmax / penalty / Adam in f32") if bf16 else "f32"
@@ -377,8 +410,7 @@ def main():
                                                        "PixelNorm + LeakyReLU in the epilogue)"),
                          "achieved": None if achieved is None else round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
-                         "traffic": DOMINANT_TRAFFIC_BYTES[bf16] if (ND, B) == (16, 256) and taps == (8 if bf16 else 4) else None,
-                         "traffic_source": "profiles/r02_hbm_traffic_%s_bs256.csv (separate --pmc passes, bytes per launch)" % ("bf16" if bf16 else "fp32"),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(kern_n), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": gconv3_flops(B, ND, taps),
                          "iteration": {"executed_gflop": round(flops_iter / 1e9, 2), "tflops": round(it_tflops, 2),
@@ -387,7 +419,12 @@ def main():
                                                "(rdgan_flop_count) / median iteration time / the same MFMA peak; includes all "
                                                "elementwise kernels' time"},
                          "iteration_direct_equiv_tflops": None if direct_equiv is None else round(direct_equiv, 2),
-                         "kernel_classes": classes},
+                         "kernel_classes": classes,
+                         "launches": launches,
+                         "launches_note": "every GEMM launch of an iteration (HIP events on the launch stream, %d extra iterations outside "
+                                          "the timed region): algorithmic GFLOP of the form run / mean duration / the dense MFMA peak of "
+                                          "the launch's operand type; a split-K launch includes its finish kernel, a weight gradient "
+                                          "its partial-slab fold" % nprof},
         }
         out.update({
             "final_losses": {"d_loss": round(d_loss, 5), "g_loss": round(g_loss, 5)},

@@ -93,6 +93,19 @@ int rdgan_gen_grad_after(rdgan_handle* h, const float* critic_params, const floa
 int rdgan_adam(float* params, const float* grad, float* v, long n, int t, float lr, float beta2,
                float eps, float grad_scale, void* stream);
 
+/* Weight-form cache.  Every gradient / forward entry first derives "weight forms" from the parameter slabs it is given
+ * (generator: the transposed last kernel and the collapsed or shared-centre forms of the three block kernels, plus their bf16
+ * images in the storage mode; critic: transposed kernels, padded / bf16 images) -- weight-only kernels that are wasted work
+ * while a network is frozen: the generator across the n_critic critic steps of an iteration (T:468-476), the critic across
+ * the generator step and the critic step that follows it (T:482, next T:472).  The caller may vouch for the CONTENT of the
+ * slabs it passes: versions set here hold for the following calls, and a call whose (slab pointer, version, form options)
+ * equal those the forms in the workspace were built from skips the rebuild.  A version is any non-zero number the caller
+ * changes whenever it writes the slab (the trainer: a fresh number after every Adam update or checkpoint load); 0 = unknown,
+ * always rebuild (the default, and what a caller that cannot vouch passes).  Results are bit-identical either way.
+ * rdgan_form_builds: how many times each network's forms have been built by this handle (tests). */
+int rdgan_set_weight_versions(rdgan_handle* h, uint64_t gen_version, uint64_t critic_version);
+int rdgan_form_builds(const rdgan_handle* h, long* gen_builds, long* critic_builds);
+
 /* Parameter slab layout: fills offsets[0..10) / sizes with the element offset and size of
  * {kernel,bias} x 5 layers in Keras weight order; returns the number of tensors (10). */
 int rdgan_gen_param_layout(const rdgan_handle* h, long* offsets, long* sizes);
@@ -174,6 +187,20 @@ int rdgan_profile(rdgan_handle* h, unsigned tag_mask);
  * this handle has launched since the last reset -- the numerator of bench.py's whole-iteration roofline fraction. */
 int rdgan_flop_count(rdgan_handle* h, double* flops, int reset);
 int rdgan_profile_read(rdgan_handle* h, int tag, double* total_ms, long* launches);
+/* Per-launch table for bench.py's `roofline.launches`: with rdgan_profile_launches(h, 1) every GEMM launch (conv / input-gradient /
+ * weight-gradient plans and the dedicated first- and last-layer kernels) is bracketed by HIP events on its launch stream and
+ * recorded with its plan, kernel tile, batch and algorithmic FLOPs (2 * rows * taps * K * N of the form actually run; a launch
+ * with split K includes its finish kernel, a weight gradient its partial-slab fold).  rdgan_launch_table synchronises the
+ * device and returns one row per (plan, kind, batch, kernel): launches, summed GFLOP and summed milliseconds since the
+ * recording was switched on.  kind: 0 = forward-type GEMM over the plan, 1 = weight gradient, 2 = dedicated edge kernel. */
+typedef struct {
+  int plan, kind, batch, launches;
+  double gflop, ms;
+  char name[48];       /* what the plan computes, e.g. "gen block3 fwd difference part" */
+  char kernel[48];     /* kernel and tile, e.g. "k_conv_gemm_ws<256,64,TG4>" */
+} rdgan_launch_stat;
+int rdgan_profile_launches(rdgan_handle* h, int on);
+int rdgan_launch_table(rdgan_handle* h, rdgan_launch_stat* out, int cap, int* n_out);
 
 /* Input pipeline either side of the step (device-resident radar array data[n_days][24][ny][nx], fp32).
  * rdgan_data_gather: the tile gather + normalisation of generate_real_samples / generate_latent_points

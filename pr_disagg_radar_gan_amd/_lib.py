@@ -13,6 +13,12 @@ c_f32p = ctypes.c_void_p      # device pointers travel as integers
 c_stream = ctypes.c_void_p
 
 # every symbol include/rdgan.h declares: name -> (restype, argtypes)
+class LaunchStat(ctypes.Structure):
+    """rdgan_launch_stat (include/rdgan.h)"""
+    _fields_ = [("plan", ctypes.c_int), ("kind", ctypes.c_int), ("batch", ctypes.c_int), ("launches", ctypes.c_int),
+                ("gflop", ctypes.c_double), ("ms", ctypes.c_double), ("name", ctypes.c_char * 48), ("kernel", ctypes.c_char * 48)]
+
+
 SIGNATURES = {
     "rdgan_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "rdgan_destroy": (None, [ctypes.c_void_p]),
@@ -34,6 +40,8 @@ SIGNATURES = {
                                             ctypes.c_int, ctypes.c_void_p, c_stream]),
     "rdgan_adam": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_float, c_stream]),
+    "rdgan_set_weight_versions": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
+    "rdgan_form_builds": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "rdgan_gen_param_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "rdgan_critic_param_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]),
     "rdgan_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),
@@ -41,6 +49,8 @@ SIGNATURES = {
     "rdgan_flop_count": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "rdgan_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
                                           ctypes.POINTER(ctypes.c_long)]),
+    "rdgan_profile_launches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rdgan_launch_table": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LaunchStat), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "rdgan_data_gather": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p, c_stream]),
     "rdgan_data_valid_tiles": (ctypes.c_int, [c_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -345,6 +345,9 @@ enum {
   PL_F1BS, PL_F2BS, PL_F3BS, PL_F1BE, PL_F2BE, PL_F3BE, PL_F1FE, PL_F2FE, PL_F3FE, PL_COUNT
 };
 
+// one GEMM launch under rdgan_profile_launches: which plan, through which kernel, how many samples and algorithmic FLOPs
+struct RdLaunchRec { int plan, kind, batch; double flops; char kernel[48]; hipEvent_t e0, e1; };
+
 struct rdgan_handle {
   int nd, s, MB, NB;
   int nc, Cin, CP, ldp1;       // condition channels, critic input channels 1+nc, floats per input voxel, P1 columns
@@ -407,6 +410,14 @@ struct rdgan_handle {
   // test hook "keep_gates": the critic step's second sweep overwrites the x_hat third of h_l in place; with the option on, that
   // third is copied here first, so that rdgan_debug_activation can return the activations (= LeakyReLU / dropout pattern) of
   // all 3B samples of the last critic step.  Allocated when the option is set, never inside a step.
+  // Weight-form cache (rdgan_set_weight_versions): the forward forms of the generator (W9T, collapsed / shared-centre forms, their
+  // bf16 images) and the critic's forms (transposes, padded / bf16 images) are functions of the weights alone.  The caller may
+  // assert a content version for each slab; a call whose (pointer, version, form options) equal those the forms in the
+  // workspace were built from skips the weight-only kernels.  Version 0 = unknown: rebuild (the default).
+  uint64_t gver_in = 0, cver_in = 0;
+  const float* gcache_ptr = nullptr; uint64_t gcache_ver = 0; int gcache_cfg = -1;
+  const float* ccache_ptr = nullptr; uint64_t ccache_ver = 0; int ccache_cfg = -1;
+  long form_builds[2] = {0, 0};   // how many times the generator / critic forms were (re)built (tests)
   int keep_gates = 0;
   void* gate_keep[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int gate_keep_B = 0;            // samples held (0: the last call was not a critic step)
@@ -416,6 +427,11 @@ struct rdgan_handle {
   // kernels whose dynamic-LDS limit has been raised on THIS handle's device (hipFuncSetAttribute is per device; keeping the
   // record per handle rather than per process makes two handles on two devices, or on two threads, independent)
   std::unordered_set<const void*> lds_attr_done;
+  // per-launch profiling (rdgan_profile_launches / rdgan_launch_table): HIP events around every GEMM launch
+  int prof_launches = 0;
+  std::vector<RdLaunchRec> launch_recs;
+  size_t launch_used = 0;
+  char cur_kernel[48] = {0};      // tile name of the launch being issued (set by the launchers while prof_launches is on)
   // profiling
   double flops_acc = 0;           // algorithmic FLOPs (2 * rows * taps * K * N of the forms actually run) of every GEMM launched so far
   unsigned prof_mask = 0;
@@ -481,6 +497,30 @@ struct ProfScope {
   }
 };
 
+// plan index of a plan that lives in the handle's table (-1: a temporary plan of the op-level entry points)
+static int plan_index(const rdgan_handle* h, const RdPlan& hp) {
+  if (!h || h->plans.empty()) return -1;
+  const RdPlan* b = h->plans.data();
+  return (&hp >= b && &hp < b + h->plans.size()) ? (int)(&hp - b) : -1;
+}
+// kinds of a recorded launch
+enum { RD_KIND_CONV = 0, RD_KIND_WGRAD = 1, RD_KIND_EDGE = 2 };
+struct LaunchScope {
+  rdgan_handle* h; hipStream_t st; RdLaunchRec* r;
+  LaunchScope(rdgan_handle* h_, int plan, int kind, int batch, double flops, hipStream_t st_) : h(h_), st(st_), r(nullptr) {
+    if (h && h->prof_launches && h->launch_used < h->launch_recs.size()) {
+      r = &h->launch_recs[h->launch_used++];
+      r->plan = plan; r->kind = kind; r->batch = batch; r->flops = flops; r->kernel[0] = 0;
+      h->cur_kernel[0] = 0;
+      (void)hipEventRecord(r->e0, st);
+    }
+  }
+  ~LaunchScope() {
+    if (r) { (void)hipEventRecord(r->e1, st); memcpy(r->kernel, h->cur_kernel, sizeof(r->kernel)); }
+  }
+};
+#define RD_KNAME(h, ...) do { if ((h) && (h)->prof_launches) snprintf((h)->cur_kernel, sizeof((h)->cur_kernel), __VA_ARGS__); } while (0)
+
 // ------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------
@@ -510,6 +550,7 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
 #endif
   auto kern = k_conv_gemm<BM, BN, WM, WN, BK, PARTIAL, SHIFT, SRC16, OUT16>;
+  RD_KNAME(h, "k_conv_gemm<%d,%d,BK%d>", BM, BN, BK);
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
   long tm = plan_tiles(hp, B, BM);
   if (tm <= 0) return 0;
@@ -589,6 +630,7 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
     // "split3": the same launch on the bf16 matrix pipe from operands split three ways in registers (rdgan_gemm_ws.hip.h)
     if (h && h->split3) kern = k_conv_gemm_ws<BM, BN, WM, WN, TG, false, 0, false, true>;
   }
+  RD_KNAME(h, "k_conv_gemm_ws<%d,%d,TG%d%s%s>", BM, BN, TG, BF ? ",bf16" : "", res ? ",res" : "");
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
   constexpr int KCH = BF ? 64 : 32;                    // K elements per chunk
   if (BF && hp.SC % 64) return bad_arg(h, "conv: bf16 operands need a multiple of 64 channels per tap");
@@ -629,6 +671,7 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
 static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* W,
                        int ldw, float* dst, const RdEpi& epi, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
+  LaunchScope ls(h, plan_index(h, hp), RD_KIND_CONV, B, plan_flops(hp, B), st);
   if (h) h->flops_acc += plan_flops(hp, B);
   const bool partial = (hp.SC & 3) != 0, shift = hp.s_shift != 0;
   if (partial && shift) return bad_arg(h, "conv: SC % 4 != 0 with a folded upsample is not supported");
@@ -691,6 +734,7 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
 static int launch_conv_a16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* W,
                            int ldw, float* dst, const RdEpi& epi, hipStream_t st, int tag, bool src16, bool out16) {
   ProfScope ps(h, tag, st);
+  LaunchScope ls(h, plan_index(h, hp), RD_KIND_CONV, B, plan_flops(hp, B), st);
   if (h) h->flops_acc += plan_flops(hp, B);
   const bool partial = (hp.SC & 3) != 0;
   if (hp.s_shift) return bad_arg(h, "conv (bf16 storage): folded upsample is not supported");
@@ -716,6 +760,7 @@ static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>(
 static int launch_conv16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* w16,
                          float* dst, const RdEpi& epi, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
+  LaunchScope ls(h, plan_index(h, hp), RD_KIND_CONV, B, plan_flops(hp, B), st);
   if (h) h->flops_acc += plan_flops(hp, B);
   if (hp.s_shift || hp.SC % 64 || hp.N % 64) return bad_arg(h, "conv16: needs SC % 64 == 0, N % 64 == 0, no folded upsample");
   const float* s = (const float*)src16; const float* w = (const float*)w16;
@@ -785,6 +830,7 @@ static int launch_wgrad_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int 
                             float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(32 * BR + 32 * BN) * sizeof(float);
   auto kern = k_wgrad_gemm<BR, BN, PARTIAL, SHIFT, DY16>;
+  RD_KNAME(h, "k_wgrad_gemm<%d,%d>", BR, BN);
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
   dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, dp, B, src, dy, partial, T);
@@ -799,6 +845,7 @@ static int launch_wgrad_ws_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, i
   constexpr size_t lds_epi = (size_t)BR * BN * sizeof(float);
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   auto kern = k_wgrad_gemm_ws<BR, BN>;
+  RD_KNAME(h, "k_wgrad_gemm_ws<%d,%d>", BR, BN);
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
   dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dp, B, src, dy, partial, T);
@@ -810,6 +857,7 @@ static int launch_wgrad_ws_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, i
 static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const float* src, const float* dy,
                         float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag, bool dy16 = false) {
   ProfScope ps(h, tag, st);
+  LaunchScope ls(h, plan_index(h, hp), RD_KIND_WGRAD, B, plan_flops(hp, B), st);
   if (h) h->flops_acc += plan_flops(hp, B);
   if (hp.N % 64) return bad_arg(h, "wgrad: N % 64 != 0");
   for (int i = 1; i < hp.nphases; ++i)
@@ -866,6 +914,7 @@ static int launch_wgrad16_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, in
   constexpr size_t lds_epi = (size_t)BR * BN * sizeof(float);
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   auto kern = k_wgrad_gemm_ws16<BR, BN>;
+  RD_KNAME(h, "k_wgrad_gemm_ws16<%d,%d>", BR, BN);
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
   dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dp, B, (const unsigned short*)src16, (const unsigned short*)dy16, partial, T);
@@ -881,6 +930,7 @@ static bool wgrad16_ok(const RdPlan& hp, int B) {
 static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* dy16,
                           float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
+  LaunchScope ls(h, plan_index(h, hp), RD_KIND_WGRAD, B, plan_flops(hp, B), st);
   if (h) h->flops_acc += plan_flops(hp, B);
   if (!wgrad16_ok(hp, B)) return bad_arg(h, "wgrad16: needs SC % 64 == 0, N % 64 == 0, a 128- or 256-row tile, no folded upsample");
   for (int i = 1; i < hp.nphases; ++i)
@@ -1213,6 +1263,7 @@ extern "C" void rdgan_destroy(rdgan_handle* h) {
   if (!h) return;
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   for (hipEvent_t e2 : {h->ev_fork, h->ev_join, h->ev_cw, h->ev_g[1], h->ev_g[2], h->ev_g[3]}) if (e2) (void)hipEventDestroy(e2);
+  for (auto& r : h->launch_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (int t = 0; t < RDGAN_NUM_TAGS; ++t) {
     for (auto e : h->ev_start[t]) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop[t]) (void)hipEventDestroy(e);
@@ -1265,6 +1316,18 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   return bad_arg(h, "set_option: unknown option");
 }
 
+extern "C" int rdgan_set_weight_versions(rdgan_handle* h, uint64_t gen_version, uint64_t critic_version) {
+  if (!h) return -2;
+  h->gver_in = gen_version; h->cver_in = critic_version;
+  return 0;
+}
+extern "C" int rdgan_form_builds(const rdgan_handle* h, long* gen_builds, long* critic_builds) {
+  if (!h) return -2;
+  if (gen_builds) *gen_builds = h->form_builds[0];
+  if (critic_builds) *critic_builds = h->form_builds[1];
+  return 0;
+}
+
 extern "C" int rdgan_profile(rdgan_handle* h, unsigned tag_mask) {
   if (!h) return -2;
   h->prof_mask = tag_mask;
@@ -1280,6 +1343,55 @@ extern "C" int rdgan_profile(rdgan_handle* h, unsigned tag_mask) {
   }
   return 0;
 }
+static const char* const RD_PLAN_NAMES[PL_COUNT] = {
+  "gen dense", "gen block1 fwd (direct)", "gen block2 fwd (direct)", "gen block3 fwd (direct)", "gen conv 64->1 fwd", "gen block1 dgrad (direct)",
+  "gen block2 dgrad (direct)", "gen block3 dgrad (direct)", "gen conv 64->1 bwd",
+  "critic layer1", "critic layer2", "critic layer3", "critic layer4", "critic layer2 dgrad", "critic layer3 dgrad", "critic layer4 dgrad",
+  "critic layer1 dgrad (column GEMM)",
+  "gen block1 (collapsed)", "gen block2 (collapsed)", "gen block3 (collapsed)", "gen block1 dgrad (collapsed)", "gen block2 dgrad (collapsed)",
+  "gen block3 dgrad (collapsed)",
+  "gen block1 shared-centre E[s]", "gen block2 shared-centre E[s]", "gen block3 shared-centre E[s]",
+  "gen block1 shared-centre S", "gen block2 shared-centre S", "gen block3 shared-centre S",
+  "gen block1 shared-centre E[s+1]", "gen block2 shared-centre E[s+1]", "gen block3 shared-centre E[s+1]",
+  "gen block1 dgrad shared part", "gen block2 dgrad shared part", "gen block3 dgrad shared part",
+  "gen block1 dgrad difference part", "gen block2 dgrad difference part", "gen block3 dgrad difference part",
+  "gen block1 fwd difference part", "gen block2 fwd difference part", "gen block3 fwd difference part"};
+
+extern "C" int rdgan_profile_launches(rdgan_handle* h, int on) {
+  if (!h) return -2;
+  if (on && h->launch_recs.empty()) {
+    h->launch_recs.resize(8192);
+    for (auto& r : h->launch_recs) { RD_CHECK(h, hipEventCreate(&r.e0)); RD_CHECK(h, hipEventCreate(&r.e1)); }
+  }
+  h->prof_launches = on ? 1 : 0;
+  if (on) h->launch_used = 0;
+  return 0;
+}
+extern "C" int rdgan_launch_table(rdgan_handle* h, rdgan_launch_stat* out, int cap, int* n_out) {
+  if (!h || !out || cap < 1 || !n_out) return -2;
+  RD_CHECK(h, hipDeviceSynchronize());
+  int n = 0;
+  for (size_t i = 0; i < h->launch_used; ++i) {
+    const RdLaunchRec& r = h->launch_recs[i];
+    float ms = 0;
+    RD_CHECK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
+    int k = 0;
+    for (; k < n; ++k)
+      if (out[k].plan == r.plan && out[k].kind == r.kind && out[k].batch == r.batch && !strcmp(out[k].kernel, r.kernel)) break;
+    if (k == n) {
+      if (n == cap) continue;
+      memset(&out[n], 0, sizeof(out[n]));
+      out[n].plan = r.plan; out[n].kind = r.kind; out[n].batch = r.batch;
+      memcpy(out[n].kernel, r.kernel, sizeof(r.kernel));
+      snprintf(out[n].name, sizeof(out[n].name), "%s", r.plan >= 0 && r.plan < PL_COUNT ? RD_PLAN_NAMES[r.plan] : "op");
+      ++n;
+    }
+    out[k].launches += 1; out[k].gflop += r.flops * 1e-9; out[k].ms += ms;
+  }
+  *n_out = n;
+  return 0;
+}
+
 extern "C" int rdgan_flop_count(rdgan_handle* h, double* flops, int reset) {
   if (!h) return -2;
   if (flops) *flops = h->flops_acc;
@@ -1341,7 +1453,12 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   const int nd = h->nd;
   const bool a16 = h->a16 != 0;
   RD_TRY(a16_check(h));
-  // ---- weight forms (read only the weights)
+  // ---- weight forms (read only the weights): skipped when the caller vouches that the forms in the workspace were built from
+  // these very weights (same slab, same content version, same form options)
+  const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0);
+  const bool forms_cached = h->gver_in != 0 && gp == h->gcache_ptr && h->gver_in == h->gcache_ver && gcfg == h->gcache_cfg;
+  if (!forms_cached) {
+  h->form_builds[0]++;
   // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
   RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, ws));
   for (int l = 1; l <= 3; ++l) {
@@ -1358,6 +1475,8 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
     }
     if (ws != st) RD_CHECK(h, hipEventRecord(h->ev_g[l], ws));
+  }
+  h->gcache_ptr = gp; h->gcache_ver = h->gver_in; h->gcache_cfg = gcfg;
   }
   // ---- activations
   {
@@ -1377,7 +1496,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     // UpSampling3D + Conv3D + bias (T:330-331), then PixelNorm + LeakyReLU (T:332-333)
     const float* Wl = gp + h->goff[2 * l];
     int pl = PL_G1F + l - 1;
-    if (ws != st) RD_CHECK(h, hipStreamWaitEvent(st, h->ev_g[l], 0));       // this block's weight forms
+    if (ws != st && !forms_cached) RD_CHECK(h, hipStreamWaitEvent(st, h->ev_g[l], 0));       // this block's weight forms
     if (gen_block_fast(h, l, fast_fwd_on(h))) {
       // shared-centre form along the hour axis: T = S x[s] once per output plane pair, then the difference part
       const int* sd = h->gdim[l - 1];
@@ -1441,6 +1560,8 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     // fp32 storage: pipelined streaming kernel on 128-pixel tiles (rdgan_edge.hip.h), nine kw-sums per grid point
     ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
     const long rows9 = (long)B * h->gpix[3];
+    LaunchScope ls(h, PL_G9F, RD_KIND_EDGE, B, 2.0 * rows9 * 64 * 27, st);
+    RD_KNAME(h, "k_g9_fwd_mfma + k_tapsum_softmax");
     h->flops_acc += 2.0 * rows9 * 64 * 27;
     if (nd * nd <= 256) {       // whole (h,w) planes in a 256-pixel tile: three sums per grid point
       const size_t lds9 = (size_t)(256 * 64 + 256 * 33) * sizeof(float);
@@ -1464,6 +1585,8 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     // so fp32 keeps the GEMM unless "edge_kernels" is 2 (tests).
     ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
     const long rows9 = (long)B * h->gpix[3];
+    LaunchScope ls(h, PL_G9F, RD_KIND_EDGE, B, 2.0 * rows9 * 64 * 27, st);
+    RD_KNAME(h, "k_g9_fwd + k_tapsum_softmax");
     h->flops_acc += 2.0 * rows9 * 64 * 27;
     RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_fwd<rd_bf16_t> : (const void*)k_g9_fwd<float>, a16 ? 36 * 1024 : 72 * 1024));
     const dim3 g9((unsigned)((rows9 + 255) / 256));
@@ -1522,6 +1645,11 @@ extern "C" int rdgan_check_numerics(rdgan_handle* h, void* stream) {
 // critic
 // ------------------------------------------------------------------------------------
 static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st) {
+  // (skipped when the forms in the workspace were built from these very weights: see rdgan_set_weight_versions)
+  const int ccfg = h->a16 ? 1 : 0;
+  if (h->cver_in != 0 && dp == h->ccache_ptr && h->cver_in == h->ccache_ver && ccfg == h->ccache_cfg) return 0;
+  h->form_builds[1]++;
+  h->ccache_ptr = dp; h->ccache_ver = h->cver_in; h->ccache_cfg = ccfg;
   for (int l = 2; l <= 4; ++l)   // [27][Cin][Cout] -> [27][Cout][Cin]
     RD_TRY(launch_transpose(h, dp + h->doff[2 * (l - 1)], h->DWT[l], 27, h->dch[l - 1], h->dch[l], h->dch[l - 1], st));
   // W1 [27*Cin][64] -> W1T [64][ldp1] (columns (tap,ci), zero padded)
@@ -1550,6 +1678,8 @@ static int launch_d1_fwd(rdgan_handle* h, const float* in, const float* w, const
                          int mode, int use_drop, uint32_t key, uint32_t idx_base, hipStream_t st) {
   ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
   const long rows = (long)NBt * h->dL[1];
+  LaunchScope ls(h, PL_D1F, RD_KIND_EDGE, NBt, 2.0 * rows * 54 * 64, st);
+  RD_KNAME(h, "k_d1_gemm_fwd<%s,%d>", h->a16 ? "bf16" : "f32", mode);
   h->flops_acc += 2.0 * rows * 54 * 64;
   constexpr size_t lds = (size_t)(128 * 64 + 64 * 64) * 4 + 2 * 128 * 8;
   const dim3 grid((unsigned)std::min<long>((rows + 127) / 128, 768));       // three workgroups per CU, each walks its tiles
@@ -1569,6 +1699,8 @@ static int launch_d1_fwd(rdgan_handle* h, const float* in, const float* w, const
 static int launch_d1_wgrad(rdgan_handle* h, const float* in, const float* u1, float* dW, int NBt, hipStream_t st) {
   ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
   const long rows = (long)NBt * h->dL[1];
+  LaunchScope ls(h, PL_D1F, RD_KIND_WGRAD, NBt, 2.0 * rows * 54 * 64, st);
+  RD_KNAME(h, "k_d1_gemm_wgrad<%s>", h->a16 ? "bf16" : "f32");
   h->flops_acc += 2.0 * rows * 54 * 64;
   // one slice of rows per workgroup: four workgroups per CU, whole 32-row chunks
   long G = std::min<long>(1024, (rows + 31) / 32);
@@ -1663,7 +1795,7 @@ extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params,
   h->gate_keep_B = 0;
   RD_TRY(a16_check(h));
   if (h->a16) RD_TRY(prep_critic_weights(h, critic_params, st));      // (also makes the bf16 kernels of layers 2-4)
-  else if (h->CP != h->Cin)
+  else if (h->CP != h->Cin && !(h->cver_in != 0 && critic_params == h->ccache_ptr && h->cver_in == h->ccache_ver))
     hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, critic_params + h->doff[0], h->W1P, h->Cin, h->CP);
   hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, sample,
                      (const float*)nullptr, cond, h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 2, 0u, 0u);
@@ -1845,6 +1977,8 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       const size_t lds_m = g9w_mfma_lds(a16);
       RD_TRY(ensure_lds(h, a16 ? (const void*)k_g9_wgrad_mfma<rd_bf16_t> : (const void*)k_g9_wgrad_mfma<float>, lds_m));
       nwg = (int)std::min<long>((npix3 + 127) / 128, 768);          // persistent: three workgroups per CU
+      LaunchScope ls(h, PL_G9B, RD_KIND_WGRAD, B, 2.0 * npix3 * 64 * 27, st);
+      RD_KNAME(h, "k_g9_wgrad_mfma<%s>", a16 ? "bf16" : "f32");
       h->flops_acc += 2.0 * npix3 * 64 * 27;
       if (a16) hipLaunchKernelGGL(k_g9_wgrad_mfma<rd_bf16_t>, dim3(nwg), dim3(256), lds_m, st, h->dl, (const rd_bf16_t*)h->h3, h->wpartial,
                                   npix3, RDGAN_NHOURS, nd, nd, ilog2(nd));

@@ -4,6 +4,7 @@ PyTorch is plumbing only (device memory, streams, torch.distributed); every FLOP
 of the step goes through librdgan_hip.so.  No CPU fallback.
 """
 import ctypes
+import itertools
 
 import numpy as np
 import torch
@@ -12,6 +13,14 @@ from . import _lib
 from . import weights as W
 
 LOSS_SLOTS = 8
+
+_versions = itertools.count(1)
+
+
+def new_version():
+    """A process-wide fresh content version for a weight slab (rdgan_set_weight_versions): whoever writes a slab takes a
+    new one, so two slabs -- or two states of one slab -- never share a number, whichever object owns them."""
+    return next(_versions)
 
 
 def require_gpu():
@@ -76,8 +85,21 @@ class Engine:
         if not (1 <= B <= cap):
             raise ValueError(f"batch {B} outside [1, {cap}] (engine created with max_batch={self.max_batch})")
 
-    # ---- entry points
-    def gen_forward(self, gen_params, z, cond, out=None):
+    def _versions(self, gen_version, critic_version):
+        """content versions of the slabs of the next call (0 = unknown: the weight forms are rebuilt)"""
+        _lib.check(self.lib.rdgan_set_weight_versions(self._h, ctypes.c_uint64(int(gen_version)), ctypes.c_uint64(int(critic_version))),
+                   self._h, "rdgan_set_weight_versions")
+
+    def form_builds(self):
+        """(generator, critic): how many times this engine has built each network's weight forms (rdgan_form_builds)"""
+        g, c = ctypes.c_long(), ctypes.c_long()
+        _lib.check(self.lib.rdgan_form_builds(self._h, ctypes.byref(g), ctypes.byref(c)), self._h, "rdgan_form_builds")
+        return g.value, c.value
+
+    # ---- entry points.  gen_version / critic_version: the caller's content version of the slab it passes (new_version()
+    # after every write); with it the engine skips rebuilding the weight forms of a network that has not changed since the
+    # last call.  0 (default) = unknown: always rebuild.
+    def gen_forward(self, gen_params, z, cond, out=None, gen_version=0):
         B = z.shape[0]
         nd = self.ndomain
         self._check_batch(B, self.max_batch)
@@ -87,6 +109,7 @@ class Engine:
         if out is None:
             out = torch.empty((B, W.NHOURS, nd, nd, 1), dtype=torch.float32, device=self.device)
         _chk_tensor(out, (B, W.NHOURS, nd, nd, 1), "out")
+        self._versions(gen_version, 0)
         _lib.check(self.lib.rdgan_gen_forward(self._h, _ptr(gen_params), _ptr(z), _ptr(cond), _ptr(out), B, self._stream()),
                    self._h, "rdgan_gen_forward")
         return out
@@ -99,7 +122,7 @@ class Engine:
             raise _lib.NumericsError("found nan in output of per_gridpoint_softmax")
         _lib.check(rc, self._h, "rdgan_check_numerics")
 
-    def critic_forward(self, critic_params, sample, cond, seed=0):
+    def critic_forward(self, critic_params, sample, cond, seed=0, critic_version=0):
         B = sample.shape[0]
         nd = self.ndomain
         self._check_batch(B, 3 * self.max_batch)
@@ -107,6 +130,7 @@ class Engine:
         _chk_tensor(sample, (B, W.NHOURS, nd, nd, 1), "sample")
         _chk_tensor(cond, (B, nd, nd, self.n_cond_channels), "cond")
         out = torch.empty((B, 1), dtype=torch.float32, device=self.device)
+        self._versions(0, critic_version)
         _lib.check(self.lib.rdgan_critic_forward(self._h, _ptr(critic_params), _ptr(sample), _ptr(cond), _ptr(out), B,
                                                  ctypes.c_uint64(seed), self._stream()), self._h, "rdgan_critic_forward")
         return out
@@ -116,7 +140,8 @@ class Engine:
         """hipEvent_t of a recorded torch.cuda.Event (None -> NULL)"""
         return ctypes.c_void_p(ev.cuda_event if ev is not None else 0)
 
-    def critic_grad(self, critic_params, gen_params, x_real, cond, z, seed, grad_out=None, critic_ready=None):
+    def critic_grad(self, critic_params, gen_params, x_real, cond, z, seed, grad_out=None, critic_ready=None,
+                    gen_version=0, critic_version=0):
         """critic_ready: torch.cuda.Event recorded (on another stream) behind the last update of critic_params; the
         current stream waits for it after the generator forward (rdgan_critic_grad_after)."""
         B = x_real.shape[0]
@@ -130,13 +155,15 @@ class Engine:
         if grad_out is None:
             grad_out = torch.empty(self.n_critic + LOSS_SLOTS, dtype=torch.float32, device=self.device)
         _chk_tensor(grad_out, (self.n_critic + LOSS_SLOTS,), "grad_out")
+        self._versions(gen_version, critic_version)
         _lib.check(self.lib.rdgan_critic_grad_after(self._h, _ptr(critic_params), _ptr(gen_params), _ptr(x_real), _ptr(cond),
                                                     _ptr(z), ctypes.c_uint64(seed), _ptr(grad_out), B,
                                                     self._event_handle(critic_ready), self._stream()),
                    self._h, "rdgan_critic_grad")
         return grad_out
 
-    def gen_grad(self, critic_params, gen_params, z, cond, seed, grad_out=None, critic_ready=None):
+    def gen_grad(self, critic_params, gen_params, z, cond, seed, grad_out=None, critic_ready=None,
+                 gen_version=0, critic_version=0):
         B = z.shape[0]
         nd = self.ndomain
         self._check_batch(B, self.max_batch)
@@ -147,6 +174,7 @@ class Engine:
         if grad_out is None:
             grad_out = torch.empty(self.n_gen + LOSS_SLOTS, dtype=torch.float32, device=self.device)
         _chk_tensor(grad_out, (self.n_gen + LOSS_SLOTS,), "grad_out")
+        self._versions(gen_version, critic_version)
         _lib.check(self.lib.rdgan_gen_grad_after(self._h, _ptr(critic_params), _ptr(gen_params), _ptr(z), _ptr(cond),
                                                  ctypes.c_uint64(seed), _ptr(grad_out), B,
                                                  self._event_handle(critic_ready), self._stream()),
@@ -185,6 +213,18 @@ class Engine:
         f = ctypes.c_double()
         _lib.check(self.lib.rdgan_flop_count(self._h, ctypes.byref(f), int(bool(reset))), self._h, "rdgan_flop_count")
         return f.value
+
+    def profile_launches(self, on):
+        _lib.check(self.lib.rdgan_profile_launches(self._h, int(bool(on))), self._h, "rdgan_profile_launches")
+
+    def launch_table(self):
+        """rows of rdgan_launch_table as dicts: name, kernel, kind, batch, launches, gflop (summed), ms (summed)"""
+        buf = (_lib.LaunchStat * 256)()
+        n = ctypes.c_int()
+        _lib.check(self.lib.rdgan_launch_table(self._h, buf, 256, ctypes.byref(n)), self._h, "rdgan_launch_table")
+        kinds = {0: "gemm", 1: "wgrad", 2: "edge"}
+        return [dict(name=r.name.decode(), kernel=r.kernel.decode(), kind=kinds.get(r.kind, "?"), batch=r.batch,
+                     launches=r.launches, gflop=r.gflop, ms=r.ms) for r in buf[:n.value]]
 
     def profile_read(self, tag):
         ms, n = ctypes.c_double(), ctypes.c_long()

@@ -51,18 +51,22 @@ class _Model:
                 raise ValueError(f"{self.kind}: weight {n} has shape {a.shape}, expected {s}")
         self._arrays = arrays
         self._slab = None
+        self._version = 0
 
     def count_params(self):
         return W.param_count(self.shapes)
 
     def device_slab(self, engine):
         if self._slab is None:
+            from .engine import new_version
             self._slab = engine.to_slab(self._arrays)
+            self._version = new_version()        # this object wrote the slab: it can vouch for its content (weight-form cache)
         return self._slab
 
     def adopt_slab(self, slab):
         """Share the trainer's device slab (weights then track training without copies)."""
         self._slab = slab
+        self._version = 0                        # written by the trainer: content version unknown here, forms rebuilt per call
 
     def save(self, path):
         """``model.save(path)`` (reference :520-521): Keras-layout .h5 when h5py is importable, .npz otherwise."""
@@ -102,7 +106,7 @@ class Generator(_Model):
         for i in range(0, n, chunk):
             z = torch.from_numpy(latent[i:i + chunk]).to(eng.device)
             c = torch.from_numpy(cond[i:i + chunk]).to(eng.device)
-            res = eng.gen_forward(slab, z, c)
+            res = eng.gen_forward(slab, z, c, gen_version=self._version)
             eng.check_numerics()                 # tf.debugging.check_numerics in the generator graph (reference T:349-350)
             out[i:i + chunk] = res.cpu().numpy()
         return out
@@ -126,7 +130,7 @@ class Critic(_Model):
         for i in range(0, n, chunk):
             x = torch.from_numpy(sample[i:i + chunk]).to(eng.device)
             c = torch.from_numpy(cond[i:i + chunk]).to(eng.device)
-            out[i:i + chunk] = eng.critic_forward(slab, x, c, seed=0).cpu().numpy()
+            out[i:i + chunk] = eng.critic_forward(slab, x, c, seed=0, critic_version=self._version).cpu().numpy()
         return out
 
 

@@ -71,6 +71,11 @@ class WGANGPTrainer:
                 setattr(self, which + "_gshard", torch.zeros(per, dtype=torch.float32, device=p0.device))
                 setattr(self, which + "_pshard", torch.zeros(per, dtype=torch.float32, device=p0.device))
         self.t = 0                      # shared optimizer.iterations
+        # content versions of the two weight slabs (engine.new_version(): process-wide unique): a fresh one after every write,
+        # so the engine rebuilds a network's weight forms once per update instead of once per call (rdgan_set_weight_versions)
+        self.weight_cache = hasattr(engine, "form_builds")
+        self.gver = self.dver = 0
+        self.weights_changed()
         self.base_seed = int(base_seed)
         self.calls = 0
         on_gpu = self.gparams.is_cuda
@@ -80,6 +85,16 @@ class WGANGPTrainer:
         self.d_ready = None             # events recorded on the communication stream behind the last critic / generator update
         self.g_ready = None
         self._native_collectives = None
+
+    def weights_changed(self, which="gd"):
+        """Call after writing a weight slab from outside (set_weights, a checkpoint load): its forms are rebuilt on next use."""
+        if self.weight_cache:
+            from .engine import new_version
+            for w in which:
+                setattr(self, w + "ver", new_version())
+
+    def _ver(self):
+        return {"gen_version": self.gver, "critic_version": self.dver} if self.weight_cache else {}
 
     # every stochastic draw inside a step (dropout masks, alpha) is keyed by (base_seed, call index, rank)
     def _next_seed(self):
@@ -139,6 +154,7 @@ class WGANGPTrainer:
             self._allreduce(grad)
             self.t += 1
             self.eng.adam(params, grad, v, self.t, self.lr, self.beta2, self.eps, 1.0 / self.world)
+            self.weights_changed(which)
             tail = grad[n:n + 5]
             return tail if self.world == 1 else tail / self.world      # (a view at world 1: no extra kernel on the step path)
         pbuf, vbuf = getattr(self, which + "_pbuf"), getattr(self, which + "_vbuf")
@@ -154,6 +170,7 @@ class WGANGPTrainer:
             pbuf[a:b].copy_(gsh[a - lo:b - lo])            # ... rides behind the weights in the all-gather
         psh.copy_(pbuf[lo:lo + per])
         self._all_gather(pbuf[:P], psh)                    # every rank: the updated weights + the loss sums
+        self.weights_changed(which)
         return pbuf[n:n + 5] / self.world
 
     def _update_overlapped(self, which):
@@ -202,25 +219,27 @@ class WGANGPTrainer:
         Returns the device tensor [total, valid, fake, gp, nonfinite] averaged over ranks."""
         seed = self._next_seed() if seed is None else seed
         if not self.overlap:
-            self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self._slab("d"))
+            self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self._slab("d"), **self._ver())
             return self._update("d")
         cur = torch.cuda.current_stream(self.dparams.device)
         if self.g_ready is not None:
             cur.wait_event(self.g_ready)               # the generator forward reads the generator weights at once
         # critic weights, their Adam state and the gradient slab are touched only behind the wait for d_ready
-        self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self._slab("d"), critic_ready=self.d_ready)
+        self.eng.critic_grad(self.dparams, self.gparams, x_real, cond, z, seed, grad_out=self._slab("d"), critic_ready=self.d_ready,
+                             **self._ver())
         return self._update_overlapped("d")
 
     def gen_step(self, z, cond, seed=None):
         """generator_model.train_on_batch([latent, cond], valid) (reference :482)."""
         seed = self._next_seed() if seed is None else seed
         if not self.overlap:
-            self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self._slab("g"))
+            self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self._slab("g"), **self._ver())
             return self._update("g")
         cur = torch.cuda.current_stream(self.gparams.device)
         if self.g_ready is not None:
             cur.wait_event(self.g_ready)
-        self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self._slab("g"), critic_ready=self.d_ready)
+        self.eng.gen_grad(self.dparams, self.gparams, z, cond, seed, grad_out=self._slab("g"), critic_ready=self.d_ready,
+                          **self._ver())
         return self._update_overlapped("g")
 
     def join(self):
@@ -294,6 +313,7 @@ class WGANGPTrainer:
                     raise ValueError(f"{path}: {name} has shape {src.shape}, expected {tuple(dst.shape)}")
                 dst.copy_(torch.from_numpy(src))
             self.t, self.calls, self.base_seed = int(f["t"]), int(f["calls"]), int(f["base_seed"])
+            self.weights_changed()
             if restore_numpy_rng:
                 pos = f["np_rng_pos"]
                 np.random.set_state(("MT19937", f["np_rng_keys"], int(pos[0]), int(pos[1]), float(f["np_rng_gauss"])))

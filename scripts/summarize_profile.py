@@ -68,6 +68,25 @@ for mode, run in (("0", "fp32_bs256"), ("1", "bf16_bs256")):
             w.writerow([r[0], r[1], f"{r[2]:.2f}", f"{r[3]:.2f}", f"{r[4]:.1f}", f"{r[5]:.0f}"])
     print("wrote", out)
 
+# profiles/hbm_traffic_dominant.json: what bench.py reports as roofline.traffic (bytes per launch of the dominant kernel: its own
+# kernel symbol, NAMETAG = 1), rewritten from the counter tables of THIS profile run so that the number cannot go stale
+import json
+dom = {"entries": []}
+for mode, bf in (("fp32", False), ("bf16", True)):
+    f = os.path.join(dst, f"{tag}_hbm_traffic_{mode}_bs256.csv")
+    if not os.path.exists(f):
+        continue
+    for r in csv.DictReader(open(f)):
+        if re.match(r"k_conv_gemm_ws<256, 64, 4, 1, \d, (true|false), 1", r["Name"]):
+            by = (float(r["fetch_MB_per_launch_x2_corrected"]) + float(r["write_MB_per_launch"])) * 1e6
+            dom["entries"].append({"bf16": bf, "ndomain": 16, "batch": 256, "bytes_per_launch": by, "kernel": r["Name"],
+                                   "source": f"profiles/{tag}_hbm_traffic_{mode}_bs256.csv (separate rocprofv3 --pmc passes: FETCH_SIZE x 2 "
+                                             f"+ WRITE_SIZE per launch)"})
+if dom["entries"]:
+    with open(os.path.join(dst, "hbm_traffic_dominant.json"), "w") as o:
+        json.dump(dom, o, indent=1)
+    print("wrote", os.path.join(dst, "hbm_traffic_dominant.json"))
+
 for mode, run in (("0", "fp32_bs256"), ("1", "bf16_bs256")):
     f = os.path.join(src, f"pmc_bf16{mode}_TCC_REQ_sum.csv")
     if not os.path.exists(f):

@@ -188,3 +188,84 @@ def test_train_mirror_in_bf16_storage_mode(tmp_path, monkeypatch):
     finally:
         models.get_engine(16, 8).set_option("bf16", 0)
         T.configure(n_disc=5)
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_weight_form_cache_is_bit_identical_and_builds_once_per_update(bf16):
+    """rdgan_set_weight_versions: the trainer vouches for the content of its slabs (a fresh version after every Adam update),
+    so a network's weight forms are built once per update instead of once per call: per iteration of n_disc = 3 critic steps
+    + 1 generator step the generator's forward forms once (4 calls use them) and the critic's forms 3 times (the generator
+    step and the critic step behind it share one build).  Same kernels on the same data: weights, Adam state and losses are
+    bit-identical to a run that rebuilds the forms in every call."""
+    from pr_disagg_radar_gan_amd import Engine
+    from pr_disagg_radar_gan_amd.trainer import WGANGPTrainer, synthetic_batch_device
+    B, n_disc, iters = 6, 3, 4
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        if bf16:
+            eng.set_option("bf16", 1)
+        rng = np.random.default_rng(12)
+        g, d = W.init_generator(rng, 16), W.init_critic(rng, 16)
+        batches = [synthetic_batch_device(B, 16, 700 + i, eng.device) for i in range(4)]
+
+        def run(cache):
+            tr = WGANGPTrainer(eng, g, d, n_disc=n_disc, base_seed=21)
+            tr.weight_cache = cache
+            if not cache:
+                tr.gver = tr.dver = 0
+            g0, c0 = eng.form_builds()
+            losses = []
+            for it in range(iters):
+                crit = [batches[(it + j) % 4] for j in range(n_disc)]
+                x, c, z = batches[(it + 3) % 4]
+                losses.append(torch.stack([t.reshape(()) for t in tr.iteration(crit, (z, c))]))
+            torch.cuda.synchronize()
+            g1, c1 = eng.form_builds()
+            return (tr.gparams.clone(), tr.dparams.clone(), tr.gv.clone(), tr.dv.clone(), torch.stack(losses)), (g1 - g0, c1 - c0)
+
+        a, na = run(True)
+        b, nb = run(False)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        assert nb == (iters * (n_disc + 1), iters * (n_disc + 1))            # every call rebuilds
+        assert na == (iters, iters * n_disc), na                             # once per update of the network
+        assert bool(torch.isfinite(a[4]).all())
+    finally:
+        eng.close()
+
+
+def test_weight_form_cache_cannot_go_stale_through_the_model_and_trainer_api(tmp_path):
+    """Whoever writes a slab takes a fresh version: Generator.set_weights / load_weights drop the device slab (a new slab, a
+    new version), a trainer-owned slab adopted by a model is passed with version 0 (rebuild), load_checkpoint bumps both
+    versions.  So predictions always follow the weights -- also when torch hands the new slab the address of the old one."""
+    from pr_disagg_radar_gan_amd.trainer import WGANGPTrainer
+    rng = np.random.default_rng(13)
+    ga, gb = W.init_generator(rng, 16), W.init_generator(rng, 16)
+    x, cond, z = ot.synthetic_batch(3, 16, 5)
+    gen = models.Generator(ga, 16)
+    out_a = gen.predict([z, cond])
+    np.testing.assert_array_equal(out_a, gen.predict([z, cond]))            # second call: forms reused, same output
+    gen.set_weights(gb)                                                      # frees the slab; the next one may reuse its address
+    out_b = gen.predict([z, cond])
+    np.testing.assert_array_equal(out_b, models.Generator(gb, 16).predict([z, cond]))
+    assert np.abs(out_a - out_b).max() > 1e-4
+    # trainer: adopt, train, predict through the model (version unknown -> rebuilt), checkpoint round trip
+    eng = models.get_engine(16, 3)
+    d = W.init_critic(rng, 16)
+    tr = WGANGPTrainer(eng, ga, d, n_disc=1)
+    gen.adopt_slab(tr.gparams)
+    dev = lambda a: torch.from_numpy(a).to(eng.device)
+    before = gen.predict([z, cond])
+    np.testing.assert_array_equal(before, out_a)
+    tr.iteration([(dev(x), dev(cond), dev(z))], (dev(z), dev(cond)))
+    after = gen.predict([z, cond])
+    assert np.abs(after - before).max() > 0
+    path = str(tmp_path / "ck.npz")
+    tr.save_checkpoint(path)
+    want = [t.clone() for t in tr.iteration([(dev(x), dev(cond), dev(z))], (dev(z), dev(cond)))]
+    w_want = tr.gparams.clone()
+    tr.load_checkpoint(path)                                                 # slabs rewritten in place: versions must change
+    got = tr.iteration([(dev(x), dev(cond), dev(z))], (dev(z), dev(cond)))
+    for u, v in zip(want, got):
+        assert torch.equal(u, v)
+    assert torch.equal(w_want, tr.gparams)

@@ -5,7 +5,7 @@ softmax / gradient penalty / Adam arithmetic in fp32.
 Tolerances.  The kernels' arithmetic is pinned at 1e-5 against the oracle on bf16-rounded operands (tests/test_hip_ops.py).
 End to end every stored tensor carries one bf16 rounding (2^-9 relative), so against the fp64 oracle: generator forward
 (fractions) within 2e-2 of the largest fraction; BOTH step gradients -- the critic step with the gradient penalty's double
-backward included -- within 6e-2 of each tensor's largest entry, measured against the fp64 oracle differentiating the
+backward included -- within 3e-2 of each tensor's largest entry, measured against the fp64 oracle differentiating the
 LeakyReLU branch the bf16 run took (tests/test_hip_step.py explains why; critic steps: option "keep_gates") and, for the
 critic step, given the generator output the bf16 run fed its critic (the generator is frozen there: a constant input).
 """
@@ -21,7 +21,7 @@ from tests.test_hip_step import _params, _t64, _grad_errors
 
 pytestmark = pytest.mark.gpu
 
-FWD_TOL, GRAD_TOL = 2e-2, 6e-2
+FWD_TOL, GRAD_TOL = 2e-2, 3e-2      # observed: forward 2-4e-3; gradients 2e-3 ... 1.5e-2 (both steps)
 
 
 def _check_bf16_case(nd, B, seed, fast=None):
