@@ -63,7 +63,8 @@ k_g9_fwd(const T* __restrict__ h3, const float* __restrict__ w9 /* [27][64] */, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) Ws[k * 32 + n0 + e] = n0 + e < 27 ? w9[(n0 + e) * 64 + k] : 0.f;
   }
-  __syncthreads();                                            // (hipcc waits vmcnt(0) in front of the barrier: the tile has landed)
+  rd_dma_landed();
+  __syncthreads();                                            // the tile has landed
 
   // ---- P[64 rows of this wave][32 taps]
   f32x16 acc[2];
@@ -183,9 +184,11 @@ k_g9_fwd_mfma(const float* __restrict__ h3, const float* __restrict__ w9 /* [27]
   const long ntiles = (rows + TP - 1) / TP;
   long tile = blockIdx.x;
   if (tile < ntiles) issue((unsigned)(tile * TP));
+  rd_dma_landed();
   for (; tile < ntiles; tile += gridDim.x) {
     const unsigned m0 = (unsigned)(tile * TP);                // (the host keeps rows < 2^31)
-    __syncthreads();                                          // (vmcnt(0) in front of it) the tile has landed; the last tile's sums are out
+    __syncthreads();                                          // the tile has landed (every wave waited for its DMA: below, and in
+    //                                                           front of the loop for the first tile); the last tile's sums are out
     const int i = wave * 32 + l31;                            // this lane's pixel (MFMA row)
     f32x4 fa[8];
 #pragma unroll
@@ -200,6 +203,7 @@ k_g9_fwd_mfma(const float* __restrict__ h3, const float* __restrict__ w9 /* [27]
     for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s >> 2][s & 3], wv[s], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Pt[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * CST + l31] = acc[r];
+    rd_dma_landed();                // the next tile's DMA had the 32 MFMAs to land; the Q stores below stay in flight over the loop head
     __syncthreads();
     // sums over the taps whose neighbours lie inside the tile (same arithmetic and order as RD_EPI_TAPGATHER)
     const int Hd = HW / Wd;
@@ -314,7 +318,8 @@ k_g9_wgrad_mfma(const float* __restrict__ dl, const T* __restrict__ h3, float* _
     store_stage();
   }
   for (; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();                                           // (vmcnt(0) in front of it) tile: h3 rows landed, rows staged
+    rd_dma_landed();
+    __syncthreads();                                           // tile: h3 rows landed, rows staged
     // this wave's 32 pixels: k-step s multiplies pixels base + s (lanes 0-31) and base + 16 + s (lanes 32-63)
     const int base = wave * 32 + 16 * lhalf;
     float a[16], b0[16], b1[16];

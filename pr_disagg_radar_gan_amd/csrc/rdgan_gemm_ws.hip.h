@@ -22,6 +22,16 @@ __device__ __forceinline__ void rd_lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float*
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
+// A wave's LDS-DMA transfers have landed once its vmcnt is zero.  Waited for EXPLICITLY in front of every barrier that publishes
+// DMA'd bytes to other waves: hipcc's own wait in front of __syncthreads() is derived from the issue order it sees on ONE path
+// into the barrier (round 3: in k_g9_wgrad_mfma's loop -- nine plain loads, then the DMAs -- it emitted the prologue's
+// `s_waitcnt vmcnt(9)`, DMAs first, at the loop head; a wave whose lanes all skip the staging stores then read the previous
+// tile's rows: run-to-run differences of 1e-3 in the last conv's weight gradient at ndomain 64 / 128).  The weight-gradient
+// loaders keep hipcc's own counted wait: there the DMAs are the OLDER operations on every path into the barrier (the next chunk's
+// row-table loads follow them), its `vmcnt(N)` is right (checked in the ISA), and a full drain in front of the barrier, or the
+// row-table loads moved in front of the DMAs, cost 2-20 % (measured, scratch/ab_libs.py).
+__device__ __forceinline__ void rd_dma_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // BF = true: bf16 operands, fp32 accumulation and output (v_mfma_f32_32x32x16_bf16).  `src` then points at bf16
 // activations in the same NDHWC layout and `W` at bf16 weights stored [tap block][N][K per tap] (K contiguous, so both
 // operands are 16-byte fragments); a K chunk is 64 elements, i.e. the same 128-byte LDS rows, DMA pattern and swizzle as
@@ -285,12 +295,14 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
 #ifdef RD_STAMP
     if (ws_st && wave == 4) atomicAdd(&rd_stamp_ws[4], rd_stamp() - ws_t0);
 #endif
-    __syncthreads();                                     // (hipcc waits vmcnt(0) in front of the barrier: chunk 0 has landed)
+    rd_dma_landed();
+    __syncthreads();                                     // chunk 0 has landed
     for (int q = 0; q < nchunks; ++q) {
       // stage (q+1)&1 was last read during chunk q-1, whose closing barrier every wave has passed
       if (q + 1 < nchunks) load_chunk((q + 1) & 1);
       // RES: channel chunk cc is first read by chunk q = cc * ntaps; chunks 1 .. CPT-1 come in behind chunk 0's weights
       if constexpr (RES) { if (q + 1 < CPT) load_resident(q + 1); }
+      rd_dma_landed();
       __syncthreads();
     }
   } else {
