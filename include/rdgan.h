@@ -264,6 +264,11 @@ int rdgan_op_fastd_wgrad(const float* src, const float* dy, float* dU, int B, in
  * dW[27][64] from dl [B][24][nd][nd] and h3 [B][24][nd][nd][64].  kernel = 1: the matrix-pipe kernel (k_g9_wgrad_mfma),
  * 0: the scalar kernel it replaced (k_g9_wgrad_pairs; nd <= 72); bf16 = 1: h3 rounded to bf16 first (storage mode). */
 int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, int B, int nd, int bf16, int kernel, void* stream);
+/* Generator block 3 forward of the bf16 storage mode (T:340-343 on the 12 x 8 x 8 x 128 input of ndomain 16) through the slab
+ * kernel alone (k_upconv_slab16): x and w are rounded to bf16 on the device, y = LeakyReLU(PixelNorm(upconv(x) + bias)) comes
+ * back as fp32 (the bf16 output widened), rinv [B,24,16,16] = 1/l2 per grid point; dbg: NULL, or [B*24*16*16][4] floats (test
+ * hook: row sum of squares and 1/l2 as the two lane halves of a row computed them). */
+int rdgan_op_upconv_slab16(const float* x, const float* w, const float* bias, float* y, float* rinv, float* dbg, int B, void* stream);
 /* PixelNormalization + LeakyReLU(0.2) forward (T:255-266, T:333) and its backward. C in {64,128,256}. */
 int rdgan_op_pixelnorm_lrelu(const float* y, float* h, float* rinv, long npix, int C, void* stream);
 int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* rinv, float* dy,

@@ -16,6 +16,7 @@
 #include "rdgan_gemm.hip.h"
 #include "rdgan_gemm_ws.hip.h"
 #include "rdgan_gemm_ws16.hip.h"
+#include "rdgan_upconv16.hip.h"
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
 #include "rdgan_edge.hip.h"
@@ -386,6 +387,8 @@ struct rdgan_handle {
   void *bU[4], *bUT;
   void *bWF[5], *bWB[5];
   void *bG1F[4], *bG1B, *bW1B;
+  void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
+  int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
   int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
   int g9_direct = 1;              // 1: backward of the 64 -> 1 conv straight from the dlogits (no im2col matrix), fused with block 3's PixelNorm backward
   int fast_fwd = -1;              // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products); -1: by storage mode
@@ -1234,6 +1237,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         for (int l = 1; l <= 3; ++l) { carve(p, 32L * gch[l - 1] * gch[l] + 8); h->bG1F[l] = p; }
         carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
         carve(p, 32L * h->ldp1 + 8); h->bW1B = p;
+        carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3I = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
     }
@@ -1300,6 +1304,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "fast_bwd")) { h->fast_bwd = value < 0 ? -1 : (value ? 1 : 0); return 0; }
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "dense_wgrad_slices")) { h->dense_slices = value; return 0; }
   if (!strcmp(name, "keep_gates")) {
     h->keep_gates = value ? 1 : 0;
@@ -1446,6 +1451,12 @@ static bool gen_block_fast(const rdgan_handle* h, int l, int enabled) {
   return h->collapse && enabled && h->gdim[l - 1][0] >= 6;
 }
 
+// generator block 3 forward by the slab kernel (rdgan_upconv16.hip.h): bf16 storage mode, collapsed form, the 12 x 8 x 8 x 128
+// -> 24 x 16 x 16 x 64 block of ndomain 16
+static bool upconv_slab_on(const rdgan_handle* h, int l) {
+  return h->upconv_slab && h->a16 && h->collapse && l == 3 && h->nd == 16 && !gen_block_fast(h, 3, fast_fwd_on(h));
+}
+
 // `ws`: stream of the weight-only kernels (the handle's side stream, forked by the caller, or `st` itself): the weight forms of
 // block l are complete behind event ev_g[l], which `st` waits for in front of the block's GEMM
 static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, const float* cond, float* out, int B,
@@ -1455,7 +1466,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   RD_TRY(a16_check(h));
   // ---- weight forms (read only the weights): skipped when the caller vouches that the forms in the workspace were built from
   // these very weights (same slab, same content version, same form options)
-  const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0);
+  const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0) | (h->upconv_slab ? 8 : 0);
   const bool forms_cached = h->gver_in != 0 && gp == h->gcache_ptr && h->gver_in == h->gcache_ver && gcfg == h->gcache_cfg;
   if (!forms_cached) {
   h->form_builds[0]++;
@@ -1472,7 +1483,8 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->fU[l], h->bU[l], 48, h->gch[l - 1], h->gch[l], ws));
     } else if (h->collapse) {
       hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * cc)), dim3(256), 0, ws, Wl, h->GWC[l], (int)cc);
-      if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
+      if (upconv_slab_on(h, l)) hipLaunchKernelGGL(k_upconv_wimg, dim3(256), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW3I);
+      else if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
     }
     if (ws != st) RD_CHECK(h, hipEventRecord(h->ev_g[l], ws));
   }
@@ -1540,6 +1552,17 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     ep.rinv = rs[l];
     ep.out16 = a16;
     ep.nametag = a16 && l == 3;
+    if (upconv_slab_on(h, l)) {     // block 3, bf16 storage: source slab resident in LDS, weights streamed in fragment order
+      ProfScope ps(h, RDGAN_TAG_GCONV3_FWD, st);
+      LaunchScope ls(h, pl, RD_KIND_CONV, B, plan_flops(h->plans[pl], B), st);
+      RD_KNAME(h, "k_upconv_slab16");
+      h->flops_acc += plan_flops(h->plans[pl], B);
+      RD_TRY(ensure_lds(h, (const void*)k_upconv_slab16<1>, RD_UPC_LDS));
+      hipLaunchKernelGGL(k_upconv_slab16<1>, dim3((unsigned)std::min(3 * B, 256)), dim3(512), RD_UPC_LDS, st, (const rd_bf16_t*)hs[l - 1],
+                         (const rd_bf16_t*)h->bW3I, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B);
+      RD_CHECK(h, hipGetLastError());
+      continue;
+    }
     if (a16) {     // collapsed form (64 taps) on the bf16 matrix pipe
       RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], h->bG1F[l], hs[l], ep, st,
                            l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
@@ -2423,6 +2446,37 @@ extern "C" int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, in
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   if (partial) (void)hipFree(partial);
   if (hb) (void)hipFree(hb);
+  return rc;
+}
+
+// Generator block 3 forward of the bf16 storage mode through the slab kernel alone (rdgan_upconv16.hip.h): x [B,12,8,8,128] and the
+// Conv3D kernel w [3,3,3,128,64] are rounded to bf16 on the device (the kernel after the upsample collapse), y [B,24,16,16,64] =
+// LeakyReLU(PixelNorm(upconv(x) + bias)) comes back as fp32 (the kernel's bf16 output widened), rinv [B,24,16,16]; dbg (optional,
+// [B*24*16*16][4]): the row sums of squares and 1/l2 as both lane halves computed them.
+extern "C" int rdgan_op_upconv_slab16(const float* x, const float* w, const float* bias, float* y, float* rinv, float* dbg, int B,
+                                      void* stream) {
+  if (!x || !w || !bias || !y || !rinv || B < 1) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long nx = (long)B * 12 * 64 * 128, ny = (long)B * 24 * 256 * 64;
+  void *xb = nullptr, *yb = nullptr, *wi = nullptr; float* wc = nullptr;
+  int rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc(&wi, 64L * 8 * 2 * 64 * 16);
+  if (rc == 0) rc = (int)hipMalloc((void**)&wc, 64L * 128 * 64 * sizeof(float));
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * 128 * 64)), dim3(256), 0, st, w, wc, 128 * 64);
+    hipLaunchKernelGGL(k_upconv_wimg, dim3(256), dim3(256), 0, st, wc, (unsigned short*)wi);
+    rc = ensure_lds(nullptr, (const void*)k_upconv_slab16<0>, RD_UPC_LDS);
+  }
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_upconv_slab16<0>, dim3((unsigned)std::min(3 * B, 256)), dim3(512), RD_UPC_LDS, st, (const rd_bf16_t*)xb,
+                       (const rd_bf16_t*)wi, bias, (rd_bf16_t*)yb, rinv, B, dbg);
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(ny)), dim3(256), 0, st, (const rd_bf16_t*)yb, y, ny);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {xb, yb, wi, (void*)wc}) if (p) (void)hipFree(p);
   return rc;
 }
 

@@ -1,0 +1,219 @@
+// bf16 storage mode, generator block 3 forward (T:340-343: UpSampling3D(2) + Conv3D(128 -> 64, 3x3x3, 'same') + PixelNorm +
+// LeakyReLU onto the 24 x 16 x 16 grid) in the collapsed form (8 output-parity phases x 8 taps of 128 channels on
+// the un-upsampled 12 x 8 x 8 grid) -- the dominant launch of BASELINE configs[2..3] -- as a SLAB kernel (round 3).
+//
+// Why another kernel.  As a streaming GEMM (k_conv_gemm_ws<256, 64, ..., bf16>) this layer has N = 64: every 256-row x 64-k
+// chunk of gathered rows (32 KB) is used for 16 MFMAs per wave and then thrown away, 40 KB pulled from L2 into LDS per 512
+// matrix-pipe cycles = 80 B/clk per CU, where a CU takes in 30-50 B/clk: 0.31 of the MFMA roof, and the one-barrier-per-chunk
+// lock-step between loader and compute waves adds what is left.  The three re-designs of round 2 kept that
+// structure.  This one does not:
+//   * A workgroup owns a SLAB: 4 source hour planes of one sample (256 positions x 128 channels) + the two halo planes, resident in
+//     LDS (6 x 16 KB) for ALL 8 phases x 8 taps: each source row is fetched once per slab instead of 64 times (96 KB per slab
+//     against 4 MB).  A tap is a shifted read of the same rows ((h, w) shifts inside the plane, d shifts = another plane slot);
+//     rows outside the picture read a zero row.
+//   * Weights never touch LDS: they are stored in HBM in MFMA-fragment order (k_upconv_wimg: 1 KB per wave-instruction, fully
+//     coalesced) and every wave streams its own fragments global -> VGPR four k-steps ahead of their use.  No loader waves, no
+//     staging, NO barrier inside a tile: the eight waves of a workgroup drift apart, and one wave's epilogue, fragment-read
+//     latency or weight wait is covered by its SIMD partner's MFMAs.
+//   * Each wave computes a 128-row x 64-channel tile of ONE phase with the operands swapped (D^T = W^T X^T: weights as the
+//     MFMA's A operand, activations as B), so a lane ends up with 32 channels of ONE output row and lane ^ 32 with the other 32:
+//     bias + PixelNorm (sum of squares: 32 FMAs + one cross-half exchange) + LeakyReLU + bf16 rounding run in registers, and the
+//     row goes out in 16-byte stores (v_permlane32_swap pairs).  No LDS round trip, no epilogue barrier.
+// Per CU and 512 matrix-pipe cycles the kernel moves 16 KB of weight fragments through L1 (8 waves x 2 KB; 8 KB from L2) and
+// reads 64 KB of row fragments from LDS (128 B/clk, half the LDS rate).
+//
+// LDS image of a plane slot: 64 rows (h*8 + w) of 256 B (128 channels), 16-byte chunk c of row r stored at c ^ (r & 15): the 32
+// lanes of a fragment read take 32 consecutive rows (shifted or not), so every 16-lane group of a ds_read_b128 hits 16 different
+// bank groups.  The DMA writes lane-linearly, so the swizzle is applied to the SOURCE address (as in k_conv_gemm_ws).
+#pragma once
+#include "rdgan_gemm_ws.hip.h"
+
+#define RD_UPC_SLOT 16384                 // bytes per plane slot
+#define RD_UPC_ZERO (6 * RD_UPC_SLOT)     // a 256-byte row of zeros: taps that fall outside the (h, w) picture
+#define RD_UPC_BIAS (RD_UPC_ZERO + 256)   // 64 floats
+#define RD_UPC_LDS (RD_UPC_BIAS + 256)
+
+// Weight image of the slab kernel from the collapsed forms Wc [64 = phase*8 + tap][128 ci][64 co] (fp32, k_collapse_weights):
+// for k-step g = (phase*8 + tap)*8 + j (j = 16-channel step 0..7) and column block nb, lane l holds the 8 bf16
+// Wc[phase*8 + tap][16 j + 8 (l >> 5) + e][32 nb + (l & 31)], e = 0..7: the A fragment of v_mfma_f32_32x32x16_bf16, 1 KB per
+// (g, nb), 1 MB in all.
+__global__ void k_upconv_wimg(const float* __restrict__ Wc, unsigned short* __restrict__ wimg) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;                 // (g, nb, lane)
+  if (idx >= 64 * 8 * 2 * 64) return;
+  const int lane = idx & 63, nb = (idx >> 6) & 1, g = idx >> 7;
+  const int pt = g >> 3, j = g & 7;
+  const int n = nb * 32 + (lane & 31), k0 = j * 16 + (lane >> 5) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = Wc[((long)pt * 128 + k0 + e) * 64 + n];
+  u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
+  *(u32x4_t*)(wimg + (long)idx * 8) = o;
+}
+
+// A weight fragment (1 KB per wave-instruction): global -> VGPR by an inline-asm load that hipcc does not see, so that it cannot
+// re-schedule the software pipeline (its own version of this loop issued every load one k-step in front of its use and waited
+// for it with vmcnt(0): the queue of four k-steps was gone) and does not drain the queue with its own waits.  The statement that
+// waits (rd_upc_wait) names the destination registers, so no consumer is scheduled above it.  `base` is wave-uniform (SGPR pair),
+// `voff` = lane * 16.
+__device__ __forceinline__ void rd_upc_wload(u32x4_t& d0, u32x4_t& d1, const char* base, unsigned voff) {
+  // (s_nop 4: `base` is an SGPR pair the compiler has just computed with SALU instructions; a vector-memory instruction that
+  // reads it needs 5 wait states behind the write, which hipcc pads for its own loads but not for an asm statement -- without
+  // the pad the load now and then went out with the previous k-step's address)
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+               : "=&v"(d0), "=&v"(d1) : "v"(voff), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void rd_upc_wait(u32x4_t& d0, u32x4_t& d1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(d0), "+v"(d1) : "i"(N));
+}
+
+// x [B][12][8][8][128] bf16 -> out [B][24][16][16][64] bf16 = LeakyReLU(PixelNorm(upconv(x) + bias)), rinv [B][24][16][16] = 1/l2.
+// grid: min(3 B, CUs) persistent workgroups of 512 threads; dynamic LDS RD_UPC_LDS.  NAMETAG: own symbol for the profiler.
+template <int NAMETAG>
+__global__ void __launch_bounds__(512, 2)
+k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ wimg, const float* __restrict__ bias,
+                rd_bf16_t* __restrict__ out, float* __restrict__ rinv, int B, float* __restrict__ dbg = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  const int rh = wave & 1, q = wave >> 1;            // row half (planes 2 rh, 2 rh + 1 of the slab), phase slot
+  const int ph = q >> 1, pw = q & 1;
+
+  if (tid < 64) {
+    *(float*)(lds + RD_UPC_BIAS + tid * 4) = bias[tid];
+    *(float*)(lds + RD_UPC_ZERO + tid * 4) = 0.f;
+  }
+  const unsigned wvoff = (unsigned)lane * 16u;
+
+  for (int slab = blockIdx.x; slab < 3 * B; slab += gridDim.x) {
+    const int b = slab / 3, d0 = (slab - b * 3) * 4;
+    __syncthreads();                                  // every wave has left the previous slab (and the bias / zero rows are in)
+    {
+      // the six planes d0 - 1 .. d0 + 4 -> slots 0 .. 5: 96 DMA instructions of 1 KB (4 rows), 12 per wave
+      const __amdgpu_buffer_rsrc_t rs = rd_make_rsrc((const float*)(x + (long)b * (12 * 64 * 128)));
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int i = wave * 12 + k;                  // wave-uniform
+        const int pi = i >> 4, ii = i & 15;
+        const int d = d0 - 1 + pi;
+        const int row = ii * 4 + (lane >> 4);
+        const int c_log = (lane & 15) ^ (row & 15);
+        unsigned voff = (unsigned)d < 12u ? (unsigned)(((d * 64 + row) * 256) + c_log * 16) : RD_OOB;
+        asm volatile("" : "+v"(voff));
+        rd_lds_dma16(rs, (float*)(lds + pi * RD_UPC_SLOT + ii * 1024), (int)voff, 0);
+      }
+    }
+    rd_dma_landed();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int pd = 0; pd < 2; ++pd) {
+      // ---- one tile: rows 128 rh .. + 127 of the slab, phase (pd, ph, pw), all 64 channels
+      const int g0 = (pd * 4 + ph * 2 + pw) * 64;     // first k-step of the phase in the weight image
+      f32x16 acc[4][2];
+      {
+        // accumulators start at the bias of their channel: register r of block nb = channel 32 nb + 8 (r >> 2) + 4 lhalf + (r & 3)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *(const f32x4*)(lds + RD_UPC_BIAS + (nb * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+              acc[mb][nb][4 * g + 0] = b4.x; acc[mb][nb][4 * g + 1] = b4.y;
+              acc[mb][nb][4 * g + 2] = b4.z; acc[mb][nb][4 * g + 3] = b4.w;
+            }
+          }
+      }
+      // weight fragments: a queue of four k-steps (8 loads in flight per wave), refilled behind the MFMAs that consumed a slot
+      const char* wph = (const char*)wimg + (long)g0 * 2048;            // wave-uniform
+      u32x4_t bq[4][2];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) rd_upc_wload(bq[s][0], bq[s][1], wph + s * 2048, wvoff);
+#pragma unroll 1
+      for (int t = 0; t < 8; ++t) {
+        // tap t = (td, th, tw): source offsets (pd - 1 + td, ph - 1 + th, pw - 1 + tw)
+        const int od = pd - 1 + (t >> 2), oh = ph - 1 + ((t >> 1) & 1), ow = pw - 1 + (t & 1);
+        int abase[4], aswz[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const int r = 32 * (mb & 1) + l31;          // row inside the plane: h = r >> 3, w = r & 7
+          const bool ok = (unsigned)((r >> 3) + oh) < 8u && (unsigned)((r & 7) + ow) < 8u;
+          const int rsft = r + oh * 8 + ow;
+          const int slot = 2 * rh + (mb >> 1) + 1 + od;
+          abase[mb] = ok ? slot * RD_UPC_SLOT + rsft * 256 : RD_UPC_ZERO;
+          aswz[mb] = ok ? ((rsft & 15) ^ lhalf) : lhalf;
+        }
+        u32x4_t afr[2][4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) afr[0][mb] = *(const u32x4_t*)(lds + abase[mb] + (aswz[mb] << 4));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j + 1 < 8) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+              afr[(j + 1) & 1][mb] = *(const u32x4_t*)(lds + abase[mb] + (((2 * (j + 1)) ^ aswz[mb]) << 4));
+          }
+          rd_upc_wait<6>(bq[j & 3][0], bq[j & 3][1]);          // the two oldest of the eight loads in flight
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, bq[j & 3][0]),
+                                                                 __builtin_bit_cast(rd_bf16x8, afr[j & 1][mb]), acc[mb][0], 0, 0, 0);
+            acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, bq[j & 3][1]),
+                                                                 __builtin_bit_cast(rd_bf16x8, afr[j & 1][mb]), acc[mb][1], 0, 0, 0);
+          }
+          {
+            // refill the slot with k-step t*8 + j + 4 of the tile (past the tile's end: its last k-step again, never used)
+            const int gn = t * 8 + j + 4;
+            rd_upc_wload(bq[j & 3][0], bq[j & 3][1], wph + (long)(gn < 63 ? gn : 63) * 2048, wvoff);
+          }
+        }
+      }
+      // The clamped refills of the last four k-steps are still in flight and nobody will read them: wait for them HERE, naming
+      // their destination registers -- to the compiler those registers are dead behind the loop, and without the operands it
+      // may hand them to the epilogue's temporaries (or schedule epilogue arithmetic above a bare wait) while the loads land.
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]), "+v"(bq[3][0]),
+                     "+v"(bq[3][1]));
+      // ---- epilogue, in registers: lane (l31, lhalf) of block mb holds 32 channels of output row m = 32 mb + l31 of the wave's
+      // 128 rows (channels 32 nb + 8 g + 4 lhalf + 0..3), lane ^ 32 the other 32
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        float ss = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ss = fmaf(acc[mb][nb][r], acc[mb][nb][r], ss);
+        ss += __shfl_xor(ss, 32, 64);                       // + the other half's 32 channels of the same row (lane ^ 32)
+        const float ri = __builtin_amdgcn_rsqf(ss * (1.0f / 64.0f) + 1.0e-8f);       // PixelNormalization (T:255-266)
+        const int r = 32 * (mb & 1) + l31;
+        const int dsrc = d0 + 2 * rh + (mb >> 1);
+        const long pix = (((long)b * 24 + 2 * dsrc + pd) * 16 + 2 * (r >> 3) + ph) * 16 + 2 * (r & 7) + pw;
+        if (lhalf == 0) rinv[pix] = ri;
+        if (dbg) { dbg[pix * 4 + lhalf] = ss; dbg[pix * 4 + 2 + lhalf] = ri; }      // (op-level test hook: both halves' row sums)
+        char* orow = (char*)out + pix * 128 + lhalf * 16;
+#pragma unroll
+        for (int G = 0; G < 8; G += 2) {             // channel groups 8 G .. 8 G + 7 and 8 (G + 1) .. : one 16-byte store per lane
+          unsigned lo[2], hi[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int nb = (G + u) >> 2, g = (G + u) & 3;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = acc[mb][nb][4 * g + e] * ri;
+              v[e] = fmaxf(y, RD_LRELU_ALPHA * y);                                    // LeakyReLU(0.2) (T:333)
+            }
+            lo[u] = rd_pack_bf16(v[0], v[1]); hi[u] = rd_pack_bf16(v[2], v[3]);
+          }
+          // lanes 0-31 keep their group G and take the upper half's group G; lanes 32-63 take the lower half's group G + 1
+          const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(hi[0], hi[1], false, false);
+          const u32x4_t o = {sx[0], sy[0], sx[1], sy[1]};
+          *(u32x4_t*)(orow + G * 16) = o;
+        }
+      }
+    }
+  }
+}
