@@ -141,6 +141,11 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "resident" (default 1; bf16 storage mode): the forward GEMMs of the shared-centre form whose tile holds whole source
  * planes keep the tile's source rows resident in LDS and stream only the weights (each source row is fetched once per
  * channel chunk instead of once per tap and chunk); same arithmetic in the same order, bit-identical to 0.
+ * "upconv_slab" (default 1; bf16 storage mode, ndomain 16, collapsed form): the forward of generator block 3 (128 -> 64
+ * channels onto the 24 x 16 x 16 grid, the dominant launch of the mode) runs in the slab kernel k_upconv_slab16: two source hour
+ * planes + their halo resident in LDS for all 8 phases x 8 taps, weights streamed global -> VGPR in MFMA-fragment order, bias +
+ * PixelNorm + LeakyReLU + bf16 rounding in registers (rdgan_upconv16.hip.h).  Same products as the streaming GEMM it replaces,
+ * summed in another order: outputs agree to one bf16 ulp.  0 = the streaming GEMM (k_conv_gemm_ws<256, 64, ..., bf16>).
  * "edge_kernels" (default 1): the weight gradient of the generator's last conv (64 -> 1) runs on the matrix pipe with the block-3
  * output streamed once (k_g9_wgrad_mfma; ndomain a power of two, otherwise the scalar kernel); the first critic layer (2 -> 64
  * channels, K = 54; one condition channel) runs as one K = 64 GEMM

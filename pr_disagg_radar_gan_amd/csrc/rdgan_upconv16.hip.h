@@ -29,7 +29,8 @@
 #include "rdgan_gemm_ws.hip.h"
 
 #define RD_UPC_SLOT 16384                 // bytes per plane slot
-#define RD_UPC_ZERO (6 * RD_UPC_SLOT)     // a 256-byte row of zeros: taps that fall outside the (h, w) picture
+#define RD_UPC_NSLOT 4                    // plane slots per workgroup: 2 centre planes + 2 halo planes
+#define RD_UPC_ZERO (RD_UPC_NSLOT * RD_UPC_SLOT)     // a 256-byte row of zeros: taps that fall outside the (h, w) picture
 #define RD_UPC_BIAS (RD_UPC_ZERO + 256)   // 64 floats
 #define RD_UPC_LDS (RD_UPC_BIAS + 256)
 
@@ -68,16 +69,28 @@ __device__ __forceinline__ void rd_upc_wait(u32x4_t& d0, u32x4_t& d1) {
 }
 
 // x [B][12][8][8][128] bf16 -> out [B][24][16][16][64] bf16 = LeakyReLU(PixelNorm(upconv(x) + bias)), rinv [B][24][16][16] = 1/l2.
-// grid: min(3 B, CUs) persistent workgroups of 512 threads; dynamic LDS RD_UPC_LDS.  NAMETAG: own symbol for the profiler.
+// Work item = HALF a slab: 2 source hour planes (128 positions) of one sample + their two halo planes (4 plane slots, 64 KB), all
+// 8 phases: four waves, wave q computes the 128 rows x 64 channels of phase (pd, q >> 1, q & 1) for pd = 0, then for pd = 1.
+// 256-thread workgroups, TWO per CU (66 KB of LDS, <= 256 VGPRs): a first version with one 512-thread workgroup per CU (4 centre
+// planes, eight waves) ran every wave of a CU in lock-step -- same work, same start behind the slab barrier -- so all eight
+// epilogues (~700 VALU instructions per wave and tile) came together and the matrix pipe idled through them (with no loads, no
+// LDS reads and no stores at all that version still needed 0.143 ms against 0.082 ms of MFMAs at bs 256).  Two independent
+// workgroups per CU drift apart: one's epilogue, slab load and barriers run beside the other's MFMAs.  (Starting the CUs' second
+// workgroups half a tile late on purpose changed nothing: 0.1774 -> 0.1746 ms at the best delay.)
+// Where the time goes (diagnostic builds -DRD_UPC_ABL_*, scratch/upc_abl.py; bs 2048, one box): K loops without weight loads,
+// LDS reads and epilogue 1.01 ms = 1.65 PFLOP/s -- the matrix pipe at the clock the chip holds under an MFMA-dense loop on random
+// data (1.5-1.7 GHz, MI355X_MICROARCH.md DVFS item 5), i.e. the attainable roof is ~0.66 of the nominal 2.5 PFLOP/s; + weight
+// stream and fragment reads 1.20; + epilogue arithmetic 1.28; + stores 1.36 = the kernel (0.50 of nominal, 0.74 of attainable).
+// grid: min(6 B, 2 CUs) persistent workgroups; dynamic LDS RD_UPC_LDS.  NAMETAG: own symbol for the profiler.
 template <int NAMETAG>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(256, 2)
 k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ wimg, const float* __restrict__ bias,
                 rd_bf16_t* __restrict__ out, float* __restrict__ rinv, int B, float* __restrict__ dbg = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhalf = lane >> 5;
-  const int rh = wave & 1, q = wave >> 1;            // row half (planes 2 rh, 2 rh + 1 of the slab), phase slot
+  const int q = wave;                                // phase slot
   const int ph = q >> 1, pw = q & 1;
 
   if (tid < 64) {
@@ -86,15 +99,15 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
   }
   const unsigned wvoff = (unsigned)lane * 16u;
 
-  for (int slab = blockIdx.x; slab < 3 * B; slab += gridDim.x) {
-    const int b = slab / 3, d0 = (slab - b * 3) * 4;
+  for (int slab = blockIdx.x; slab < 6 * B; slab += gridDim.x) {
+    const int b = slab / 6, d0 = (slab - b * 6) * 2;
     __syncthreads();                                  // every wave has left the previous slab (and the bias / zero rows are in)
     {
-      // the six planes d0 - 1 .. d0 + 4 -> slots 0 .. 5: 96 DMA instructions of 1 KB (4 rows), 12 per wave
+      // the four planes d0 - 1 .. d0 + 2 -> slots 0 .. 3: 64 DMA instructions of 1 KB (4 rows), 16 per wave
       const __amdgpu_buffer_rsrc_t rs = rd_make_rsrc((const float*)(x + (long)b * (12 * 64 * 128)));
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        const int i = wave * 12 + k;                  // wave-uniform
+      for (int k = 0; k < 16; ++k) {
+        const int i = wave * 16 + k;                  // wave-uniform
         const int pi = i >> 4, ii = i & 15;
         const int d = d0 - 1 + pi;
         const int row = ii * 4 + (lane >> 4);
@@ -109,7 +122,7 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
 
 #pragma unroll 1
     for (int pd = 0; pd < 2; ++pd) {
-      // ---- one tile: rows 128 rh .. + 127 of the slab, phase (pd, ph, pw), all 64 channels
+      // ---- one tile: the 128 rows of the two centre planes, phase (pd, ph, pw), all 64 channels
       const int g0 = (pd * 4 + ph * 2 + pw) * 64;     // first k-step of the phase in the weight image
       f32x16 acc[4][2];
       {
@@ -141,7 +154,7 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
           const int r = 32 * (mb & 1) + l31;          // row inside the plane: h = r >> 3, w = r & 7
           const bool ok = (unsigned)((r >> 3) + oh) < 8u && (unsigned)((r & 7) + ow) < 8u;
           const int rsft = r + oh * 8 + ow;
-          const int slot = 2 * rh + (mb >> 1) + 1 + od;
+          const int slot = (mb >> 1) + 1 + od;
           abase[mb] = ok ? slot * RD_UPC_SLOT + rsft * 256 : RD_UPC_ZERO;
           aswz[mb] = ok ? ((rsft & 15) ^ lhalf) : lhalf;
         }
@@ -150,12 +163,21 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
         for (int mb = 0; mb < 4; ++mb) afr[0][mb] = *(const u32x4_t*)(lds + abase[mb] + (aswz[mb] << 4));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+#ifndef RD_UPC_ABL_NOA               // (diagnostic builds, scratch/upc_abl.py: the K loop without its LDS fragment reads)
           if (j + 1 < 8) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
               afr[(j + 1) & 1][mb] = *(const u32x4_t*)(lds + abase[mb] + (((2 * (j + 1)) ^ aswz[mb]) << 4));
           }
+#else
+          if (j + 1 < 8) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) { afr[(j + 1) & 1][mb] = afr[j & 1][mb]; asm volatile("" : "+v"(afr[(j + 1) & 1][mb])); }
+          }
+#endif
+#ifndef RD_UPC_ABL_NOW               // (diagnostic builds: the K loop without its weight stream)
           rd_upc_wait<6>(bq[j & 3][0], bq[j & 3][1]);          // the two oldest of the eight loads in flight
+#endif
 #pragma unroll
           for (int mb = 0; mb < 4; ++mb) {
             acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, bq[j & 3][0]),
@@ -163,11 +185,15 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
             acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, bq[j & 3][1]),
                                                                  __builtin_bit_cast(rd_bf16x8, afr[j & 1][mb]), acc[mb][1], 0, 0, 0);
           }
+#ifndef RD_UPC_ABL_NOW
           {
             // refill the slot with k-step t*8 + j + 4 of the tile (past the tile's end: its last k-step again, never used)
             const int gn = t * 8 + j + 4;
             rd_upc_wload(bq[j & 3][0], bq[j & 3][1], wph + (long)(gn < 63 ? gn : 63) * 2048, wvoff);
           }
+#else
+          asm volatile("" : "+v"(bq[j & 3][0]), "+v"(bq[j & 3][1]));
+#endif
         }
       }
       // The clamped refills of the last four k-steps are still in flight and nobody will read them: wait for them HERE, naming
@@ -176,10 +202,21 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
       asm volatile("s_waitcnt vmcnt(0)"
                    : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]), "+v"(bq[3][0]),
                      "+v"(bq[3][1]));
+#ifdef RD_UPC_ABL_NOEPI              // (diagnostic builds: K loops only; one element of every accumulator keeps the MFMAs alive)
+      {
+        float tsum = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) tsum += acc[mb][0][3] + acc[mb][1][7];
+        if (tsum == 12345.678f) rinv[0] = tsum;
+        continue;
+      }
+#endif
       // ---- epilogue, in registers: lane (l31, lhalf) of block mb holds 32 channels of output row m = 32 mb + l31 of the wave's
       // 128 rows (channels 32 nb + 8 g + 4 lhalf + 0..3), lane ^ 32 the other 32
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
+        // (two-wide float arithmetic -- v_pk_fma_f32 / v_pk_mul_f32, 416 instead of ~700 instructions per tile -- was measured:
+        // 3 % SLOWER, scratch/upc_abl.py; packed fp32 issues at half rate beside the partner's MFMAs)
         float ss = 0.f;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -188,7 +225,7 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
         ss += __shfl_xor(ss, 32, 64);                       // + the other half's 32 channels of the same row (lane ^ 32)
         const float ri = __builtin_amdgcn_rsqf(ss * (1.0f / 64.0f) + 1.0e-8f);       // PixelNormalization (T:255-266)
         const int r = 32 * (mb & 1) + l31;
-        const int dsrc = d0 + 2 * rh + (mb >> 1);
+        const int dsrc = d0 + (mb >> 1);
         const long pix = (((long)b * 24 + 2 * dsrc + pd) * 16 + 2 * (r >> 3) + ph) * 16 + 2 * (r & 7) + pw;
         if (lhalf == 0) rinv[pix] = ri;
         if (dbg) { dbg[pix * 4 + lhalf] = ss; dbg[pix * 4 + 2 + lhalf] = ri; }      // (op-level test hook: both halves' row sums)
@@ -203,7 +240,7 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float y = acc[mb][nb][4 * g + e] * ri;
-              v[e] = fmaxf(y, RD_LRELU_ALPHA * y);                                    // LeakyReLU(0.2) (T:333)
+              v[e] = fmaxf(y, RD_LRELU_ALPHA * y);
             }
             lo[u] = rd_pack_bf16(v[0], v[1]); hi[u] = rd_pack_bf16(v[2], v[3]);
           }
@@ -211,7 +248,11 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
           const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
           const auto sy = __builtin_amdgcn_permlane32_swap(hi[0], hi[1], false, false);
           const u32x4_t o = {sx[0], sy[0], sx[1], sy[1]};
-          *(u32x4_t*)(orow + G * 16) = o;
+#ifdef RD_UPC_ABL_NOST               // (diagnostic builds: no output stores)
+          if (o.x == 0x12345678u)
+#endif
+          *(u32x4_t*)(orow + G * 16) = o;      // (non-temporal stores: 25 % slower -- the four 16-byte pieces of a row's 128-byte line
+          //                                       leave this lane in four instructions and want to meet in L2)
         }
       }
     }

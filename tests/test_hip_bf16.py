@@ -105,6 +105,35 @@ def test_resident_tile_kernel_is_bit_identical(nd, B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [3, 96, 200])
+def test_slab_kernel_equals_the_streaming_gemm_to_one_bf16_ulp(B):
+    """"upconv_slab" (default on at ndomain 16): the forward of generator block 3 in the slab kernel k_upconv_slab16 against the
+    streaming bf16 GEMM of the same engine -- the same bf16 products, summed in another order in fp32 and rounded to bf16 once:
+    the stored block output h3 differs by at most one bf16 ulp (2^-7 relative), in a small share of the elements, and the generator
+    output follows.  B = 96: persistent workgroups walk two work items; B = 200: three."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 53)
+        x, cond, z = ot.synthetic_batch(B, 16, 47)
+        gs = eng.to_slab(g)
+        eng.set_option("bf16", 1)
+        res = {}
+        for slab in (0, 1):
+            eng.set_option("upconv_slab", slab)
+            out = eng.gen_forward(gs, dev(z), dev(cond)).clone()
+            res[slab] = (out, eng.debug_activation(3, (B, 24, 16, 16, 64)).clone())
+            again = eng.gen_forward(gs, dev(z), dev(cond))
+            assert torch.equal(out, again)                                     # run-to-run deterministic
+        (o0, h0), (o1, h1) = res[0], res[1]
+        assert bool(torch.isfinite(h1).all())
+        rel = (h1 - h0).abs() / h0.abs().clamp_min(1e-3)
+        assert float(rel.max()) <= 2.0 ** -7 + 1e-6, float(rel.max())
+        assert float((h1 != h0).float().mean()) < 5e-3
+        assert float((o1 - o0).abs().max()) < 1e-3 * float(o0.max())
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:

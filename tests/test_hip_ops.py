@@ -246,3 +246,39 @@ def test_last_conv_weight_gradient_kernels(nd, B, bf16, kernel):
         return                   # whose four dlogits planes must fit in LDS: ndomain <= 72)
     assert rc == 0
     assert rel_err(dW.cpu().numpy().reshape(3, 3, 3, 64), ref) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_upconv_slab_kernel_vs_oracle(B):
+    """k_upconv_slab16 alone (rdgan_op_upconv_slab16): generator block 3 of the bf16 storage mode -- UpSampling3D(2) + Conv3D(128 ->
+    64, 3x3x3, 'same') + bias + PixelNorm + LeakyReLU(0.2) (T:340-343) on a 12 x 8 x 8 x 128 input -- against the fp64 oracle on the
+    bf16-rounded input.  The kernel rounds the COLLAPSED weights (sums of up to 8 taps) to bf16 and its output to bf16: 2^-8 each,
+    so 2e-2 of the largest output (observed 6e-3); the per-pixel 1/l2 it hands to the backward pass at 1e-2."""
+    g = torch.Generator(); g.manual_seed(100 + B)
+    x = torch.randn((B, 12, 8, 8, 128), generator=g)
+    w = 0.02 * torch.randn((3, 3, 3, 128, 64), generator=g)
+    bias = 0.05 * torch.randn((64,), generator=g)
+    u = ot.upsample3d(x.to(torch.bfloat16).double())
+    pre = ot._conv3d_tf(u, w.double(), bias.double(), 1, (1, 1, 1), u.shape[1:4])
+    ref = ot._lrelu(ot.pixel_norm(pre)).numpy()
+    rinv_ref = (1.0 / torch.sqrt((pre * pre).mean(-1) + 1e-8)).numpy()
+    xd, wd, bd = dev(x.numpy()), dev(w.numpy()), dev(bias.numpy())
+    y = torch.full((B, 24, 16, 16, 64), float("nan"), device="cuda")
+    rinv = torch.full((B, 24, 16, 16), float("nan"), device="cuda")
+    rc = lib().rdgan_op_upconv_slab16(ptr(xd), ptr(wd), ptr(bd), ptr(y), ptr(rinv), ptr(None), B, stream())
+    assert rc == 0
+    assert rel_err(y.cpu().numpy(), ref) < 2e-2
+    assert rel_err(rinv.cpu().numpy(), rinv_ref) < 1e-2
+    # one-hot probe: a single kernel tap and channel pair must move exactly the source voxel the definition names into the output
+    x1 = torch.zeros((1, 12, 8, 8, 128)); x1[..., 77] = (torch.arange(12 * 64, dtype=torch.float32).reshape(1, 12, 8, 8) % 251) + 1
+    for tap in (0, 13, 26, 5):
+        w1 = torch.zeros((3, 3, 3, 128, 64)); w1[tap // 9, (tap // 3) % 3, tap % 3, 77, 5] = 1.0
+        u1 = ot.upsample3d(x1.double())
+        want = ot._conv3d_tf(u1, w1.double(), torch.zeros(64).double(), 1, (1, 1, 1), u1.shape[1:4])[..., 5].numpy()
+        xd, wd, bd = dev(x1.numpy()), dev(w1.numpy()), dev(np.zeros(64, np.float32))
+        dbg = torch.zeros((24 * 256, 4), device="cuda")
+        y1 = torch.empty((1, 24, 16, 16, 64), device="cuda"); r1 = torch.empty((1, 24, 16, 16), device="cuda")
+        assert lib().rdgan_op_upconv_slab16(ptr(xd), ptr(wd), ptr(bd), ptr(y1), ptr(r1), ptr(dbg), 1, stream()) == 0
+        got = dbg.cpu().numpy().reshape(1, 24, 16, 16, 4)
+        np.testing.assert_array_equal(got[..., 0], got[..., 1])                  # both lane halves of a row hold the same sum
+        np.testing.assert_allclose(np.sqrt(got[..., 0]), want, rtol=0, atol=1e-3), tap
