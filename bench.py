@@ -344,8 +344,9 @@ def main():
         launches = []
         for r in sorted(rows, key=lambda r: -r["ms"]):
             n = max(r["launches"], 1)
-            # the fp32-pipe GEMMs of the bf16 storage mode (Dense, first critic layer, 64 -> 1 conv) are priced against the fp32 peak
-            peak_r = FP32_MFMA_PEAK_TFLOPS if (not bf16 or "bf16" not in r["kernel"] and "ws16" not in r["kernel"]) else pk
+            # the fp32-pipe GEMMs of the bf16 storage mode (Dense, the 64 -> 1 conv's weight gradient) are priced against the fp32 peak
+            on_bf16_pipe = bf16 and ("bf16" in r["kernel"] or "ws16" in r["kernel"]) and "g9_wgrad" not in r["kernel"]
+            peak_r = pk if on_bf16_pipe else FP32_MFMA_PEAK_TFLOPS
             tf = r["gflop"] / max(r["ms"], 1e-9)
             launches.append({"what": r["name"], "kind": r["kind"], "kernel": r["kernel"], "samples": r["batch"],
                              "launches_per_iteration": round(r["launches"] / nprof, 2), "gflop_per_launch": round(r["gflop"] / n, 3),

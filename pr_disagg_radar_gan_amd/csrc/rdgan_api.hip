@@ -1555,7 +1555,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     if (upconv_slab_on(h, l)) {     // block 3, bf16 storage: source slab resident in LDS, weights streamed in fragment order
       ProfScope ps(h, RDGAN_TAG_GCONV3_FWD, st);
       LaunchScope ls(h, pl, RD_KIND_CONV, B, plan_flops(h->plans[pl], B), st);
-      RD_KNAME(h, "k_upconv_slab16");
+      RD_KNAME(h, "k_upconv_slab16<bf16>");
       h->flops_acc += plan_flops(h->plans[pl], B);
       RD_TRY(ensure_lds(h, (const void*)k_upconv_slab16<1>, RD_UPC_LDS));
       hipLaunchKernelGGL(k_upconv_slab16<1>, dim3((unsigned)std::min(6 * B, 512)), dim3(256), RD_UPC_LDS, st, (const rd_bf16_t*)hs[l - 1],

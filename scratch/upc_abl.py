@@ -23,7 +23,7 @@ for B in (256, 2048):
             e.profile_launches(True)
             for _ in range(4):
                 e.gen_forward(gs, zd, cd)
-            rows = [r for r in e.launch_table() if "block3" in r["name"]]
+            rows = [r for r in e.launch_table() if "block3" in r["name"] and r["kind"] == "gemm"]
             e.profile_launches(False)
             tot[n].append(rows[0]["ms"] / rows[0]["launches"])
     for n, v in tot.items():

@@ -25,7 +25,7 @@ for B in (3, 256, 2048):
         eng.profile_launches(True)
         for _ in range(5):
             eng.gen_forward(gs, zd, cd)
-        rows = [r for r in eng.launch_table() if "block3" in r["name"]]
+        rows = [r for r in eng.launch_table() if "block3" in r["name"] and r["kind"] == "gemm"]
         eng.profile_launches(False)
         res[opt] = (out, h3, rows)
     o0, h0, r0 = res[0]; o1, h1, r1 = res[1]
