@@ -984,7 +984,7 @@ static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, fl
     const int bt = std::max(64, std::min(256, (C + 63) / 64 * 64));
     hipLaunchKernelGGL(k_colsum_partial_any, dim3((unsigned)nblk, (C + bt - 1) / bt), dim3(bt), 0, st, src, rows, C, h->cpartial, rpb);
   }
-  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 15) / 16), dim3(256), 0, st, h->cpartial, (int)nblk, C, out);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 15) / 16), dim3(rd_reduce_threads((int)nblk)), 0, st, h->cpartial, (int)nblk, C, out);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -1673,17 +1673,23 @@ static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st)
   if (h->cver_in != 0 && dp == h->ccache_ptr && h->cver_in == h->ccache_ver && ccfg == h->ccache_cfg) return 0;
   h->form_builds[1]++;
   h->ccache_ptr = dp; h->ccache_ver = h->cver_in; h->ccache_cfg = ccfg;
-  for (int l = 2; l <= 4; ++l)   // [27][Cin][Cout] -> [27][Cout][Cin]
-    RD_TRY(launch_transpose(h, dp + h->doff[2 * (l - 1)], h->DWT[l], 27, h->dch[l - 1], h->dch[l], h->dch[l - 1], st));
-  // W1 [27*Cin][64] -> W1T [64][ldp1] (columns (tap,ci), zero padded)
-  RD_TRY(launch_transpose(h, dp + h->doff[0], h->W1T, 1, 27 * h->Cin, 64, h->ldp1, st));
+  if (!h->a16) {       // fp32 storage: transposed kernels of the input-gradient GEMMs (the bf16 storage mode reads bf16 images instead)
+    for (int l = 2; l <= 4; ++l)   // [27][Cin][Cout] -> [27][Cout][Cin]
+      RD_TRY(launch_transpose(h, dp + h->doff[2 * (l - 1)], h->DWT[l], 27, h->dch[l - 1], h->dch[l], h->dch[l - 1], st));
+    // W1 [27*Cin][64] -> W1T [64][ldp1] (columns (tap,ci), zero padded)
+    RD_TRY(launch_transpose(h, dp + h->doff[0], h->W1T, 1, 27 * h->Cin, 64, h->ldp1, st));
+  }
   if (h->CP != h->Cin) hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, dp + h->doff[0], h->W1P, h->Cin, h->CP);
   if (h->a16) {
+    // layers 2-4 in ONE launch per image kind (forward [27][Cout][Cin], input gradient [27][Cin][Cout]): 3 launches per build
+    // instead of 11 -- the critic's forms are rebuilt after each of its n_critic updates per iteration
+    RdW3 a;
     for (int l = 2; l <= 4; ++l) {
-      const float* w = dp + h->doff[2 * (l - 1)];
-      RD_TRY(launch_weights_to_bf16_t(h, w, h->bWF[l], 27, h->dch[l - 1], h->dch[l], st));
-      RD_TRY(launch_to_bf16(h, w, h->bWB[l], 27L * h->dch[l - 1] * h->dch[l], st));
+      a.in[l - 2] = dp + h->doff[2 * (l - 1)];
+      a.outT[l - 2] = (unsigned short*)h->bWF[l]; a.outC[l - 2] = (unsigned short*)h->bWB[l];
+      a.K[l - 2] = h->dch[l - 1]; a.N[l - 2] = h->dch[l];
     }
+    hipLaunchKernelGGL(k_weights3_to_bf16, dim3(8, 8, 3 * 27), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_w1_to_bf16, dim3(ew_blocks(64L * h->ldp1)), dim3(256), 0, st, dp + h->doff[0], (rd_bf16_t*)h->bW1B,
                        27 * h->Cin, h->ldp1);
   }
@@ -2016,7 +2022,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       else hipLaunchKernelGGL(k_g9_wgrad_pairs<float>, dim3(nwg), dim3(256), lds, st, h->dl, (const float*)h->h3, h->wpartial,
                               RDGAN_NHOURS, nd, nd, nunits);
     }
-    hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(256), 0, st, h->wpartial, nwg, 1728, grad + h->goff[8]);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(rd_reduce_threads(nwg)), 0, st, h->wpartial, nwg, 1728, grad + h->goff[8]);
   } else {
     {
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
@@ -2440,7 +2446,7 @@ extern "C" int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, in
     }
   }
   if (rc == 0) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(256), 0, st, partial, nwg, 1728, dW);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((1728 + 15) / 16), dim3(rd_reduce_threads(nwg)), 0, st, partial, nwg, 1728, dW);
     rc = (int)hipGetLastError();
   }
   if (rc == 0) rc = (int)hipStreamSynchronize(st);

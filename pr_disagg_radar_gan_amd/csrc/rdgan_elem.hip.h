@@ -568,30 +568,34 @@ __global__ void k_colsum_partial_any(const float* __restrict__ src, long rows, i
   if (r < r1) s0 += src[r * C + c];
   partial[(long)blockIdx.x * C + c] = s0 + s1;
 }
-// stage 2: out[c] = sum_k partial[k][c]; block = 16 columns x 16 partial groups, folded in a fixed order
-__global__ void __launch_bounds__(256)
+// stage 2: out[c] = sum_k partial[k][c]; block = 16 columns x G partial groups (G = blockDim.x / 16: 16, or 64 when there are
+// hundreds of partial rows -- the fold is a chain of dependent loads: with 16 groups, 1024 rows of bias-gradient partials took 20 us
+// on 4-16 workgroups), folded in a fixed order
+__global__ void __launch_bounds__(1024)
 k_reduce_partials(const float* __restrict__ partial, int nsplit, int n, float* __restrict__ out) {
-  __shared__ float red[256];
+  __shared__ float red[1024];
+  const int G = blockDim.x >> 4;
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < n) {
     int k = g;
     // four independent partial sums per thread: four loads in flight (with two, folding 768 slabs took 27 us of latency)
-    for (; k + 48 < nsplit; k += 64) {
-      const float a0 = partial[(long)k * n + c], a1 = partial[(long)(k + 16) * n + c];
-      const float a2 = partial[(long)(k + 32) * n + c], a3 = partial[(long)(k + 48) * n + c];
+    for (; k + 3 * G < nsplit; k += 4 * G) {
+      const float a0 = partial[(long)k * n + c], a1 = partial[(long)(k + G) * n + c];
+      const float a2 = partial[(long)(k + 2 * G) * n + c], a3 = partial[(long)(k + 3 * G) * n + c];
       s0 += a0; s1 += a1; s2 += a2; s3 += a3;
     }
-    for (; k < nsplit; k += 16) s0 += partial[(long)k * n + c];
+    for (; k < nsplit; k += G) s0 += partial[(long)k * n + c];
   }
   red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0 && c < n) {
     float s = red[threadIdx.x];
-    for (int j = 1; j < 16; ++j) s += red[j * 16 + threadIdx.x];
+    for (int j = 1; j < G; ++j) s += red[j * 16 + threadIdx.x];
     out[c] = s;
   }
 }
+static inline int rd_reduce_threads(int nsplit) { return nsplit >= 192 ? 1024 : 256; }
 
 // col2im of the D1 input gradient restricted to the sample channel (channel 0):
 // g0[b][pos] = sum over taps t with (pos - t) even and o = (pos - t)/2 inside D1's output of
@@ -932,6 +936,35 @@ __global__ void k_weights_to_bf16_t(const float* __restrict__ in, unsigned short
       out[(t * N + n) * K + k] = __builtin_bit_cast(unsigned short, v);
     }
   }
+}
+// The critic's layers 2-4 in one launch: per layer l (blockIdx.z / 27) and tap (blockIdx.z % 27) the transposed bf16 image
+// outT[tap][n][k] (forward GEMMs) AND the plain bf16 copy outC[tap][k][n] (input-gradient GEMMs) of in[tap][k][n]; 32 x 32 tiles
+// through LDS, grid (8, 8, 81) covers K, N <= 256 in tile-strided loops
+struct RdW3 { const float* in[3]; unsigned short* outT[3]; unsigned short* outC[3]; int K[3], N[3]; };
+__global__ void k_weights3_to_bf16(RdW3 a) {
+  __shared__ float tile[32][33];
+  const int l = blockIdx.z / 27;
+  const long t = blockIdx.z % 27;
+  const int K = a.K[l], N = a.N[l];
+  const float* in = a.in[l];
+  unsigned short* outT = a.outT[l];
+  unsigned short* outC = a.outC[l];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k0 = blockIdx.y * 32; k0 < K; k0 += gridDim.y * 32)
+    for (int n0 = blockIdx.x * 32; n0 < N; n0 += gridDim.x * 32) {
+      __syncthreads();
+      for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, n = n0 + tx;
+        const float v = (k < K && n < N) ? in[(t * K + k) * N + n] : 0.f;
+        tile[i][tx] = v;
+        if (k < K && n < N) outC[(t * K + k) * N + n] = __builtin_bit_cast(unsigned short, (__bf16)v);
+      }
+      __syncthreads();
+      for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, k = k0 + tx;
+        if (n < N && k < K) outT[(t * N + n) * K + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][i]);
+      }
+    }
 }
 // out[q][:] = bf16(in[map[q]][:]) for q < gridDim.y, cc floats per block (cc % 8 == 0): the input-gradient weight forms of the
 // bf16 conv GEMM are the forward forms U themselves ([Cin][Cout] = [N][K] of that GEMM), re-ordered by tap
