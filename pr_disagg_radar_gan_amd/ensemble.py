@@ -29,10 +29,15 @@ def crps_ensemble_device(ens, obs, scale=None):
     return out
 
 
-def generate_ensemble_device(gen, cond_norm, n_members, chunk=1024, seed=None):
+def generate_ensemble_device(gen, cond_norm, n_members, chunk=1024, seed=None, latent=None):
     """n_members generator samples for ONE normalised condition (nd,nd,1); returns the (n,24,nd,nd) fractions on the
-    device.  Latent noise from the global numpy RNG (as reference :183) unless a torch seed is given."""
+    device.  Latent noise from the global numpy RNG (as reference :183) unless a torch seed is given, or `latent`
+    (n_members, 100; numpy or a tensor) supplies it -- the reference's same-noise comparison, generate_and_evaluate.py:551-560."""
     nd = gen.ndomain
+    if latent is not None:
+        latent = torch.as_tensor(latent, dtype=torch.float32)
+        if tuple(latent.shape) != (n_members, W.LATENT_DIM):
+            raise ValueError(f"latent must have shape ({n_members}, {W.LATENT_DIM}), got {tuple(latent.shape)}")
     eng = models.get_engine(nd, min(chunk, n_members))
     slab = gen.device_slab(eng)
     cond_t = torch.from_numpy(np.ascontiguousarray(cond_norm, dtype=np.float32).reshape(1, nd, nd, 1)).to(eng.device)
@@ -42,13 +47,27 @@ def generate_ensemble_device(gen, cond_norm, n_members, chunk=1024, seed=None):
         g = torch.Generator(device=eng.device); g.manual_seed(int(seed))
     for i in range(0, n_members, eng.max_batch):
         m = min(eng.max_batch, n_members - i)
-        if g is None:
+        if latent is not None:
+            z = latent[i:i + m].to(eng.device).contiguous()
+        elif g is None:
             z = torch.from_numpy(np.random.normal(size=(m, W.LATENT_DIM)).astype(np.float32)).to(eng.device)
         else:
             z = torch.randn((m, W.LATENT_DIM), generator=g, device=eng.device)
         eng.gen_forward(slab, z, cond_t.expand(m, nd, nd, 1).contiguous(), out=out[i:i + m])
         eng.check_numerics()                     # reference T:349-350
     return out.view(n_members, W.NHOURS, nd, nd)
+
+
+def generate_same_noise_pair(gen, cond1_norm, cond2_norm, n_members=1000, latent=None):
+    """The reference's condition-sensitivity experiment (generate_and_evaluate.py:551-560): ONE latent block (n_members, 100)
+    drawn once from the global numpy RNG (:550), pushed through the generator under two different normalised conditions, so that
+    differences between the two ensembles come from the condition alone.  Returns (fractions1, fractions2, latent), the
+    fractions (n,24,nd,nd) on the device."""
+    if latent is None:
+        latent = np.random.normal(size=(n_members, W.LATENT_DIM)).astype(np.float32)
+    f1 = generate_ensemble_device(gen, cond1_norm, n_members, latent=latent)
+    f2 = generate_ensemble_device(gen, cond2_norm, n_members, latent=latent)
+    return f1, f2, latent
 
 
 def crps_for_day(gen, real_precip, n_fake_per_real=1000, norm_scale=W.NORM_SCALE, seed=None):

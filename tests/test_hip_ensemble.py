@@ -40,3 +40,29 @@ def test_crps_for_day_pipeline():
     precip = frac * real.sum(0)[None, None]
     ref = od.crps_ensemble(real, precip).mean(axis=(1, 2))
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-6)
+
+
+def test_same_noise_two_conditions():
+    """reference generate_and_evaluate.py:551-560: one latent block under two conditions; each ensemble equals the oracle's
+    generator on (latent, cond_i), and a second call with the returned latent reproduces the first bit for bit."""
+    from pr_disagg_radar_gan_amd import gan_train_cwgangp_pixelnorm as T
+    from pr_disagg_radar_gan_amd import ensemble
+    T.configure(ndomain=16)
+    gen = T.create_generator(seed=5)
+    rng = np.random.default_rng(3)
+    c1 = rng.gamma(0.5, 0.2, (16, 16, 1)).astype(np.float32)
+    c2 = rng.gamma(0.5, 0.2, (16, 16, 1)).astype(np.float32)
+    n = 40
+    np.random.seed(17)
+    f1, f2, z = ensemble.generate_same_noise_pair(gen, c1, c2, n_members=n)
+    np.random.seed(17)
+    assert np.array_equal(z, np.random.normal(size=(n, 100)).astype(np.float32))          # drawn once, reference :550
+    params = [w.astype(np.float64) for w in gen.get_weights()]
+    for f, c in ((f1, c1), (f2, c2)):
+        ref = onp.generator_forward(params, z.astype(np.float64), np.repeat(c[None].astype(np.float64), n, axis=0))
+        np.testing.assert_allclose(f.cpu().numpy(), ref.reshape(n, 24, 16, 16), rtol=2e-4, atol=2e-6)
+    assert not torch.equal(f1, f2)
+    g1, g2, _ = ensemble.generate_same_noise_pair(gen, c1, c2, n_members=n, latent=z)
+    assert torch.equal(f1, g1) and torch.equal(f2, g2)
+    with pytest.raises(ValueError):
+        ensemble.generate_ensemble_device(gen, c1, n, latent=z[:-1])
