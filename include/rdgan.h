@@ -146,6 +146,14 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * planes + their halo resident in LDS for all 8 phases x 8 taps, weights streamed global -> VGPR in MFMA-fragment order, bias +
  * PixelNorm + LeakyReLU + bf16 rounding in registers (rdgan_upconv16.hip.h).  Same products as the streaming GEMM it replaces,
  * summed in another order: outputs agree to one bf16 ulp.  0 = the streaming GEMM (k_conv_gemm_ws<256, 64, ..., bf16>).
+ * "d2_slab" (default 1; bf16 storage mode, ndomain 16): the input gradient of the critic's second layer (128 -> 64 channels onto
+ * the 11 x 7 x 7 grid, eight parity phases of 8 ... 1 taps) runs in the slab kernel k_d2_dgrad_slab16: two samples' output
+ * gradient resident in LDS for all phases and taps, weights streamed in MFMA-fragment order, LeakyReLU' x dropout gate + bf16
+ * rounding in registers (rdgan_d2slab16.hip.h).  Same taps and k order as the streaming GEMM (0).
+ * "d1_wgrad16" (default 1; bf16 storage mode, one condition channel): the first critic layer's weight gradient runs on the bf16
+ * matrix pipe (k_d1_wgrad16: im2col rows rounded to bf16 as in the layer's forward GEMM, both operands read transposed from
+ * position-major LDS images) and delivers the layer's bias gradient from a ones column of the same product; 0 = the fp32-pipe
+ * kernel k_d1_gemm_wgrad<bf16> + a column-sum pass.
  * "edge_kernels" (default 1): the weight gradient of the generator's last conv (64 -> 1) runs on the matrix pipe with the block-3
  * output streamed once (k_g9_wgrad_mfma; ndomain a power of two, otherwise the scalar kernel); the first critic layer (2 -> 64
  * channels, K = 54; one condition channel) runs as one K = 64 GEMM
@@ -274,6 +282,12 @@ int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, int B, int nd
  * back as fp32 (the bf16 output widened), rinv [B,24,16,16] = 1/l2 per grid point; dbg: NULL, or [B*24*16*16][4] floats (test
  * hook: row sum of squares and 1/l2 as the two lane halves of a row computed them). */
 int rdgan_op_upconv_slab16(const float* x, const float* w, const float* bias, float* y, float* rinv, float* dbg, int B, void* stream);
+/* Input gradient of the critic's second layer (backward of T:291, Conv3D(128, 3x3x3, stride 2, 'same') on the 11 x 7 x 7 x 64
+ * output of layer 1, ndomain 16) through the slab kernel of the bf16 storage mode alone (k_d2_dgrad_slab16): gy [B,6,4,4,128], the
+ * layer's kernel w [3,3,3,64,128] and aux [B,11,7,7,64] (layer 1's output) are rounded to bf16 on the device;
+ * gx [B,11,7,7,64] = conv3d_input_grad(gy, w) * gate(aux), as fp32; gate = LeakyReLU'(aux), and with use_drop != 0 aux is read as
+ * a stored post-dropout activation: +0.0 = dropped (gate 0), anything else kept (gate LeakyReLU'(aux) / 0.75). */
+int rdgan_op_d2_dgrad_slab16(const float* gy, const float* w, const float* aux, float* gx, int B, int use_drop, void* stream);
 /* PixelNormalization + LeakyReLU(0.2) forward (T:255-266, T:333) and its backward. C in {64,128,256}. */
 int rdgan_op_pixelnorm_lrelu(const float* y, float* h, float* rinv, long npix, int C, void* stream);
 int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* rinv, float* dy,

@@ -20,6 +20,7 @@
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
 #include "rdgan_edge.hip.h"
+#include "rdgan_d2slab16.hip.h"
 static_assert(RDGAN_LOSS_SLOTS == 8, "k_critic_losses / k_gen_loss write slots 0..7");
 // k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
 static bool g9w_mfma_ok(int nd, long npix) { return nd >= 8 && nd <= 128 && (nd & (nd - 1)) == 0 && npix < 0x7FFFFFFFL; }
@@ -389,6 +390,9 @@ struct rdgan_handle {
   void *bG1F[4], *bG1B, *bW1B;
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
+  void* bW2S;                     // weight image of the slab kernel of critic layer 2's input gradient (rdgan_d2slab16.hip.h): 432 KB
+  int d1_wgrad16 = 1;             // 1: bf16 storage mode: layer-1 weight gradient + bias gradient on the bf16 matrix pipe (k_d1_wgrad16)
+  int d2_slab = 1;                // 1: bf16 storage mode, ndomain 16: input gradient of critic layer 2 by k_d2_dgrad_slab16
   int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
   int g9_direct = 1;              // 1: backward of the 64 -> 1 conv straight from the dlogits (no im2col matrix), fused with block 3's PixelNorm backward
   int fast_fwd = -1;              // 1: forward of generator blocks 2, 3 as shared part T = S x + difference part (48 instead of 64 tap products); -1: by storage mode
@@ -1238,6 +1242,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
         carve(p, 32L * h->ldp1 + 8); h->bW1B = p;
         carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3I = p;
+        carve(p, (long)RD_D2S_KSTEPS * 2 * 64 * 4 + 8); h->bW2S = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
     }
@@ -1305,6 +1310,8 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "d1_wgrad16")) { h->d1_wgrad16 = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "d2_slab")) { h->d2_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
   if (!strcmp(name, "dense_wgrad_slices")) { h->dense_slices = value; return 0; }
   if (!strcmp(name, "keep_gates")) {
     h->keep_gates = value ? 1 : 0;
@@ -1667,9 +1674,10 @@ extern "C" int rdgan_check_numerics(rdgan_handle* h, void* stream) {
 // ------------------------------------------------------------------------------------
 // critic
 // ------------------------------------------------------------------------------------
+static bool d2_slab_on(const rdgan_handle* h) { return h->d2_slab && h->a16 && h->nd == 16; }
 static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st) {
   // (skipped when the forms in the workspace were built from these very weights: see rdgan_set_weight_versions)
-  const int ccfg = h->a16 ? 1 : 0;
+  const int ccfg = (h->a16 ? 1 : 0) | (h->d2_slab ? 2 : 0);
   if (h->cver_in != 0 && dp == h->ccache_ptr && h->cver_in == h->ccache_ver && ccfg == h->ccache_cfg) return 0;
   h->form_builds[1]++;
   h->ccache_ptr = dp; h->ccache_ver = h->cver_in; h->ccache_cfg = ccfg;
@@ -1690,6 +1698,8 @@ static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st)
       a.K[l - 2] = h->dch[l - 1]; a.N[l - 2] = h->dch[l];
     }
     hipLaunchKernelGGL(k_weights3_to_bf16, dim3(8, 8, 3 * 27), dim3(256), 0, st, a);
+    if (d2_slab_on(h))
+      hipLaunchKernelGGL(k_d2s_wimg, dim3((RD_D2S_KSTEPS * 2 * 64 + 255) / 256), dim3(256), 0, st, dp + h->doff[2], (unsigned short*)h->bW2S);
     hipLaunchKernelGGL(k_w1_to_bf16, dim3(ew_blocks(64L * h->ldp1)), dim3(256), 0, st, dp + h->doff[0], (rd_bf16_t*)h->bW1B,
                        27 * h->Cin, h->ldp1);
   }
@@ -1725,9 +1735,26 @@ static int launch_d1_fwd(rdgan_handle* h, const float* in, const float* w, const
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
-static int launch_d1_wgrad(rdgan_handle* h, const float* in, const float* u1, float* dW, int NBt, hipStream_t st) {
+// bf16 storage mode: the layer-1 weight gradient on the bf16 matrix pipe, bias gradient (rows < bias_rows) in the same pass
+static bool d1_wgrad16_on(const rdgan_handle* h) { return h->a16 && h->d1_wgrad16; }
+static int launch_d1_wgrad(rdgan_handle* h, const float* in, const float* u1, float* dW, int NBt, hipStream_t st,
+                           float* db = nullptr, long bias_rows = 0) {
   ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
   const long rows = (long)NBt * h->dL[1];
+  if (d1_wgrad16_on(h)) {
+    LaunchScope ls(h, PL_D1F, RD_KIND_WGRAD, NBt, 2.0 * rows * 54 * 64, st);
+    RD_KNAME(h, "k_d1_wgrad16<bf16>");
+    h->flops_acc += 2.0 * rows * 54 * 64;
+    long G = std::min<long>(1024, (rows + 63) / 64);
+    long rpw = ((rows + G - 1) / G + 63) / 64 * 64;
+    G = (rows + rpw - 1) / rpw;
+    if ((size_t)G * 4096 > h->wpartial_cap) return bad_arg(h, "d1 wgrad: partial workspace too small");
+    hipLaunchKernelGGL(k_d1_wgrad16, dim3((unsigned)G), dim3(256), 0, st, in, (const rd_bf16_t*)u1, h->wpartial, rows, rpw,
+                       db ? bias_rows : 0L, h->nd, h->ddim[1][0], h->ddim[1][1], h->ddim[1][2]);
+    hipLaunchKernelGGL(k_d1_wgrad_fold, dim3((db ? 55 : 54) * 64 / 16), dim3(256), 0, st, h->wpartial, (int)G, dW, db);
+    RD_CHECK(h, hipGetLastError());
+    return 0;
+  }
   LaunchScope ls(h, PL_D1F, RD_KIND_WGRAD, NBt, 2.0 * rows * 54 * 64, st);
   RD_KNAME(h, "k_d1_gemm_wgrad<%s>", h->a16 ? "bf16" : "f32");
   h->flops_acc += 2.0 * rows * 54 * 64;
@@ -1792,6 +1819,18 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
     int pl = PL_D2B + l - 2;
     RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, h->dh[l - 1], use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 2), 0);
     ep.out16 = a16;
+    if (l == 2 && d2_slab_on(h)) {      // two samples' output gradient resident in LDS, weights streamed in fragment order
+      ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+      LaunchScope ls(h, pl, RD_KIND_CONV, NBt, plan_flops(h->plans[pl], NBt), st);
+      RD_KNAME(h, "k_d2_dgrad_slab16<bf16>");
+      h->flops_acc += plan_flops(h->plans[pl], NBt);
+      RD_TRY(ensure_lds(h, (const void*)k_d2_dgrad_slab16, RD_D2S_LDS));
+      hipLaunchKernelGGL(k_d2_dgrad_slab16, dim3((unsigned)std::min((NBt + 1) / 2, 512)), dim3(256), RD_D2S_LDS, st,
+                         (const rd_bf16_t*)h->du[2], (const rd_bf16_t*)h->bW2S, (const rd_bf16_t*)h->dh[1], (rd_bf16_t*)h->du[1], NBt,
+                         use_drop, ep.key, ep.idx_base);
+      RD_CHECK(h, hipGetLastError());
+      continue;
+    }
     if (a16)
       RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->bWB[l], h->du[l - 1], ep, st, RDGAN_TAG_CRITIC_GEMM));
     else
@@ -1870,8 +1909,10 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   // GEMMs below (nothing below writes du[l]; the column-sum scratch is used by these launches only)
   {
     hipStream_t cs = side_fork(h, st);
-    for (int l = 1; l <= 4; ++l)
+    for (int l = 1; l <= 4; ++l) {
+      if (l == 1 && d1_gemm_ok(h) && d1_wgrad16_on(h)) continue;      // comes out of the weight-gradient GEMM (k_d1_wgrad16)
       RD_TRY(launch_colsum(h, h->du[l], (long)2 * B * h->dL[l], h->dch[l], grad + h->doff[2 * (l - 1) + 1], cs, h->a16 != 0));
+    }
   }
   // gradient penalty (T:238-241, T:382): g0 = dD/dx_hat, n = ||g0||, r0 = d(10 mean((n-1)^2))/dg0
   RD_TRY(critic_input_grad(h, act_off(h, h->du[1], (long)2 * B * h->dL[1] * 64), B, st));
@@ -1921,7 +1962,7 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
     const float* in = l == 1 ? h->cin : h->dh[l - 1];
     const bool padded = l == 1 && h->CP != h->Cin;   // D1 with padding channels: gradient of the padded kernel, then drop the pad rows
     if (l == 1 && d1_gemm_ok(h)) {
-      RD_TRY(launch_d1_wgrad(h, in, h->du[1], grad + h->doff[0], NBt, st));
+      RD_TRY(launch_d1_wgrad(h, in, h->du[1], grad + h->doff[0], NBt, st, grad + h->doff[1], (long)2 * B * h->dL[1]));
     } else if (a16 && l >= 2) {      // layers 2-4: bf16 activations against bf16 output gradients
       if (!wgrad16_ok(h->plans[pl], NBt)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this critic layer");
       RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], grad + h->doff[2 * (l - 1)], h->wpartial,
@@ -2483,6 +2524,37 @@ extern "C" int rdgan_op_upconv_slab16(const float* x, const float* w, const floa
   }
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   for (void* p : {xb, yb, wi, (void*)wc}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// Input gradient of the critic's second layer through the slab kernel alone (rdgan_d2slab16.hip.h), ndomain 16: gy [B,6,4,4,128],
+// the layer's kernel w [3,3,3,64,128] and the gating activation aux [B,11,7,7,64] (layer 1's output) are rounded to bf16 on the
+// device; gx [B,11,7,7,64] = conv3d_input_grad(gy, w; stride 2, 'same') * gate(aux) comes back as fp32 (the kernel's bf16 output
+// widened).  gate = LeakyReLU'(aux); with use_drop, aux is a stored post-dropout activation (rd_drop_apply: +0.0 = dropped) and
+// gate = 0 for dropped elements, LeakyReLU'(aux) / 0.75 for kept ones (rd_gate_from_out).
+extern "C" int rdgan_op_d2_dgrad_slab16(const float* gy, const float* w, const float* aux, float* gx, int B, int use_drop, void* stream) {
+  if (!gy || !w || !aux || !gx || B < 1) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long ny = (long)B * RD_D2S_SROWS * 128, nx = (long)B * RD_D2S_OPOS * 64;
+  void *yb = nullptr, *ab = nullptr, *xb = nullptr, *wi = nullptr;
+  int rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc(&ab, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&wi, (long)RD_D2S_KSTEPS * 2 * 64 * 16);
+  if (rc == 0) rc = launch_to_bf16(nullptr, gy, yb, ny, st);
+  if (rc == 0) rc = launch_to_bf16(nullptr, aux, ab, nx, st);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_d2s_wimg, dim3((RD_D2S_KSTEPS * 2 * 64 + 255) / 256), dim3(256), 0, st, w, (unsigned short*)wi);
+    rc = ensure_lds(nullptr, (const void*)k_d2_dgrad_slab16, RD_D2S_LDS);
+  }
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_d2_dgrad_slab16, dim3((unsigned)std::min((B + 1) / 2, 512)), dim3(256), RD_D2S_LDS, st, (const rd_bf16_t*)yb,
+                       (const rd_bf16_t*)wi, (const rd_bf16_t*)ab, (rd_bf16_t*)xb, B, use_drop != 0, 0u, 0u);
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(nx)), dim3(256), 0, st, (const rd_bf16_t*)xb, gx, nx);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {yb, ab, xb, wi}) if (p) (void)hipFree(p);
   return rc;
 }
 

@@ -1,0 +1,247 @@
+// bf16 storage mode, ndomain 16: input gradient of the critic's second layer (T:291: Conv3D(128, 3x3x3, stride 2, 'same') on
+// the 11 x 7 x 7 x 64 output of layer 1 -> 6 x 4 x 4 x 128) as a SLAB kernel in the pattern of k_upconv_slab16.
+//
+// Why.  By input parity the gradient splits into 8 phases of 8, 4, 4, 2, 4, 2, 2, 1 taps (plan_conv_dgrad_s2), each a GEMM with
+// N = 64 output channels and K = taps x 128.  As tiles of the streaming kernel (k_conv_gemm_ws<256, 64, ..., bf16>) that is
+// 12 936 workgroups of 2-16 K chunks each at 6144 samples: all prologue and epilogue, 0.58 ms = 0.11 of the bf16 roof, the slowest
+// launch per FLOP of BASELINE configs[2] (2.9 ms of a 45.8 ms iteration).  Here:
+//   * a workgroup owns TWO samples' output gradient (2 x 96 positions x 128 channels = 48 KB, one contiguous piece of HBM) resident
+//     in LDS for all 8 phases x 27 taps; every tap of every phase is a shifted read of those rows.  With 'same' padding (1,1,1)
+//     and these extents every tap of every phase lands inside the picture: no masks.
+//   * weights: MFMA-fragment order in HBM (k_d2s_wimg, 432 KB, L2-resident), streamed global -> VGPR four k-steps ahead by the
+//     wave that uses them; no barrier inside an item besides the one that publishes the slab.
+//   * operands swapped (weights = A, positions = B): a lane ends up with 32 channels of ONE position, so LeakyReLU' x dropout of
+//     layer 1 (the gate, RD_EPI_GATE_AUX of the streaming kernel: same dropout counter = flat index of the destination) and the
+//     bf16 rounding run in registers, 16-byte stores.
+// Rows of a phase = (sample in the item, position in the phase's 5|6 x 3|4 x 3|4 sub-grid), flattened: 90 ... 192 rows, cut into
+// tiles of 2-4 row blocks of 32 and dealt to the four waves so that taps x blocks + epilogues balance (table rd_d2s_tiles).
+// Same tap order, same k order, same fp32 accumulation as the streaming kernel.
+#pragma once
+#include "rdgan_upconv16.hip.h"
+
+#define RD_D2S_S 2                                    // samples per work item
+#define RD_D2S_SROWS 96                               // source positions per sample (6 x 4 x 4)
+#define RD_D2S_IMG (RD_D2S_S * RD_D2S_SROWS * 256)    // bytes of the resident image
+#define RD_D2S_ZERO RD_D2S_IMG                        // a 256-byte row of zeros: rows past the item's last position
+#define RD_D2S_LDS (RD_D2S_IMG + 256)
+#define RD_D2S_KSTEPS 216                             // 27 taps x 8 steps of 16 channels
+#define RD_D2S_OPOS 539                               // destination positions per sample (11 x 7 x 7)
+
+// first tap slot of phase cls (phases in plan order: cls = (pd, ph, pw) parity bits of position + pad; taps 8,4,4,2,4,2,2,1)
+__host__ __device__ __forceinline__ int rd_d2s_tap0(int cls) {
+  return (0x1A181612100C0800ull >> (8 * cls)) & 0xFF;   // 0, 8, 12, 16, 18, 22, 24, 26
+}
+
+// Weight image from the layer's kernel w2 [27][64 ci][128 co] (fp32): for k-step g = slot * 8 + j (slot = tap in phase order,
+// j = 16-channel step of co) and block nb of 32 ci, lane l holds the 8 bf16 w2[tap][32 nb + (l & 31)][16 j + 8 (l >> 5) + e]:
+// the A fragment of v_mfma_f32_32x32x16_bf16 for gx^T = W gy^T.
+__global__ void k_d2s_wimg(const float* __restrict__ w2, unsigned short* __restrict__ wimg) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;                 // (g, nb, lane)
+  if (idx >= RD_D2S_KSTEPS * 2 * 64) return;
+  const int lane = idx & 63, nb = (idx >> 6) & 1, g = idx >> 7;
+  const int j = g & 7, slot = g >> 3;
+  int cls = 7;
+  while (rd_d2s_tap0(cls) > slot) --cls;
+  int rem = slot - rd_d2s_tap0(cls), wtap = 0, mul = 1;
+  for (int a = 2; a >= 0; --a) {                  // axes w, h, d: an axis of parity 0 takes taps 0 and 2 (w fastest), parity 1 tap 1
+    const int pi = (cls >> (2 - a)) & 1;
+    int ta = 1;
+    if (!pi) { ta = 2 * (rem & 1); rem >>= 1; }
+    wtap += ta * mul; mul *= 3;
+  }
+  const int n = nb * 32 + (lane & 31), k0 = j * 16 + (lane >> 5) * 8;
+  const float* s = w2 + ((long)wtap * 64 + n) * 128 + k0;
+  u32x4_t o = {rd_pack_bf16(s[0], s[1]), rd_pack_bf16(s[2], s[3]), rd_pack_bf16(s[4], s[5]), rd_pack_bf16(s[6], s[7])};
+  *(u32x4_t*)(wimg + (long)idx * 8) = o;
+}
+
+// tiles of an item: wave w runs rd_d2s_tiles[w][0..2] = cls | first row << 4 | row blocks << 12
+// (taps x blocks per wave: 24+3+3, 16+6+4, 16+6+4, 16+6+4; row blocks, i.e. epilogues: 9, 9, 9, 9)
+__constant__ int rd_d2s_tiles[4][3] = {
+  {0 | (0 << 4) | (3 << 12), 7 | (0 << 4) | (3 << 12), 7 | (96 << 4) | (3 << 12)},
+  {1 | (0 << 4) | (4 << 12), 3 | (0 << 4) | (3 << 12), 3 | (96 << 4) | (2 << 12)},
+  {2 | (0 << 4) | (4 << 12), 5 | (0 << 4) | (3 << 12), 5 | (96 << 4) | (2 << 12)},
+  {4 | (0 << 4) | (4 << 12), 6 | (0 << 4) | (3 << 12), 6 | (96 << 4) | (2 << 12)},
+};
+
+// one tile: rows row0 .. row0 + 32 MB - 1 of phase cls, all 64 channels
+template <int MB>
+__device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, unsigned wvoff, int cls, int row0, int ns, long b0,
+                                            const rd_bf16_t* __restrict__ aux, rd_bf16_t* __restrict__ out, int use_drop,
+                                            uint32_t key, uint32_t idx_base, int l31, int lhalf) {
+  const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+  const int cd = 5 + pd, chh = 3 + ph, cw = 3 + pw;            // the phase's sub-grid (positions 2 l + 1 - parity)
+  const int chw = chh * cw, cnt = cd * chw;
+  const int rows = ns * cnt;
+  const int ntaps = 8 >> (pd + ph + pw);
+  const int nks = ntaps * 8;
+  int srow[MB];                 // source row of tap offset (0,0,0), or -1
+  int orow[MB];                 // destination row
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int r = row0 + 32 * mb + l31;
+    const int s = r >= cnt ? 1 : 0;
+    const int p = r - s * cnt;
+    const int ld = p / chw, q = p - ld * chw, lh = q / cw, lw = q - lh * cw;
+    srow[mb] = r < rows ? s * RD_D2S_SROWS + ld * 16 + lh * 4 + lw : -1;
+    orow[mb] = ((int)b0 + s) * RD_D2S_OPOS + ((2 * ld + 1 - pd) * 7 + 2 * lh + 1 - ph) * 7 + 2 * lw + 1 - pw;
+  }
+  f32x16 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  const char* wph = wimg + (long)rd_d2s_tap0(cls) * 8 * 2048;        // wave-uniform
+  u32x4_t bq[4][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) rd_upc_wload(bq[s][0], bq[s][1], wph + (s < nks ? s : nks - 1) * 2048, wvoff);
+  int ti = 0;
+#pragma unroll 1
+  for (int tc = 0; tc < 8; ++tc) {
+    const int jd = tc >> 2, jh = (tc >> 1) & 1, jw = tc & 1;
+    if ((jd & pd) | (jh & ph) | (jw & pw)) continue;                  // (wave-uniform) an axis of parity 1 has one tap
+    // source offset of the tap: 1 - j on an axis of parity 0, 0 on an axis of parity 1
+    const int shift = (pd ? 0 : 1 - jd) * 16 + (ph ? 0 : 1 - jh) * 4 + (pw ? 0 : 1 - jw);
+    int abase[MB], aswz[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int rs = srow[mb] + shift;
+      abase[mb] = srow[mb] >= 0 ? rs * 256 : RD_D2S_ZERO;
+      aswz[mb] = srow[mb] >= 0 ? ((rs & 15) ^ lhalf) : lhalf;
+    }
+    u32x4_t afr[2][MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) afr[0][mb] = *(const u32x4_t*)(lds + abase[mb] + (aswz[mb] << 4));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#ifndef RD_D2S_ABL_NOA               // (diagnostic builds, scratch/d2s_abl.py: the K loop without its LDS fragment reads)
+      if (j + 1 < 8) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          afr[(j + 1) & 1][mb] = *(const u32x4_t*)(lds + abase[mb] + (((2 * (j + 1)) ^ aswz[mb]) << 4));
+      }
+#else
+      if (j + 1 < 8) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { afr[(j + 1) & 1][mb] = afr[j & 1][mb]; asm volatile("" : "+v"(afr[(j + 1) & 1][mb])); }
+      }
+#endif
+#ifndef RD_D2S_ABL_NOW               // (diagnostic builds: the K loop without its weight stream)
+      rd_upc_wait<6>(bq[j & 3][0], bq[j & 3][1]);
+#endif
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, bq[j & 3][0]),
+                                                             __builtin_bit_cast(rd_bf16x8, afr[j & 1][mb]), acc[mb][0], 0, 0, 0);
+        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, bq[j & 3][1]),
+                                                             __builtin_bit_cast(rd_bf16x8, afr[j & 1][mb]), acc[mb][1], 0, 0, 0);
+      }
+#ifndef RD_D2S_ABL_NOW
+      {
+        const int gn = ti * 8 + j + 4;            // refill with k-step + 4 of the tile (past its end: the last one again, never used)
+        rd_upc_wload(bq[j & 3][0], bq[j & 3][1], wph + (long)(gn < nks ? gn : nks - 1) * 2048, wvoff);
+      }
+#else
+      asm volatile("" : "+v"(bq[j & 3][0]), "+v"(bq[j & 3][1]));
+#endif
+    }
+    ++ti;
+  }
+  // (the clamped refills are still in flight: see k_upconv_slab16)
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]), "+v"(bq[3][0]),
+                 "+v"(bq[3][1]));
+#ifdef RD_D2S_ABL_NOEPI              // (diagnostic builds: K loops only; one element of every accumulator keeps the MFMAs alive)
+  {
+    float tsum = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) tsum += acc[mb][0][3] + acc[mb][1][7];
+    if (tsum == 12345.678f) out[0] = 1;
+    return;
+  }
+#endif
+  // ---- epilogue in registers: lane (l31, lhalf) of block mb holds channels 32 nb + 8 g + 4 lhalf + 0..3 of its row
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    if (srow[mb] < 0) continue;                   // (lanes l and l ^ 32 share their row: the swaps below see both or neither)
+    const rd_bf16_t* arow = aux + (long)orow[mb] * 64 + 4 * lhalf;
+    const uint32_t ibase = (uint32_t)orow[mb] * 64u + idx_base + 4 * lhalf;
+    char* op = (char*)out + (long)orow[mb] * 128 + lhalf * 16;
+    rd_u32x2 gate[8];
+#pragma unroll
+#ifndef RD_D2S_ABL_NOGATE            // (diagnostic builds: no gate loads)
+    for (int G = 0; G < 8; ++G) gate[G] = *(const rd_u32x2*)(arow + 8 * G);
+#else
+    for (int G = 0; G < 8; ++G) { gate[G].x = 0x3F803F80u + G + orow[mb]; gate[G].y = 0xBF803F80u; }
+#endif
+#pragma unroll
+    for (int G = 0; G < 8; G += 2) {
+      unsigned lo[2], hi[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int nb = (G + u) >> 2, g = (G + u) & 3;
+        const f32x4 ga = rd_unpack_bf16x4(gate[G + u]);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gt = rd_gate_from_out(ga[e], use_drop);
+          v[e] = acc[mb][nb][4 * g + e] * gt;
+        }
+        lo[u] = rd_pack_bf16(v[0], v[1]); hi[u] = rd_pack_bf16(v[2], v[3]);
+      }
+      const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(hi[0], hi[1], false, false);
+      const u32x4_t o = {sx[0], sy[0], sx[1], sy[1]};
+#ifdef RD_D2S_ABL_NOST               // (diagnostic builds: no output stores)
+      if (o.x == 0x12345678u)
+#endif
+      *(u32x4_t*)(op + G * 16) = o;
+    }
+  }
+}
+
+// gy [B][6][4][4][128] bf16 (gradient at layer 2's pre-activation... i.e. h->du[2]) -> gx [B][11][7][7][64] bf16
+// = (sum over taps W[t]^T gy) * LeakyReLU'(aux) * dropout(key, flat index + idx_base); aux = layer 1's output, layout of gx.
+// grid: min((B + 1) / 2, 2 per CU) persistent workgroups of 256 threads; dynamic LDS RD_D2S_LDS.
+__global__ void __launch_bounds__(256, 2)
+k_d2_dgrad_slab16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restrict__ wimg, const rd_bf16_t* __restrict__ aux,
+                  rd_bf16_t* __restrict__ gx, int B, int use_drop, uint32_t key, uint32_t idx_base) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  if (tid < 64) *(float*)(lds + RD_D2S_ZERO + tid * 4) = 0.f;
+  const unsigned wvoff = (unsigned)lane * 16u;
+  const int nitems = (B + RD_D2S_S - 1) / RD_D2S_S;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const long b0 = (long)item * RD_D2S_S;
+    const int ns = min(RD_D2S_S, B - (int)b0);
+    __syncthreads();                                  // every wave has left the previous item (and the zero row is in)
+    {
+      // 48 KB, contiguous: 48 DMA instructions of 1 KB (4 rows), 12 per wave; chunk swizzle c ^ (row & 15) on the source side
+      const __amdgpu_buffer_rsrc_t rs = rd_make_rsrc((const float*)(gy + b0 * (RD_D2S_SROWS * 128)));
+#pragma unroll
+      for (int k = 0; k < RD_D2S_S * RD_D2S_SROWS / 16; ++k) {
+        const int i = wave * (RD_D2S_S * RD_D2S_SROWS / 16) + k;      // wave-uniform
+        const int row = i * 4 + (lane >> 4);
+        const int c_log = (lane & 15) ^ (row & 15);
+        unsigned voff = row < ns * RD_D2S_SROWS ? (unsigned)(row * 256 + c_log * 16) : RD_OOB;
+        asm volatile("" : "+v"(voff));
+        rd_lds_dma16(rs, (float*)(lds + i * 1024), (int)voff, 0);
+      }
+    }
+    rd_dma_landed();
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {
+      const int desc = rd_d2s_tiles[wave][t];
+      const int cls = desc & 15, row0 = (desc >> 4) & 255, mbs = desc >> 12;
+      if (mbs == 4) rd_d2s_tile<4>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, key, idx_base, l31, lhalf);
+      else if (mbs == 3) rd_d2s_tile<3>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, key, idx_base, l31, lhalf);
+      else rd_d2s_tile<2>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, key, idx_base, l31, lhalf);
+    }
+  }
+}

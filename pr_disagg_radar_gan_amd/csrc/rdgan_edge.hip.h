@@ -5,7 +5,7 @@
 // LDS-broadcast inputs (LDS-bound), FMAs fed from scalar loads (SGPR spills in the forward, scalar-cache misses in the weight
 // gradient).  What does: the im2col row as ONE K = 64 operand row staged through registers, the matrix pipe, persistent tiles.
 #pragma once
-#include "rdgan_gemm_ws.hip.h"
+#include "rdgan_gemm_ws16.hip.h"
 
 // ------------------------------------------------------------------------------------
 // Last generator conv, forward (T:345): per grid point the 27 column products P[pos][tap] = h3[pos][:] . W9[tap][:], with the
@@ -546,15 +546,14 @@ k_d1_gemm_fwd(const float* __restrict__ cin, const float* __restrict__ w, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = rd_lrelu(v[e]);
-          if (use_drop) t *= rd_drop_scale(key, (uint32_t)idx + idx_base + e);
+          if (use_drop) t = rd_drop_apply(t, key, (uint32_t)idx + idx_base + e);
           v[e] = t;
         }
       } else {
         const f32x4 a4 = rd_ld4(aux + idx);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float g = rd_lrelu_slope_from_out(a4[e]);
-          if (use_drop) g *= rd_drop_scale(key, (uint32_t)idx + idx_base + e);
+          const float g = rd_gate_from_out(a4[e], use_drop);
           v[e] *= g;
         }
       }
@@ -676,20 +675,150 @@ k_d1_gemm_wgrad(const float* __restrict__ cin, const TG* __restrict__ u1, float*
     o[row * 64 + wn * 32 + l31] = acc[r];
   }
 }
+// The same weight gradient in the bf16 storage mode, on the bf16 matrix pipe (round 3).  k_d1_gemm_wgrad<bf16> multiplies on the
+// fp32 pipe (v_mfma_f32_32x32x2f32: 64 cycles per TWO rows of the contraction) and is bound by it -- 0.38 ms at 6144 samples, 0.46
+// of the fp32 MFMA roof, for a launch whose bytes (u1 424 MB bf16 + the 2-channel input 302 MB) would pass in 0.15 ms.  Here both
+// operands are bf16 images in LDS, position-major as they arrive -- u1 rows by LDS-DMA straight from HBM, im2col rows rounded to
+// bf16 on their way from registers (the forward GEMM k_d1_gemm_fwd<bf16> rounds them the same way) -- and both MFMA operands (8
+// consecutive positions of one column) are read with ds_read_b64_tr_b16 exactly as in k_wgrad_gemm_ws16: 32 cycles per SIXTEEN
+// rows.  Column 54 of the im2col image holds 1 for the first `bias_rows` rows (the real | fake thirds: the penalty third does not
+// reach the bias, T:382) and 0 behind: row 54 of the product is the layer's bias gradient -- the column-sum pass over u1
+// (k_colsum_partial, 0.11 ms beside the GEMMs) is gone.  partial[blockIdx.x][64][64], folded by k_d1_wgrad_fold in a fixed order.
+// LDS per stage: im2col [64 rows][128 B] + u1 [64 rows][128 B]; 16-byte chunk c of row r at c ^ (((r >> 1) & 1) << 2) (rd_tr_swz<128>).
+__global__ void __launch_bounds__(256, 4)
+k_d1_wgrad16(const float* __restrict__ cin, const rd_bf16_t* __restrict__ u1, float* __restrict__ partial, long rows,
+             long rows_per_wg, long bias_rows, int nd, int Do, int Ho, int Wo) {
+  constexpr int BKR = 64;                   // rows per chunk: four 16-deep MFMA steps
+  constexpr int IMG = BKR * 128;            // bytes per image
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * IMG];     // [stage][im2col | u1]
+  __shared__ long rowoff[2][BKR];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lhalf = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long mbeg = (long)blockIdx.x * rows_per_wg, mend = min(rows, mbeg + rows_per_wg);
+  const int NPOS = Do * Ho * Wo, HoWo = Ho * Wo;
+  const long nin = (long)RDGAN_NHOURS * nd * nd * 2;
+  const int nchunks = mend > mbeg ? (int)((mend - mbeg + BKR - 1) / BKR) : 0;
+  auto decode_rows = [&](int q) {          // element offset of each row's window in cin (-1 = no row): threads 0 .. 63
+    if (tid < BKR) {
+      const long m = mbeg + (long)q * BKR + tid;
+      long off = -1;
+      if (m < mend) {
+        const long b = m / NPOS;
+        const int p = (int)(m - b * NPOS);
+        const int od = p / HoWo, qq = p - od * HoWo, oh = qq / Wo, ow = qq - oh * Wo;
+        off = b * nin + ((long)(2 * od * nd + 2 * oh) * nd + 2 * ow) * 2;
+      }
+      rowoff[q & 1][tid] = off;
+    }
+  };
+  constexpr int NSG = (BKR * 9 + 255) / 256;          // im2col segments per thread (3; the last one only for tid < 64)
+  float2 sa[NSG][3];
+  const __amdgpu_buffer_rsrc_t rsG = rd_make_rsrc((const float*)(u1 + mbeg * 64));
+  auto load_regs = [&](int q) {
+#pragma unroll
+    for (int u = 0; u < NSG; ++u) {
+      const int sgi = tid + u * 256;
+      const int sg = sgi >> 6, r = sgi & (BKR - 1);           // lanes along the rows of one segment
+      float2 a = {0.f, 0.f}, c = a, e = a;
+      const long off = sgi < BKR * 9 ? rowoff[q & 1][r] : -1;
+      if (off >= 0) {
+        const int kd = sg / 3, kh = sg - kd * 3;
+        const float* src = cin + off + (kd * nd + kh) * nd * 2;
+        a = *(const float2*)src; c = *(const float2*)(src + 2); e = *(const float2*)(src + 4);
+      }
+      sa[u][0] = a; sa[u][1] = c; sa[u][2] = e;
+    }
+  };
+  auto dma_u1 = [&](int q, int buf) {                 // 64 rows x 128 B: 8 DMA instructions of 8 rows, 2 per wave
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = wave * 2 + k;
+      const int r = i * 8 + (lane >> 3);
+      const long m = (long)q * BKR + r;               // relative to mbeg
+      const int cl = (lane & 7) ^ rd_tr_swz<128>(r);
+      unsigned voff = mbeg + m < mend ? (unsigned)(m * 128 + cl * 16) : RD_OOB;
+      asm volatile("" : "+v"(voff));
+      rd_lds_dma16(rsG, (float*)(lds + buf * 2 * IMG + IMG + i * 1024), (int)voff, 0);
+    }
+  };
+  auto store_lds = [&](int q, int buf) {
+    char* Xs = lds + buf * 2 * IMG;
+#pragma unroll
+    for (int u = 0; u < NSG; ++u) {
+      const int sgi = tid + u * 256;
+      if (sgi < BKR * 9) {
+        const int sg = sgi >> 6, r = sgi & (BKR - 1), k0 = sg * 6;
+        char* rowp = Xs + r * 128;
+        const int sw = rd_tr_swz<128>(r);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const int k = k0 + 2 * e;
+          *(unsigned*)(rowp + (((k >> 3) ^ sw) * 16) + (k & 7) * 2) = rd_pack_bf16(sa[u][e].x, sa[u][e].y);
+        }
+      }
+    }
+    if (tid < BKR) {                                  // columns 54 .. 63: the ones column of the bias gradient, then zeros
+      const int r = tid;
+      const long m = mbeg + (long)q * BKR + r;
+      char* rowp = Xs + r * 128;
+      const int sw = rd_tr_swz<128>(r);
+      *(unsigned*)(rowp + ((6 ^ sw) * 16) + 12) = (m < mend && m < bias_rows) ? 0x00003F80u : 0u;      // k = 54 (1.0), 55
+      *(u32x4_t*)(rowp + ((7 ^ sw) * 16)) = (u32x4_t){0u, 0u, 0u, 0u};                                   // k = 56 .. 63
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // transposed-read addresses (k_wgrad_gemm_ws16): this lane is lane 4 q4 + p4 of 16-lane group g in half lhalf
+  const int g = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int ckA = (wm * 32) / 8 + 2 * g + (p4 >> 1), ckB = (wn * 32) / 8 + 2 * g + (p4 >> 1);
+  const int a_off = (8 * lhalf + q4) * 128 + ((ckA ^ rd_tr_swz<128>(q4)) * 16) + (p4 & 1) * 8;
+  const int b_off = IMG + (8 * lhalf + q4) * 128 + ((ckB ^ rd_tr_swz<128>(q4)) * 16) + (p4 & 1) * 8;
+  decode_rows(0); decode_rows(1);
+  __syncthreads();
+  if (nchunks > 0) { dma_u1(0, 0); load_regs(0); store_lds(0, 0); }
+  rd_dma_landed();
+  __syncthreads();
+  for (int q = 0; q < nchunks; ++q) {
+    const int buf = q & 1;
+    if (q + 1 < nchunks) { dma_u1(q + 1, buf ^ 1); load_regs(q + 1); }
+    decode_rows(q + 2);                                // slot q & 1: last read by load_regs(q), a barrier ago
+    const char* st = lds + buf * 2 * IMG;
+#pragma unroll
+    for (int kk = 0; kk < BKR / 16; ++kk) {
+      const rd_bf16x8 fa = rd_tr_frag(st, a_off + kk * 16 * 128, a_off + (kk * 16 + 4) * 128);
+      const rd_bf16x8 fb = rd_tr_frag(st, b_off + kk * 16 * 128, b_off + (kk * 16 + 4) * 128);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    if (q + 1 < nchunks) store_lds(q + 1, buf ^ 1);
+    rd_dma_landed();
+    __syncthreads();
+  }
+  float* o = partial + (long)blockIdx.x * 4096;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+    o[row * 64 + wn * 32 + l31] = acc[r];
+  }
+}
 // dW1[i] = sum over workgroups of partial[g][i], i < 54 * 64 (fixed order)
 // (block = 16 outputs x 16 slices of the workgroup range, folded through LDS in a fixed order)
+// (db != nullptr, grid 55 * 4 blocks: row 54 of the product = the layer's bias gradient, k_d1_wgrad16)
 __global__ void __launch_bounds__(256)
-k_d1_wgrad_fold(const float* __restrict__ partial, int G, float* __restrict__ dw) {
+k_d1_wgrad_fold(const float* __restrict__ partial, int G, float* __restrict__ dw, float* __restrict__ db = nullptr) {
   __shared__ float red[256];
   const int i = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+  const int n = db ? 55 * 64 : 54 * 64;
   float s = 0.f;
-  if (i < 54 * 64)
+  if (i < n)
     for (int g = sl; g < G; g += 16) s += partial[(long)g * 4096 + i];
   red[threadIdx.x] = s;
   __syncthreads();
-  if (sl == 0 && i < 54 * 64) {
+  if (sl == 0 && i < n) {
     float t = red[threadIdx.x];
     for (int j = 1; j < 16; ++j) t += red[j * 16 + threadIdx.x];
-    dw[i] = t;
+    if (i < 54 * 64) dw[i] = t; else db[i - 54 * 64] = t;
   }
 }

@@ -495,8 +495,7 @@ __global__ void k_critic_top_bwd(const T* __restrict__ h4, const float* __restri
   const long total = (long)NB * F;
   for (long f = blockIdx.x * (long)blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     int b = (int)(f / F), i = (int)(f - (long)b * F);
-    float g = rd_lrelu_slope_from_out(rd_ld1(h4 + f));
-    if (use_drop) g *= rd_drop_scale(key, (uint32_t)f);
+    const float g = rd_gate_from_out(rd_ld1(h4 + f), use_drop);
     rd_st1(u4 + f, g * w[i] * rd_dv(b, B, mode));
   }
 }

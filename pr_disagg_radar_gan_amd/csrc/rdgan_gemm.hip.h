@@ -60,6 +60,24 @@ __device__ __forceinline__ float rd_lrelu(float x) { return x > 0.f ? x : RD_LRE
 // slope of LeakyReLU recovered from its (possibly dropout-scaled) output: TF's LeakyReluGrad
 // uses features > 0 ? 1 : alpha, and sign(output) == sign(features) for kept elements.
 __device__ __forceinline__ float rd_lrelu_slope_from_out(float h) { return h > 0.f ? 1.f : RD_LRELU_ALPHA; }
+// Inverted dropout (T:288-300, rate 0.25) on a LeakyReLU output, leaving the mask readable in the stored value: a DROPPED element
+// is stored as +0.0 whatever its sign was, a kept element that is exactly zero as -0.0.  The backward kernels then take the
+// whole gate -- LeakyReLU' x mask x 1/0.75 -- from the stored activation (rd_gate_from_out) instead of hashing the element's
+// counter again: two rd_mix32 = four quarter-rate v_mul_lo_u32 per element were the largest VALU item of every gating epilogue
+// (0.18 ms of pure VALU time per sweep over critic layer 1's output at 6144 samples).  Same mask, same arithmetic as
+// slope * rd_drop_scale; as a value -0.0 is 0.0 to everything downstream.  (bf16 storage: a kept value below 2^-133 would round
+// to +0.0 and read as dropped; not reachable from this network's magnitudes.)
+__device__ __forceinline__ float rd_drop_apply(float x, uint32_t key, uint32_t idx) {
+  const float s = rd_drop_scale(key, idx);
+  const float y = x * s;
+  return s != 0.f ? (y == 0.f ? -0.0f : y) : 0.0f;
+}
+// LeakyReLU'(features) x dropout factor from the layer's stored output h (TF: features > 0 ? 1 : alpha; dropout grad = mask/0.75)
+__device__ __forceinline__ float rd_gate_from_out(float h, int use_drop) {
+  float g = h > 0.f ? 1.f : RD_LRELU_ALPHA;
+  if (use_drop) g = __builtin_bit_cast(unsigned, h) == 0u ? 0.f : g * (1.0f / 0.75f);
+  return g;
+}
 
 __device__ __forceinline__ f32x4 rd_buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
@@ -579,15 +597,14 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = rd_lrelu(v[e]);
-            if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, ibase + (rb / OSZ) + e);
+            if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply(x, epi.key, ibase + (rb / OSZ) + e);
             v[e] = x;
           }
         } else if (mode == RD_EPI_GATE_AUX) {
           const f32x4 a4 = ld_act(rsX, rb + colb);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float g = rd_lrelu_slope_from_out(a4[e]);
-            if (epi.use_drop) g *= rd_drop_scale(epi.key, ibase + (rb / OSZ) + e);
+            const float g = rd_gate_from_out(a4[e], epi.use_drop);
             v[e] *= g;
           }
         }
@@ -620,10 +637,9 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
             v = rd_lrelu(v + epi.bias[col]);
           } else if (mode == RD_EPI_BIAS_LRELU_DROP) {
             v = rd_lrelu(v + epi.bias[col]);
-            if (epi.use_drop) v *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
+            if (epi.use_drop) v = rd_drop_apply(v, epi.key, (uint32_t)idx + epi.idx_base);
           } else if (mode == RD_EPI_GATE_AUX) {
-            float g = rd_lrelu_slope_from_out(OUT16 ? rd_ld1((const rd_bf16_t*)epi.aux + idx) : epi.aux[idx]);
-            if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
+            const float g = rd_gate_from_out(OUT16 ? rd_ld1((const rd_bf16_t*)epi.aux + idx) : epi.aux[idx], epi.use_drop);
             v *= g;
           }
           if constexpr (OUT16) rd_st1((rd_bf16_t*)dst + idx, v); else dst[idx] = v;
@@ -657,10 +673,9 @@ __global__ void k_splitk_finish(float* dst, long total, int N, RdEpi epi) {
         x = rd_lrelu(x + epi.bias[col0 + e]);
       } else if (mode == RD_EPI_BIAS_LRELU_DROP) {
         x = rd_lrelu(x + epi.bias[col0 + e]);
-        if (epi.use_drop) x *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
+        if (epi.use_drop) x = rd_drop_apply(x, epi.key, (uint32_t)idx + epi.idx_base);
       } else if (mode == RD_EPI_GATE_AUX) {
-        float g = rd_lrelu_slope_from_out(OUT16 ? rd_ld1((const rd_bf16_t*)epi.aux + idx) : epi.aux[idx]);
-        if (epi.use_drop) g *= rd_drop_scale(epi.key, (uint32_t)idx + epi.idx_base);
+        const float g = rd_gate_from_out(OUT16 ? rd_ld1((const rd_bf16_t*)epi.aux + idx) : epi.aux[idx], epi.use_drop);
         x *= g;
       }
       v[e] = x;

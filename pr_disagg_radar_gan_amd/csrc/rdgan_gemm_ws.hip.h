@@ -577,15 +577,14 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float x = rd_lrelu(v[e]);
-              if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+              if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply(x, epi.key, ibase + (rb >> 2) + e);
               v[e] = x;
             }
           } else if (mode == RD_EPI_GATE_AUX) {
             const f32x4 a4 = rd_buf_load4_bf16(rsX, oob(rb) + colh);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float g = rd_lrelu_slope_from_out(a4[e]);
-              if (epi.use_drop) g *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+              const float g = rd_gate_from_out(a4[e], epi.use_drop);
               v[e] *= g;
             }
           }
@@ -630,15 +629,14 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = rd_lrelu(v[e]);
-          if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+          if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply(x, epi.key, ibase + (rb >> 2) + e);
           v[e] = x;
         }
       } else if (mode == RD_EPI_GATE_AUX) {
         const f32x4 a4 = rd_buf_load4(rsX, rb + colb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float g = rd_lrelu_slope_from_out(a4[e]);
-          if (epi.use_drop) g *= rd_drop_scale(epi.key, ibase + (rb >> 2) + e);
+          const float g = rd_gate_from_out(a4[e], epi.use_drop);
           v[e] *= g;
         }
       }

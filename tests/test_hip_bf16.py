@@ -134,6 +134,65 @@ def test_slab_kernel_equals_the_streaming_gemm_to_one_bf16_ulp(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [5, 64])
+def test_d2_slab_kernel_equals_the_streaming_gemm(B):
+    """"d2_slab" (default on at ndomain 16): the input gradient of critic layer 2 in the slab kernel k_d2_dgrad_slab16 against the
+    streaming bf16 GEMM of the same engine: the same bf16 products in the same tap and k order, fp32 accumulation, the same
+    dropout counter, one rounding to bf16 -- the whole critic-step gradient slab (layer 1's weight gradient and, through the
+    penalty's input gradient, everything else hangs on that tensor) and the losses agree bit for bit; so does the generator
+    step, whose critic backward runs the same launch at B samples instead of 3 B."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 57)
+        x, cond, z = ot.synthetic_batch(B, 16, 49)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for slab in (0, 1):
+            eng.set_option("d2_slab", slab)
+            c = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 13).clone()
+            gg = eng.gen_grad(ds, gs, dev(z), dev(cond), 14).clone()
+            assert torch.equal(c, eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 13))      # run-to-run deterministic
+            res[slab] = (c, gg)
+        assert bool(torch.isfinite(res[1][0]).all()) and bool(torch.isfinite(res[1][1]).all())
+        for a, b, n, what in ((res[0][0], res[1][0], eng.n_critic, "critic"), (res[0][1], res[1][1], eng.n_gen, "gen")):
+            e = float((a[:n] - b[:n]).abs().max() / a[:n].abs().max())
+            le = float((a[n:n + 4] - b[n:n + 4]).abs().max())
+            print(f"B {B} {what}-step gradients, d2_slab 1 vs 0: {e:.2e} of the largest entry; losses differ by {le:.2e}")
+            assert e < 2e-3 and le < 1e-3 * (1.0 + float(a[n:n + 4].abs().max())), (what, e, le)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("B", [3, 70])
+def test_d1_wgrad16_equals_the_fp32_pipe_kernel_up_to_operand_rounding(B):
+    """"d1_wgrad16" (default on): the first critic layer's weight gradient on the bf16 matrix pipe, bias gradient from the ones
+    column of the same product, against the fp32-pipe kernel + column-sum pass of the same engine.  The new kernel rounds the
+    im2col operand (the 2-channel critic input) to bf16 as the layer's forward GEMM does -- 2^-9 per element, averaging out over
+    the 3 B x 539 rows of the sum -- the old one kept it fp32: kernel gradient within 4e-3 of its largest entry; the bias
+    gradient sums the same bf16 values in another order: 1e-5.  Everything else in the slab is untouched: equal bit for bit."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 59)
+        x, cond, z = ot.synthetic_batch(B, 16, 50)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("d1_wgrad16", on)
+            res[on] = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 21).clone()
+            assert torch.equal(res[on], eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 21))      # run-to-run deterministic
+        a, b = res[0].cpu().numpy(), res[1].cpu().numpy()
+        nw, nb = 27 * 2 * 64, 64
+        ew = np.abs(a[:nw] - b[:nw]).max() / np.abs(a[:nw]).max()
+        eb = np.abs(a[nw:nw + nb] - b[nw:nw + nb]).max() / np.abs(a[nw:nw + nb]).max()
+        print(f"B {B} d1_wgrad16 1 vs 0: kernel gradient {ew:.2e}, bias gradient {eb:.2e} of the largest entry")
+        assert 0 < ew < 4e-3 and eb < 1e-5, (ew, eb)
+        assert np.array_equal(a[nw + nb:], b[nw + nb:])
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:

@@ -282,3 +282,43 @@ def test_upconv_slab_kernel_vs_oracle(B):
         got = dbg.cpu().numpy().reshape(1, 24, 16, 16, 4)
         np.testing.assert_array_equal(got[..., 0], got[..., 1])                  # both lane halves of a row hold the same sum
         np.testing.assert_allclose(np.sqrt(got[..., 0]), want, rtol=0, atol=1e-3), tap
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 7, 130, 1100])
+def test_d2_dgrad_slab_kernel_vs_oracle(B):
+    """k_d2_dgrad_slab16 alone (rdgan_op_d2_dgrad_slab16): input gradient of the critic's second layer (backward of T:291,
+    Conv3D(128, 3x3x3, stride 2, 'same') on 11 x 7 x 7 x 64 -> 6 x 4 x 4 x 128) times the LeakyReLU'/dropout gate of layer 1
+    (T:287-289), against the definition (every tap scattered, oracle/rdgan_np.py conv3d_input_grad) in fp64 on the bf16-rounded
+    operands.  The kernel accumulates in fp32 and rounds its output to bf16 once: 2^-8 of each element (checked per element), odd
+    B = a last work item of one sample, B = 1100 = persistent workgroups walk two items.  With dropout the kernel reads the mask
+    from the stored activation (+0.0 = dropped, rd_drop_apply / rd_gate_from_out), a kept exact zero is stored as -0.0."""
+    from oracle import rdgan_np as onp
+    rng = np.random.default_rng(200 + B)
+    gy = rng.standard_normal((B, 6, 4, 4, 128)).astype(np.float32)
+    w = (0.05 * rng.standard_normal((3, 3, 3, 64, 128))).astype(np.float32)
+    aux = rng.standard_normal((B, 11, 7, 7, 64)).astype(np.float32)
+    gx_ref = onp.conv3d_input_grad(_bf16_round(gy).astype(np.float64), _bf16_round(w).astype(np.float64), (11, 7, 7), 2, (1, 1, 1))
+    slope = np.where(_bf16_round(aux) > 0, 1.0, 0.2)
+    gyd, wd = dev(gy), dev(w)
+    for seed in (0, 0x5DEECE66D):
+        want, a = gx_ref * slope, aux.copy()
+        if seed:
+            m = orng.dropout_scale_mask(seed, orng.STREAM_D1, want.shape)
+            a[m == 0] = 0.0                                   # dropped: +0.0
+            kept0 = (m > 0) & (rng.random(want.shape) < 0.01)
+            a[kept0] = -0.0                                   # kept, exactly zero: LeakyReLU' = alpha there (TF: features > 0 ? 1 : alpha)
+            want = gx_ref * np.where(_bf16_round(a) > 0, 1.0, 0.2) * m
+        gx = torch.full((B, 11, 7, 7, 64), float("nan"), device="cuda")
+        assert lib().rdgan_op_d2_dgrad_slab16(ptr(gyd), ptr(wd), ptr(dev(a)), ptr(gx), B, int(seed != 0), stream()) == 0
+        got = gx.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(got))
+        np.testing.assert_allclose(got, want, rtol=2.0 ** -8 + 1e-5, atol=1e-5 * np.abs(want).max())
+    # one-hot probe: one kernel tap and channel pair moves exactly the voxels the definition names
+    gy1 = np.zeros((1, 6, 4, 4, 128), np.float32); gy1[..., 77] = (np.arange(96).reshape(1, 6, 4, 4) % 61) + 1
+    a1 = np.ones((1, 11, 7, 7, 64), np.float32)
+    for tap in (0, 13, 26, 5, 21):
+        w1 = np.zeros((3, 3, 3, 64, 128), np.float32); w1[tap // 9, (tap // 3) % 3, tap % 3, 9, 77] = 1.0
+        want = onp.conv3d_input_grad(gy1.astype(np.float64), w1.astype(np.float64), (11, 7, 7), 2, (1, 1, 1))
+        gx = torch.full((1, 11, 7, 7, 64), float("nan"), device="cuda")
+        assert lib().rdgan_op_d2_dgrad_slab16(ptr(dev(gy1)), ptr(dev(w1)), ptr(dev(a1)), ptr(gx), 1, 0, stream()) == 0
+        np.testing.assert_array_equal(gx.cpu().numpy(), want.astype(np.float32)), tap
