@@ -1827,7 +1827,7 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
       RD_TRY(ensure_lds(h, (const void*)k_d2_dgrad_slab16, RD_D2S_LDS));
       hipLaunchKernelGGL(k_d2_dgrad_slab16, dim3((unsigned)std::min((NBt + 1) / 2, 512)), dim3(256), RD_D2S_LDS, st,
                          (const rd_bf16_t*)h->du[2], (const rd_bf16_t*)h->bW2S, (const rd_bf16_t*)h->dh[1], (rd_bf16_t*)h->du[1], NBt,
-                         use_drop, ep.key, ep.idx_base);
+                         use_drop);
       RD_CHECK(h, hipGetLastError());
       continue;
     }
@@ -2549,7 +2549,7 @@ extern "C" int rdgan_op_d2_dgrad_slab16(const float* gy, const float* w, const f
   }
   if (rc == 0) {
     hipLaunchKernelGGL(k_d2_dgrad_slab16, dim3((unsigned)std::min((B + 1) / 2, 512)), dim3(256), RD_D2S_LDS, st, (const rd_bf16_t*)yb,
-                       (const rd_bf16_t*)wi, (const rd_bf16_t*)ab, (rd_bf16_t*)xb, B, use_drop != 0, 0u, 0u);
+                       (const rd_bf16_t*)wi, (const rd_bf16_t*)ab, (rd_bf16_t*)xb, B, use_drop != 0);
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(nx)), dim3(256), 0, st, (const rd_bf16_t*)xb, gx, nx);
     rc = (int)hipGetLastError();
   }

@@ -55,20 +55,22 @@ __global__ void k_d2s_wimg(const float* __restrict__ w2, unsigned short* __restr
   *(u32x4_t*)(wimg + (long)idx * 8) = o;
 }
 
-// tiles of an item: wave w runs rd_d2s_tiles[w][0..2] = cls | first row << 4 | row blocks << 12
-// (taps x blocks per wave: 24+3+3, 16+6+4, 16+6+4, 16+6+4; row blocks, i.e. epilogues: 9, 9, 9, 9)
-__constant__ int rd_d2s_tiles[4][3] = {
-  {0 | (0 << 4) | (3 << 12), 7 | (0 << 4) | (3 << 12), 7 | (96 << 4) | (3 << 12)},
-  {1 | (0 << 4) | (4 << 12), 3 | (0 << 4) | (3 << 12), 3 | (96 << 4) | (2 << 12)},
-  {2 | (0 << 4) | (4 << 12), 5 | (0 << 4) | (3 << 12), 5 | (96 << 4) | (2 << 12)},
-  {4 | (0 << 4) | (4 << 12), 6 | (0 << 4) | (3 << 12), 6 | (96 << 4) | (2 << 12)},
+// tiles of an item: wave w runs rd_d2s_tiles[w][0..3] = cls | first row << 4 | row blocks << 12 (0 blocks: no tile)
+// (taps x blocks per wave: 24+3+3, 8+8+6+4, 8+8+6+4, 8+8+6+4; row blocks, i.e. epilogues: 9, 9, 9, 9.  At most 3 blocks per tile:
+// with 4 the accumulators (128), the weight queue (32) and the tile's gate rows (64) do not fit 256 registers)
+#define RD_D2S_T(cls, row0, mbs) ((cls) | ((row0) << 4) | ((mbs) << 12))
+__constant__ int rd_d2s_tiles[4][4] = {
+  {RD_D2S_T(0, 0, 3), RD_D2S_T(7, 0, 3), RD_D2S_T(7, 96, 3), 0},
+  {RD_D2S_T(1, 0, 2), RD_D2S_T(1, 64, 2), RD_D2S_T(3, 0, 3), RD_D2S_T(3, 96, 2)},
+  {RD_D2S_T(2, 0, 2), RD_D2S_T(2, 64, 2), RD_D2S_T(5, 0, 3), RD_D2S_T(5, 96, 2)},
+  {RD_D2S_T(4, 0, 2), RD_D2S_T(4, 64, 2), RD_D2S_T(6, 0, 3), RD_D2S_T(6, 96, 2)},
 };
 
 // one tile: rows row0 .. row0 + 32 MB - 1 of phase cls, all 64 channels
 template <int MB>
 __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, unsigned wvoff, int cls, int row0, int ns, long b0,
                                             const rd_bf16_t* __restrict__ aux, rd_bf16_t* __restrict__ out, int use_drop,
-                                            uint32_t key, uint32_t idx_base, int l31, int lhalf) {
+                                            int l31, int lhalf) {
   const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
   const int cd = 5 + pd, chh = 3 + ph, cw = 3 + pw;            // the phase's sub-grid (positions 2 l + 1 - parity)
   const int chw = chh * cw, cnt = cd * chw;
@@ -97,12 +99,16 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
   const char* wph = wimg + (long)rd_d2s_tap0(cls) * 8 * 2048;        // wave-uniform
   u32x4_t bq[4][2];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) rd_upc_wload(bq[s][0], bq[s][1], wph + (s < nks ? s : nks - 1) * 2048, wvoff);
-  int ti = 0;
+  for (int s = 0; s < 4; ++s) rd_upc_wload(bq[s][0], bq[s][1], wph + s * 2048, wvoff);
+  // (no `continue` in this loop: the weight queue is carried around it with loads in flight, and a path that skips the body would
+  // make its registers phi values -- see the refill below)
 #pragma unroll 1
-  for (int tc = 0; tc < 8; ++tc) {
-    const int jd = tc >> 2, jh = (tc >> 1) & 1, jw = tc & 1;
-    if ((jd & pd) | (jh & ph) | (jw & pw)) continue;                  // (wave-uniform) an axis of parity 1 has one tap
+  for (int ti = 0; ti < ntaps; ++ti) {
+    // tap ti of the phase: the bits of ti go to the axes of parity 0, w first (an axis of parity 1 has one tap)
+    int rem = ti;
+    const int jw = pw ? 0 : (rem & 1); rem >>= pw ? 0 : 1;
+    const int jh = ph ? 0 : (rem & 1); rem >>= ph ? 0 : 1;
+    const int jd = pd ? 0 : (rem & 1);
     // source offset of the tap: 1 - j on an axis of parity 0, 0 on an axis of parity 1
     const int shift = (pd ? 0 : 1 - jd) * 16 + (ph ? 0 : 1 - jh) * 4 + (pw ? 0 : 1 - jw);
     int abase[MB], aswz[MB];
@@ -130,7 +136,7 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
       }
 #endif
 #ifndef RD_D2S_ABL_NOW               // (diagnostic builds: the K loop without its weight stream)
-      rd_upc_wait<6>(bq[j & 3][0], bq[j & 3][1]);
+      rd_upc_wait<6>(bq[j & 3][0], bq[j & 3][1]);          // the two oldest of the eight loads in flight
 #endif
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
@@ -141,19 +147,41 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
       }
 #ifndef RD_D2S_ABL_NOW
       {
-        const int gn = ti * 8 + j + 4;            // refill with k-step + 4 of the tile (past its end: the last one again, never used)
+        // refill with k-step + 4 of the tile (past its end: the last one again, never used).  The SAME two statements for every
+        // k-step, no branch between a load and its wait: a first attempt to stop the refills at the tile's end (waits of 4, 2, 0
+        // in the last tap, chosen by a wave-uniform branch) made the queue registers phi values, and hipcc placed the copies that
+        // reconcile them IN FRONT of the wait -- copies of registers a load was still in flight to (phase 0 wrong, round 3)
+        const int gn = ti * 8 + j + 4;
         rd_upc_wload(bq[j & 3][0], bq[j & 3][1], wph + (long)(gn < nks ? gn : nks - 1) * 2048, wvoff);
       }
 #else
       asm volatile("" : "+v"(bq[j & 3][0]), "+v"(bq[j & 3][1]));
 #endif
     }
-    ++ti;
   }
-  // (the clamped refills are still in flight: see k_upconv_slab16)
+  // The clamped refills of the last four k-steps are still in flight and nobody will read them: wait for them HERE, naming their
+  // destination registers, before anything else is allocated -- to hipcc those registers are dead behind the loop.  (With the
+  // gate loads below in front of this wait it handed them the queue registers for their ADDRESSES; a late weight fragment then
+  // overwrote an address between its computation and the load that used it: memory fault, round 3.)
   asm volatile("s_waitcnt vmcnt(0)"
                : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]), "+v"(bq[3][0]),
                  "+v"(bq[3][1]));
+  // The gate rows of the WHOLE tile (layer 1's stored output at this tile's destination rows, 64 B per lane and row) are requested
+  // here, in one go: one memory round trip per tile.  (A first version loaded them block by block
+  // inside the epilogue loop -- a divergent `continue` for rows past the item's end kept hipcc from hoisting them -- and paid a
+  // round trip per 32-row block: 0.16 of the kernel's 0.38 ms at 6144 samples, scratch/d2s_abl.py.)  Rows past the end read the
+  // item's first row instead of branching.
+  rd_u32x2 gate[MB][8];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const rd_bf16_t* arow = aux + (long)(srow[mb] >= 0 ? orow[mb] : (int)b0 * RD_D2S_OPOS) * 64 + 4 * lhalf;
+#pragma unroll
+#ifndef RD_D2S_ABL_NOGATE            // (diagnostic builds: no gate loads)
+    for (int G = 0; G < 8; ++G) gate[mb][G] = *(const rd_u32x2*)(arow + 8 * G);
+#else
+    for (int G = 0; G < 8; ++G) { gate[mb][G].x = 0x3F803F80u + G + orow[mb]; gate[mb][G].y = 0xBF803F80u; }
+#endif
+  }
 #ifdef RD_D2S_ABL_NOEPI              // (diagnostic builds: K loops only; one element of every accumulator keeps the MFMAs alive)
   {
     float tsum = 0.f;
@@ -166,30 +194,18 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
   // ---- epilogue in registers: lane (l31, lhalf) of block mb holds channels 32 nb + 8 g + 4 lhalf + 0..3 of its row
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    if (srow[mb] < 0) continue;                   // (lanes l and l ^ 32 share their row: the swaps below see both or neither)
-    const rd_bf16_t* arow = aux + (long)orow[mb] * 64 + 4 * lhalf;
-    const uint32_t ibase = (uint32_t)orow[mb] * 64u + idx_base + 4 * lhalf;
+    const bool ok = srow[mb] >= 0;                // (lanes l and l ^ 32 share their row: the swaps below see both or neither)
     char* op = (char*)out + (long)orow[mb] * 128 + lhalf * 16;
-    rd_u32x2 gate[8];
-#pragma unroll
-#ifndef RD_D2S_ABL_NOGATE            // (diagnostic builds: no gate loads)
-    for (int G = 0; G < 8; ++G) gate[G] = *(const rd_u32x2*)(arow + 8 * G);
-#else
-    for (int G = 0; G < 8; ++G) { gate[G].x = 0x3F803F80u + G + orow[mb]; gate[G].y = 0xBF803F80u; }
-#endif
 #pragma unroll
     for (int G = 0; G < 8; G += 2) {
       unsigned lo[2], hi[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int nb = (G + u) >> 2, g = (G + u) & 3;
-        const f32x4 ga = rd_unpack_bf16x4(gate[G + u]);
+        const f32x4 ga = rd_unpack_bf16x4(gate[mb][G + u]);
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float gt = rd_gate_from_out(ga[e], use_drop);
-          v[e] = acc[mb][nb][4 * g + e] * gt;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * g + e] * rd_gate_from_out(ga[e], use_drop);
         lo[u] = rd_pack_bf16(v[0], v[1]); hi[u] = rd_pack_bf16(v[2], v[3]);
       }
       const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
@@ -198,17 +214,18 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
 #ifdef RD_D2S_ABL_NOST               // (diagnostic builds: no output stores)
       if (o.x == 0x12345678u)
 #endif
-      *(u32x4_t*)(op + G * 16) = o;
+      if (ok) *(u32x4_t*)(op + G * 16) = o;
     }
   }
 }
 
 // gy [B][6][4][4][128] bf16 (gradient at layer 2's pre-activation... i.e. h->du[2]) -> gx [B][11][7][7][64] bf16
-// = (sum over taps W[t]^T gy) * LeakyReLU'(aux) * dropout(key, flat index + idx_base); aux = layer 1's output, layout of gx.
+// = (sum over taps W[t]^T gy) * rd_gate_from_out(aux): LeakyReLU' x dropout factor read from aux = layer 1's stored output (layout
+// of gx; +0.0 = dropped).
 // grid: min((B + 1) / 2, 2 per CU) persistent workgroups of 256 threads; dynamic LDS RD_D2S_LDS.
 __global__ void __launch_bounds__(256, 2)
 k_d2_dgrad_slab16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restrict__ wimg, const rd_bf16_t* __restrict__ aux,
-                  rd_bf16_t* __restrict__ gx, int B, int use_drop, uint32_t key, uint32_t idx_base) {
+                  rd_bf16_t* __restrict__ gx, int B, int use_drop) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,12 +253,12 @@ k_d2_dgrad_slab16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restrict_
     rd_dma_landed();
     __syncthreads();
 #pragma unroll 1
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < 4; ++t) {
       const int desc = rd_d2s_tiles[wave][t];
       const int cls = desc & 15, row0 = (desc >> 4) & 255, mbs = desc >> 12;
-      if (mbs == 4) rd_d2s_tile<4>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, key, idx_base, l31, lhalf);
-      else if (mbs == 3) rd_d2s_tile<3>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, key, idx_base, l31, lhalf);
-      else rd_d2s_tile<2>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, key, idx_base, l31, lhalf);
+      if (mbs == 0) break;
+      if (mbs == 3) rd_d2s_tile<3>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf);
+      else rd_d2s_tile<2>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf);
     }
   }
 }

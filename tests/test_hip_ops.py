@@ -309,7 +309,8 @@ def test_d2_dgrad_slab_kernel_vs_oracle(B):
             a[kept0] = -0.0                                   # kept, exactly zero: LeakyReLU' = alpha there (TF: features > 0 ? 1 : alpha)
             want = gx_ref * np.where(_bf16_round(a) > 0, 1.0, 0.2) * m
         gx = torch.full((B, 11, 7, 7, 64), float("nan"), device="cuda")
-        assert lib().rdgan_op_d2_dgrad_slab16(ptr(gyd), ptr(wd), ptr(dev(a)), ptr(gx), B, int(seed != 0), stream()) == 0
+        ad = dev(a)
+        assert lib().rdgan_op_d2_dgrad_slab16(ptr(gyd), ptr(wd), ptr(ad), ptr(gx), B, int(seed != 0), stream()) == 0
         got = gx.cpu().numpy().astype(np.float64)
         assert np.all(np.isfinite(got))
         np.testing.assert_allclose(got, want, rtol=2.0 ** -8 + 1e-5, atol=1e-5 * np.abs(want).max())
@@ -320,5 +321,6 @@ def test_d2_dgrad_slab_kernel_vs_oracle(B):
         w1 = np.zeros((3, 3, 3, 64, 128), np.float32); w1[tap // 9, (tap // 3) % 3, tap % 3, 9, 77] = 1.0
         want = onp.conv3d_input_grad(gy1.astype(np.float64), w1.astype(np.float64), (11, 7, 7), 2, (1, 1, 1))
         gx = torch.full((1, 11, 7, 7, 64), float("nan"), device="cuda")
-        assert lib().rdgan_op_d2_dgrad_slab16(ptr(dev(gy1)), ptr(dev(w1)), ptr(dev(a1)), ptr(gx), 1, 0, stream()) == 0
+        g1d, w1d, a1d = dev(gy1), dev(w1), dev(a1)
+        assert lib().rdgan_op_d2_dgrad_slab16(ptr(g1d), ptr(w1d), ptr(a1d), ptr(gx), 1, 0, stream()) == 0
         np.testing.assert_array_equal(gx.cpu().numpy(), want.astype(np.float32)), tap
