@@ -150,6 +150,10 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * the 11 x 7 x 7 grid, eight parity phases of 8 ... 1 taps) runs in the slab kernel k_d2_dgrad_slab16: two samples' output
  * gradient resident in LDS for all phases and taps, weights streamed in MFMA-fragment order, LeakyReLU' x dropout gate + bf16
  * rounding in registers (rdgan_d2slab16.hip.h).  Same taps and k order as the streaming GEMM (0).
+ * "d1_dgrad_fused" (default 1; bf16 storage mode, ndomain 16, one condition channel): the first critic layer's input gradient
+ * with respect to the sample channel (the penalty's dD/dx_hat and the generator step's dL/dfake) in one pass per sample
+ * (k_d1_dgrad_sample16: the 539 x 27 tap products of a sample stay in LDS, the outputs gather from there); same sums in the same
+ * order as 0 = column GEMM [rows][64] in HBM + k_d1_col2im.
  * "d1_wgrad16" (default 1; bf16 storage mode, one condition channel): the first critic layer's weight gradient runs on the bf16
  * matrix pipe (k_d1_wgrad16: im2col rows rounded to bf16 as in the layer's forward GEMM, both operands read transposed from
  * position-major LDS images) and delivers the layer's bias gradient from a ones column of the same product; 0 = the fp32-pipe

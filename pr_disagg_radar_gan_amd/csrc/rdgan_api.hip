@@ -391,6 +391,7 @@ struct rdgan_handle {
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
   void* bW2S;                     // weight image of the slab kernel of critic layer 2's input gradient (rdgan_d2slab16.hip.h): 432 KB
+  int d1_dgrad_fused = 1;         // 1: bf16 storage mode, ndomain 16: dD/d(sample) of layer 1 in one pass per sample (k_d1_dgrad_sample16)
   int d1_wgrad16 = 1;             // 1: bf16 storage mode: layer-1 weight gradient + bias gradient on the bf16 matrix pipe (k_d1_wgrad16)
   int d2_slab = 1;                // 1: bf16 storage mode, ndomain 16: input gradient of critic layer 2 by k_d2_dgrad_slab16
   int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
@@ -1310,6 +1311,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_wgrad16")) { h->d1_wgrad16 = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_slab")) { h->d2_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
   if (!strcmp(name, "dense_wgrad_slices")) { h->dense_slices = value; return 0; }
@@ -1841,7 +1843,18 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
 }
 
 // dD/d(sample channel) for `B` samples whose u1 starts at u1: column GEMM + col2im -> h->g0
-static int critic_input_grad(rdgan_handle* h, const float* u1, int B, hipStream_t st) {
+static int critic_input_grad(rdgan_handle* h, const float* dp, const float* u1, int B, hipStream_t st) {
+  if (h->a16 && h->d1_dgrad_fused && h->nd == 16 && d1_gemm_ok(h)) {      // one pass, no column matrix (k_d1_dgrad_sample16)
+    ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+    LaunchScope ls(h, PL_D1B, RD_KIND_CONV, B, 2.0 * B * h->dL[1] * 27 * 64, st);
+    RD_KNAME(h, "k_d1_dgrad_sample16<bf16>");
+    h->flops_acc += 2.0 * B * h->dL[1] * 27 * 64;
+    RD_TRY(ensure_lds(h, (const void*)k_d1_dgrad_sample16, RD_D1DG_LDS));
+    hipLaunchKernelGGL(k_d1_dgrad_sample16, dim3((unsigned)std::min(B, 512)), dim3(256), RD_D1DG_LDS, st, (const rd_bf16_t*)u1,
+                       dp + h->doff[0], h->g0, B);
+    RD_CHECK(h, hipGetLastError());
+    return 0;
+  }
   if (h->a16)     // bf16 u1 against the bf16 first kernel [ldp1][64], fp32 column matrix
     RD_TRY(launch_conv16(h, h->plans[PL_D1B], h->d_plans + PL_D1B, B, u1, h->bW1B, h->P1, epi_make(RD_EPI_PLAIN), st,
                          RDGAN_TAG_CRITIC_GEMM));
@@ -1915,7 +1928,7 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
     }
   }
   // gradient penalty (T:238-241, T:382): g0 = dD/dx_hat, n = ||g0||, r0 = d(10 mean((n-1)^2))/dg0
-  RD_TRY(critic_input_grad(h, act_off(h, h->du[1], (long)2 * B * h->dL[1] * 64), B, st));
+  RD_TRY(critic_input_grad(h, dp, act_off(h, h->du[1], (long)2 * B * h->dL[1] * 64), B, st));
   float* cin_hat = h->cin + (long)2 * B * h->dL[0] * h->CP;
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
@@ -2021,7 +2034,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   }
   RD_TRY(critic_forward_impl(h, dp, B, seed, st));              // critic frozen, dropout active (T:395,405)
   RD_TRY(critic_dgrad_chain(h, dp, B, B, 1, seed, st));
-  RD_TRY(critic_input_grad(h, h->du[1], B, st));                 // g0 = dL/d fake
+  RD_TRY(critic_input_grad(h, dp, h->du[1], B, st));                 // g0 = dL/d fake
   const bool a16 = h->a16 != 0;
   const long npix3 = (long)B * h->gpix[3];
   {

@@ -675,6 +675,79 @@ k_d1_gemm_wgrad(const float* __restrict__ cin, const TG* __restrict__ u1, float*
     o[row * 64 + wn * 32 + l31] = acc[r];
   }
 }
+// Input gradient of the same layer with respect to the SAMPLE channel (the gradient penalty's dD/dx_hat, T:238-241, and the
+// generator step's dL/dfake, T:395-408), bf16 storage mode, ndomain 16: g0[b][d][h][w] = sum over (tap, o: 2 o + tap = (d,h,w)) of
+// sum_c u1[b][o][c] * w1[tap][channel 0][c].  The GEMM path writes the whole column matrix P [rows][64 columns (tap, ci)] as fp32
+// (283 MB at 2048 samples, half of its columns -- the condition channel's -- never read) and folds it in a second pass (k_d1_col2im):
+// 0.11 + 0.13 ms per call, six calls per iteration of BASELINE configs[2].  Here a workgroup owns one sample: its 539 x 27 products
+// (every u1 row against the 27 sample-channel taps, one v_mfma_f32_32x32x16_bf16 pass per 32 rows, A fragments straight from
+// global memory) stay in LDS and the 24 x 16 x 16 outputs gather their <= 8 terms from there, in k_d1_col2im's order: the same
+// fp32 sums, bit for bit.  LDS: [544 rows][33] floats (row stride 33: the 32 taps of a row and the rows of a register quad fall
+// into different banks).  grid: min(B, 2 per CU) persistent workgroups.
+#define RD_D1DG_LDS (544 * 33 * 4)
+__global__ void __launch_bounds__(256, 2)
+k_d1_dgrad_sample16(const rd_bf16_t* __restrict__ u1, const float* __restrict__ w1, float* __restrict__ g0, int B) {
+  extern __shared__ __attribute__((aligned(16))) float Dl[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  // B operand, once: tap n = l31 (27 used), channels 16 kk + 8 lhalf + e of the sample channel's kernel w1[tap][0][c]
+  rd_bf16x8 wf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = l31 < 27 ? w1[(l31 * 2) * 64 + kk * 16 + lhalf * 8 + e] : 0.f;
+    const u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
+    wf[kk] = __builtin_bit_cast(rd_bf16x8, o);
+  }
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const rd_bf16_t* ub = u1 + (long)b * (539 * 64);
+    // ---- products: 17 blocks of 32 rows dealt to the four waves (5, 4, 4, 4); rows past 538 are zeros
+    for (int blk = wave; blk < 17; blk += 4) {
+      const int row = blk * 32 + l31;
+      const bool ok = row < 539;
+      const rd_bf16_t* rp = ub + (long)(ok ? row : 0) * 64 + lhalf * 8;
+      u32x4_t a[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) a[kk] = *(const u32x4_t*)(rp + kk * 16);
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, ok ? a[kk] : z), wf[kk], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Dl[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 33 + l31] = acc[r];
+    }
+    __syncthreads();
+    // ---- outputs: voxel f = (d, h, w), <= 8 terms, in the order of k_d1_col2im
+    float* gb = g0 + (long)b * 6144;
+#pragma unroll 4
+    for (int f = tid; f < 6144; f += 256) {
+      const int d = f >> 8, h = (f >> 4) & 15, w = f & 15;
+      float sum = 0.f;
+      for (int td = (d & 1); td < 3; td += 2) {
+        const int od = (d - td) >> 1;
+        if (d - td < 0 || od >= 11) continue;
+        for (int th = (h & 1); th < 3; th += 2) {
+          const int oh = (h - th) >> 1;
+          if (h - th < 0 || oh >= 7) continue;
+          for (int tw = (w & 1); tw < 3; tw += 2) {
+            const int ow = (w - tw) >> 1;
+            if (w - tw < 0 || ow >= 7) continue;
+            sum += Dl[((od * 7 + oh) * 7 + ow) * 33 + (td * 3 + th) * 3 + tw];
+          }
+        }
+      }
+      gb[f] = sum;
+    }
+    __syncthreads();                                  // the products are read: the next sample may overwrite them
+  }
+}
+
 // The same weight gradient in the bf16 storage mode, on the bf16 matrix pipe (round 3).  k_d1_gemm_wgrad<bf16> multiplies on the
 // fp32 pipe (v_mfma_f32_32x32x2f32: 64 cycles per TWO rows of the contraction) and is bound by it -- 0.38 ms at 6144 samples, 0.46
 // of the fp32 MFMA roof, for a launch whose bytes (u1 424 MB bf16 + the 2-channel input 302 MB) would pass in 0.15 ms.  Here both

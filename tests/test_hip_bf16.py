@@ -164,6 +164,32 @@ def test_d2_slab_kernel_equals_the_streaming_gemm(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [1, 6, 600])
+def test_d1_dgrad_fused_equals_the_column_gemm_bit_for_bit(B):
+    """"d1_dgrad_fused" (default on at ndomain 16): dD/d(sample) of the first critic layer in one pass per sample
+    (k_d1_dgrad_sample16) against the column GEMM + col2im of the same engine: the same bf16 products, summed over the channels by
+    the same MFMA steps and over the taps in the same order -- the critic step (gradient penalty through dD/dx_hat) and the
+    generator step (dL/dfake feeds the whole generator backward) are equal bit for bit.  B = 600: workgroups walk two samples."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 61)
+        x, cond, z = ot.synthetic_batch(min(B, 64), 16, 52)
+        rep = lambda a: np.concatenate([a] * (B // a.shape[0] + 1))[:B]
+        x, cond, z = rep(x), rep(cond), rep(z)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("d1_dgrad_fused", on)
+            res[on] = (eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 23).clone(), eng.gen_grad(ds, gs, dev(z), dev(cond), 24).clone())
+        assert bool(torch.isfinite(res[1][0]).all()) and bool(torch.isfinite(res[1][1]).all())
+        assert float(res[1][1][:eng.n_gen].abs().max()) > 0
+        assert torch.equal(res[0][0], res[1][0])
+        assert torch.equal(res[0][1], res[1][1])
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [3, 70])
 def test_d1_wgrad16_equals_the_fp32_pipe_kernel_up_to_operand_rounding(B):
     """"d1_wgrad16" (default on): the first critic layer's weight gradient on the bf16 matrix pipe, bias gradient from the ones
