@@ -8,7 +8,9 @@ this stateless definition instead (mirrored in csrc/rdgan_rng.h):
     key(seed, stream) = mix(lo32(seed) ^ mix(hi32(seed) ^ 0x9E3779B9)) + stream * 0x85EBCA6B
     bits(idx)         = mix(mix(idx) ^ key)                       (all uint32, wrapping)
     uniform(idx)      = (bits >> 8) * 2**-24            in [0, 1)
-    keep(idx)         = (bits >> 8) >= 0x400000         P(keep) = 0.75 for rate 0.25
+    keep(idx)         = byte (idx & 3) of bits(idx >> 2) >= 64      P(keep) = 192/256 = 0.75 for rate 0.25
+                        (one hash word decides four consecutive elements: the kernels' epilogues hold four consecutive
+                        channels per lane and pay the hash once per quad)
 
 ``mix`` is the lowbias32 integer finaliser.  ``idx`` is the flat NDHWC element index of the
 tensor the mask is applied to (for the critic step: the 3B batch [real; fake; interpolated]).
@@ -16,7 +18,7 @@ tensor the mask is applied to (for the critic step: the 3B batch [real; fake; in
 import numpy as np
 
 STREAM_D1, STREAM_D2, STREAM_D3, STREAM_D4, STREAM_ALPHA = 1, 2, 3, 4, 5
-DROP_THRESHOLD = 0x400000  # 0.25 * 2**24
+DROP_THRESHOLD = 64  # 0.25 * 2**8: one byte of the hash word per element
 DROP_SCALE = np.float32(1.0) / np.float32(0.75)
 
 
@@ -57,5 +59,7 @@ def dropout_scale_mask(seed, stream, shape):
     n = int(np.prod(shape))
     if seed == 0:
         return np.ones(shape, np.float32)
-    keep = (bits(seed, stream, n) >> np.uint32(8)) >= np.uint32(DROP_THRESHOLD)
+    words = np.repeat(bits(seed, stream, (n + 3) // 4), 4)[:n]
+    byte = (words >> (np.uint32(8) * (np.arange(n, dtype=np.uint32) & np.uint32(3)))) & np.uint32(0xFF)
+    keep = byte >= np.uint32(DROP_THRESHOLD)
     return np.where(keep, DROP_SCALE, np.float32(0)).astype(np.float32).reshape(shape)

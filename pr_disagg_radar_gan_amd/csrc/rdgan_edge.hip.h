@@ -546,7 +546,7 @@ k_d1_gemm_fwd(const float* __restrict__ cin, const float* __restrict__ w, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = rd_lrelu(v[e]);
-          if (use_drop) t = rd_drop_apply(t, key, (uint32_t)idx + idx_base + e);
+          if (use_drop) t = rd_drop_apply_w(t, rd_drop_word(key, (uint32_t)idx + idx_base), e);
           v[e] = t;
         }
       } else {

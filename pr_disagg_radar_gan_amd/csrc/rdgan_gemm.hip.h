@@ -72,6 +72,11 @@ __device__ __forceinline__ float rd_drop_apply(float x, uint32_t key, uint32_t i
   const float y = x * s;
   return s != 0.f ? (y == 0.f ? -0.0f : y) : 0.0f;
 }
+// the same for element idx0 + e of an aligned quad (idx0 % 4 == 0) whose hash word is `word` = rd_drop_word(key, idx0)
+__device__ __forceinline__ float rd_drop_apply_w(float x, uint32_t word, int e) {
+  const float y = x * (1.0f / 0.75f);
+  return rd_drop_keep(word, (uint32_t)e) ? (y == 0.f ? -0.0f : y) : 0.0f;
+}
 // LeakyReLU'(features) x dropout factor from the layer's stored output h (TF: features > 0 ? 1 : alpha; dropout grad = mask/0.75)
 __device__ __forceinline__ float rd_gate_from_out(float h, int use_drop) {
   float g = h > 0.f ? 1.f : RD_LRELU_ALPHA;
@@ -597,7 +602,7 @@ k_conv_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ sr
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = rd_lrelu(v[e]);
-            if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply(x, epi.key, ibase + (rb / OSZ) + e);
+            if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply_w(x, rd_drop_word(epi.key, ibase + (rb / OSZ)), e);
             v[e] = x;
           }
         } else if (mode == RD_EPI_GATE_AUX) {
@@ -673,7 +678,7 @@ __global__ void k_splitk_finish(float* dst, long total, int N, RdEpi epi) {
         x = rd_lrelu(x + epi.bias[col0 + e]);
       } else if (mode == RD_EPI_BIAS_LRELU_DROP) {
         x = rd_lrelu(x + epi.bias[col0 + e]);
-        if (epi.use_drop) x = rd_drop_apply(x, epi.key, (uint32_t)idx + epi.idx_base);
+        if (epi.use_drop) x = rd_drop_apply_w(x, rd_drop_word(epi.key, (uint32_t)idx0 + epi.idx_base), e);
       } else if (mode == RD_EPI_GATE_AUX) {
         const float g = rd_gate_from_out(OUT16 ? rd_ld1((const rd_bf16_t*)epi.aux + idx) : epi.aux[idx], epi.use_drop);
         x *= g;

@@ -577,7 +577,7 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float x = rd_lrelu(v[e]);
-              if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply(x, epi.key, ibase + (rb >> 2) + e);
+              if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply_w(x, rd_drop_word(epi.key, ibase + (rb >> 2)), e);
               v[e] = x;
             }
           } else if (mode == RD_EPI_GATE_AUX) {
@@ -629,7 +629,7 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = rd_lrelu(v[e]);
-          if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply(x, epi.key, ibase + (rb >> 2) + e);
+          if (mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop) x = rd_drop_apply_w(x, rd_drop_word(epi.key, ibase + (rb >> 2)), e);
           v[e] = x;
         }
       } else if (mode == RD_EPI_GATE_AUX) {
