@@ -150,6 +150,10 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * the 11 x 7 x 7 grid, eight parity phases of 8 ... 1 taps) runs in the slab kernel k_d2_dgrad_slab16: two samples' output
  * gradient resident in LDS for all phases and taps, weights streamed in MFMA-fragment order, LeakyReLU' x dropout gate + bf16
  * rounding in registers (rdgan_d2slab16.hip.h).  Same taps and k order as the streaming GEMM (0).
+ * "upwgrad_slab" (default 1; bf16 storage mode, ndomain 16, collapsed form): the weight gradient of generator block 3 runs in the slab
+ * kernel k_upconv_wgrad_slab16: a workgroup owns one output-parity phase and keeps its eight tap products (eight 128 x 64 fp32
+ * tiles, one per wave) in registers over its share of the batch; source planes and output-gradient rows arrive by LDS-DMA in two
+ * stages, both MFMA operands are read transposed from the position-major images (rdgan_upwgrad16.hip.h).  0 = k_wgrad_gemm_ws16<256,64>.
  * "d1_dgrad_fused" (default 1; bf16 storage mode, ndomain 16, one condition channel): the first critic layer's input gradient
  * with respect to the sample channel (the penalty's dD/dx_hat and the generator step's dL/dfake) in one pass per sample
  * (k_d1_dgrad_sample16: the 539 x 27 tap products of a sample stay in LDS, the outputs gather from there); same sums in the same
@@ -286,6 +290,11 @@ int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, int B, int nd
  * back as fp32 (the bf16 output widened), rinv [B,24,16,16] = 1/l2 per grid point; dbg: NULL, or [B*24*16*16][4] floats (test
  * hook: row sum of squares and 1/l2 as the two lane halves of a row computed them). */
 int rdgan_op_upconv_slab16(const float* x, const float* w, const float* bias, float* y, float* rinv, float* dbg, int B, void* stream);
+/* Weight gradient of generator block 3 in the collapsed form (backward of T:340-341 on the 12 x 8 x 8 x 128 input of ndomain 16)
+ * through the slab kernel of the bf16 storage mode alone (k_upconv_wgrad_slab16): x [B,12,8,8,128] and dy [B,24,16,16,64] (gradient
+ * at the conv output) are rounded to bf16 on the device; dWc [64 = phase*8 + tap][128][64] fp32 -- entry (phase, tap) is the sum over
+ * samples and source positions r of x[r + off(phase, tap)] (outer) dy[2 r + phase], off = phase - 1 + tap per axis. */
+int rdgan_op_upconv_wgrad_slab16(const float* x, const float* dy, float* dWc, int B, void* stream);
 /* Input gradient of the critic's second layer (backward of T:291, Conv3D(128, 3x3x3, stride 2, 'same') on the 11 x 7 x 7 x 64
  * output of layer 1, ndomain 16) through the slab kernel of the bf16 storage mode alone (k_d2_dgrad_slab16): gy [B,6,4,4,128], the
  * layer's kernel w [3,3,3,64,128] and aux [B,11,7,7,64] (layer 1's output) are rounded to bf16 on the device;

@@ -21,6 +21,7 @@
 #include "rdgan_data.hip.h"
 #include "rdgan_edge.hip.h"
 #include "rdgan_d2slab16.hip.h"
+#include "rdgan_upwgrad16.hip.h"
 static_assert(RDGAN_LOSS_SLOTS == 8, "k_critic_losses / k_gen_loss write slots 0..7");
 // k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
 static bool g9w_mfma_ok(int nd, long npix) { return nd >= 8 && nd <= 128 && (nd & (nd - 1)) == 0 && npix < 0x7FFFFFFFL; }
@@ -391,6 +392,7 @@ struct rdgan_handle {
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
   void* bW2S;                     // weight image of the slab kernel of critic layer 2's input gradient (rdgan_d2slab16.hip.h): 432 KB
+  int upwgrad_slab = 1;           // 1: bf16 storage mode, ndomain 16, collapsed form: weight gradient of generator block 3 by k_upconv_wgrad_slab16
   int d1_dgrad_fused = 1;         // 1: bf16 storage mode, ndomain 16: dD/d(sample) of layer 1 in one pass per sample (k_d1_dgrad_sample16)
   int d1_wgrad16 = 1;             // 1: bf16 storage mode: layer-1 weight gradient + bias gradient on the bf16 matrix pipe (k_d1_wgrad16)
   int d2_slab = 1;                // 1: bf16 storage mode, ndomain 16: input gradient of critic layer 2 by k_d2_dgrad_slab16
@@ -1164,6 +1166,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     if (g9w_mfma_ok(nd, (long)MB * h->gpix[3]))                            // k_g9_wgrad_mfma: [27][64] per persistent workgroup
       wneed = std::max(wneed, (size_t)std::min<long>(((long)MB * h->gpix[3] + 127) / 128, 768) * 1728);
   }
+  if (nd == 16) wneed = std::max(wneed, (size_t)32 * 64 * RD_UWG_TILE);     // k_upconv_wgrad_slab16: [32 groups][64][128][64]
   h->wpartial_cap = wneed;
   h->cpartial_cap = (size_t)1024 * std::max(h->n_nodes, 256);
   {  // split-K partials: up to 8 copies of the largest small-M destination (critic layers 3/4, Dense, generator block 1)
@@ -1311,6 +1314,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_wgrad16")) { h->d1_wgrad16 = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_slab")) { h->d2_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
@@ -2204,7 +2208,20 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       }
     } else if (col) {
       int plf = PL_G1FC + l - 1, plb = PL_G1BC + l - 1;
-      if (a16) {
+      if (a16 && l == 3 && h->upwgrad_slab && h->nd == 16) {
+        // each workgroup owns one phase and keeps its eight tap products in registers over its share of the batch
+        ProfScope ps(h, RDGAN_TAG_GCONV_WGRAD, st);
+        LaunchScope ls(h, plf, RD_KIND_WGRAD, B, plan_flops(h->plans[plf], B), st);
+        RD_KNAME(h, "k_upconv_wgrad_slab16<bf16>");
+        h->flops_acc += plan_flops(h->plans[plf], B);
+        const int G = 6 * B >= 64 ? 32 : 8;
+        if ((size_t)G * 64 * RD_UWG_TILE > h->wpartial_cap) return bad_arg(h, "upconv wgrad: partial workspace too small");
+        RD_TRY(ensure_lds(h, (const void*)k_upconv_wgrad_slab16, RD_UWG_LDS));
+        hipLaunchKernelGGL(k_upconv_wgrad_slab16, dim3(8 * G), dim3(512), RD_UWG_LDS, st, (const rd_bf16_t*)hs[l - 1],
+                           (const rd_bf16_t*)dys[l], h->wpartial, B, G);
+        hipLaunchKernelGGL(k_upconv_wgrad_fold, dim3(64 * RD_UWG_TILE / 4 / 256), dim3(256), 0, st, h->wpartial, G, h->dWc);
+        RD_CHECK(h, hipGetLastError());
+      } else if (a16) {
         if (!wgrad16_ok(h->plans[plf], B)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this block");
         RD_TRY(launch_wgrad16(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap, st,
                               RDGAN_TAG_GCONV_WGRAD));
@@ -2537,6 +2554,30 @@ extern "C" int rdgan_op_upconv_slab16(const float* x, const float* w, const floa
   }
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   for (void* p : {xb, yb, wi, (void*)wc}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// Collapsed weight gradient of generator block 3 through the slab kernel alone (rdgan_upwgrad16.hip.h), ndomain 16: x [B,12,8,8,128]
+// and dy [B,24,16,16,64] are rounded to bf16 on the device; dWc [64 = phase*8 + tap][128][64] fp32.
+extern "C" int rdgan_op_upconv_wgrad_slab16(const float* x, const float* dy, float* dWc, int B, void* stream) {
+  if (!x || !dy || !dWc || B < 1) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long nx = (long)B * 12 * 64 * 128, ny = (long)B * 24 * 256 * 64;
+  const int G = 6 * B >= 64 ? 32 : 8;
+  void *xb = nullptr, *yb = nullptr; float* part = nullptr;
+  int rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc((void**)&part, (size_t)G * 64 * RD_UWG_TILE * sizeof(float));
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) rc = launch_to_bf16(nullptr, dy, yb, ny, st);
+  if (rc == 0) rc = ensure_lds(nullptr, (const void*)k_upconv_wgrad_slab16, RD_UWG_LDS);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_upconv_wgrad_slab16, dim3(8 * G), dim3(512), RD_UWG_LDS, st, (const rd_bf16_t*)xb, (const rd_bf16_t*)yb, part, B, G);
+    hipLaunchKernelGGL(k_upconv_wgrad_fold, dim3(64 * RD_UWG_TILE / 4 / 256), dim3(256), 0, st, part, G, dWc);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {xb, yb, (void*)part}) if (p) (void)hipFree(p);
   return rc;
 }
 

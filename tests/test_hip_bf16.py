@@ -164,6 +164,35 @@ def test_d2_slab_kernel_equals_the_streaming_gemm(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [4, 40])
+def test_upwgrad_slab_equals_the_streaming_wgrad(B):
+    """"upwgrad_slab" (default on at ndomain 16): generator block 3's weight gradient in the slab kernel k_upconv_wgrad_slab16
+    against k_wgrad_gemm_ws16<256,64> of the same engine: the same bf16 products summed in fp32 in another order -- block 3's
+    kernel gradient within 2e-5 of its largest entry, every other entry of the generator-step slab equal bit for bit."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 63)
+        x, cond, z = ot.synthetic_batch(B, 16, 54)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("upwgrad_slab", on)
+            res[on] = eng.gen_grad(ds, gs, dev(z), dev(cond), 26).clone()
+            assert torch.equal(res[on], eng.gen_grad(ds, gs, dev(z), dev(cond), 26))
+        a, b = res[0].cpu().numpy(), res[1].cpu().numpy()
+        off, layout = 0, {}
+        for name, shp in eng.gen_shapes:
+            n = int(np.prod(shp)); layout[name] = (off, n); off += n
+        (o3, n3) = [v for k, v in layout.items() if tuple(dict(eng.gen_shapes)[k]) == (3, 3, 3, 128, 64)][0]
+        e = np.abs(a[o3:o3 + n3] - b[o3:o3 + n3]).max() / np.abs(a[o3:o3 + n3]).max()
+        print(f"B {B} upwgrad_slab 1 vs 0: block-3 kernel gradient differs by {e:.2e} of its largest entry")
+        assert e < 2e-5
+        assert np.array_equal(a[:o3], b[:o3]) and np.array_equal(a[o3 + n3:], b[o3 + n3:])
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [1, 6, 600])
 def test_d1_dgrad_fused_equals_the_column_gemm_bit_for_bit(B):
     """"d1_dgrad_fused" (default on at ndomain 16): dD/d(sample) of the first critic layer in one pass per sample

@@ -324,3 +324,34 @@ def test_d2_dgrad_slab_kernel_vs_oracle(B):
         g1d, w1d, a1d = dev(gy1), dev(w1), dev(a1)
         assert lib().rdgan_op_d2_dgrad_slab16(ptr(g1d), ptr(w1d), ptr(a1d), ptr(gx), 1, 0, stream()) == 0
         np.testing.assert_array_equal(gx.cpu().numpy(), want.astype(np.float32)), tap
+
+
+@pytest.mark.parametrize("B", [1, 3, 12])
+def test_upconv_wgrad_slab_kernel_vs_definition(B):
+    """k_upconv_wgrad_slab16 alone (rdgan_op_upconv_wgrad_slab16): the collapsed weight gradient of generator block 3 (backward of
+    T:340-341) -- entry (phase, tap) = sum over samples and source positions r of x[r + phase - 1 + tap] (outer) dy[2 r + phase],
+    zero outside the picture -- against the definition in fp64 on the bf16-rounded operands.  bf16 products are exact in fp32 and
+    the kernel accumulates in fp32: 2e-5 of the largest entry.  B = 12: 32 groups of workgroups (two stages in flight), B = 1, 3:
+    8 groups, some without an item."""
+    rng = np.random.default_rng(300 + B)
+    x = rng.standard_normal((B, 12, 8, 8, 128)).astype(np.float32)
+    dy = rng.standard_normal((B, 24, 16, 16, 64)).astype(np.float32)
+    xr, dyr = _bf16_round(x).astype(np.float64), _bf16_round(dy).astype(np.float64)
+    xp = np.zeros((B, 14, 10, 10, 128)); xp[:, 1:13, 1:9, 1:9] = xr
+    ref = np.zeros((64, 128, 64))
+    for p in range(8):
+        par = (p >> 2, (p >> 1) & 1, p & 1)
+        dyp = dyr[:, par[0]::2, par[1]::2, par[2]::2]
+        for t in range(8):
+            o = [par[a] - 1 + ((t >> (2 - a)) & 1) for a in range(3)]
+            xs = xp[:, 1 + o[0]:13 + o[0], 1 + o[1]:9 + o[1], 1 + o[2]:9 + o[2]]
+            ref[p * 8 + t] = np.einsum("bdhwi,bdhwo->io", xs, dyp, optimize=True)
+    xd, dyd = dev(x), dev(dy)
+    out = torch.full((64, 128, 64), float("nan"), device="cuda")
+    assert lib().rdgan_op_upconv_wgrad_slab16(ptr(xd), ptr(dyd), ptr(out), B, stream()) == 0
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - ref).max() < 2e-5 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+    out2 = torch.empty_like(out)
+    assert lib().rdgan_op_upconv_wgrad_slab16(ptr(xd), ptr(dyd), ptr(out2), B, stream()) == 0
+    assert torch.equal(out, out2)                                   # deterministic
