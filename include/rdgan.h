@@ -150,6 +150,10 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * the 11 x 7 x 7 grid, eight parity phases of 8 ... 1 taps) runs in the slab kernel k_d2_dgrad_slab16: two samples' output
  * gradient resident in LDS for all phases and taps, weights streamed in MFMA-fragment order, LeakyReLU' x dropout gate + bf16
  * rounding in registers (rdgan_d2slab16.hip.h).  Same taps and k order as the streaming GEMM (0).
+ * "d2_wgrad_slab" (default 1; bf16 storage mode, ndomain 16): the weight gradient of the critic's second layer runs in the slab
+ * kernel k_d2_wgrad_slab16: a wave owns one of the 27 taps and keeps its 64 x 128 product in registers over the workgroup's share
+ * of the batch; by input parity the taps fall into 8 classes, each a dense sub-grid of layer 1's output on which its taps are shifts
+ * (rdgan_d2wgrad16.hip.h).  0 = k_wgrad_gemm_ws16<128,128>.
  * "upwgrad_slab" (default 1; bf16 storage mode, ndomain 16, collapsed form): the weight gradient of generator block 3 runs in the slab
  * kernel k_upconv_wgrad_slab16: a workgroup owns one output-parity phase and keeps its eight tap products (eight 128 x 64 fp32
  * tiles, one per wave) in registers over its share of the batch; source planes and output-gradient rows arrive by LDS-DMA in two
@@ -295,6 +299,10 @@ int rdgan_op_upconv_slab16(const float* x, const float* w, const float* bias, fl
  * at the conv output) are rounded to bf16 on the device; dWc [64 = phase*8 + tap][128][64] fp32 -- entry (phase, tap) is the sum over
  * samples and source positions r of x[r + off(phase, tap)] (outer) dy[2 r + phase], off = phase - 1 + tap per axis. */
 int rdgan_op_upconv_wgrad_slab16(const float* x, const float* dy, float* dWc, int B, void* stream);
+/* Weight gradient of the critic's second layer (backward of T:291, Conv3D(128, 3x3x3, stride 2, 'same') on 11 x 7 x 7 x 64) through
+ * the slab kernel of the bf16 storage mode alone (k_d2_wgrad_slab16): x [B,11,7,7,64] (layer 1's output) and dy [B,6,4,4,128] are
+ * rounded to bf16 on the device; dW [3,3,3,64,128] fp32 = sum over samples and output positions o of x[2 o + tap - 1] (outer) dy[o]. */
+int rdgan_op_d2_wgrad_slab16(const float* x, const float* dy, float* dW, int B, void* stream);
 /* Input gradient of the critic's second layer (backward of T:291, Conv3D(128, 3x3x3, stride 2, 'same') on the 11 x 7 x 7 x 64
  * output of layer 1, ndomain 16) through the slab kernel of the bf16 storage mode alone (k_d2_dgrad_slab16): gy [B,6,4,4,128], the
  * layer's kernel w [3,3,3,64,128] and aux [B,11,7,7,64] (layer 1's output) are rounded to bf16 on the device;

@@ -22,6 +22,7 @@
 #include "rdgan_edge.hip.h"
 #include "rdgan_d2slab16.hip.h"
 #include "rdgan_upwgrad16.hip.h"
+#include "rdgan_d2wgrad16.hip.h"
 static_assert(RDGAN_LOSS_SLOTS == 8, "k_critic_losses / k_gen_loss write slots 0..7");
 // k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
 static bool g9w_mfma_ok(int nd, long npix) { return nd >= 8 && nd <= 128 && (nd & (nd - 1)) == 0 && npix < 0x7FFFFFFFL; }
@@ -392,6 +393,7 @@ struct rdgan_handle {
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
   void* bW2S;                     // weight image of the slab kernel of critic layer 2's input gradient (rdgan_d2slab16.hip.h): 432 KB
+  int d2_wgrad_slab = 1;          // 1: bf16 storage mode, ndomain 16: weight gradient of critic layer 2 by k_d2_wgrad_slab16
   int upwgrad_slab = 1;           // 1: bf16 storage mode, ndomain 16, collapsed form: weight gradient of generator block 3 by k_upconv_wgrad_slab16
   int d1_dgrad_fused = 1;         // 1: bf16 storage mode, ndomain 16: dD/d(sample) of layer 1 in one pass per sample (k_d1_dgrad_sample16)
   int d1_wgrad16 = 1;             // 1: bf16 storage mode: layer-1 weight gradient + bias gradient on the bf16 matrix pipe (k_d1_wgrad16)
@@ -1166,6 +1168,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     if (g9w_mfma_ok(nd, (long)MB * h->gpix[3]))                            // k_g9_wgrad_mfma: [27][64] per persistent workgroup
       wneed = std::max(wneed, (size_t)std::min<long>(((long)MB * h->gpix[3] + 127) / 128, 768) * 1728);
   }
+  if (nd == 16) wneed = std::max(wneed, (size_t)64 * 27 * RD_D2W_TILE);    // k_d2_wgrad_slab16: [64 groups][27][64][128]
   if (nd == 16) wneed = std::max(wneed, (size_t)32 * 64 * RD_UWG_TILE);     // k_upconv_wgrad_slab16: [32 groups][64][128][64]
   h->wpartial_cap = wneed;
   h->cpartial_cap = (size_t)1024 * std::max(h->n_nodes, 256);
@@ -1314,6 +1317,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "d2_wgrad_slab")) { h->d2_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_wgrad16")) { h->d1_wgrad16 = value ? 1 : 0; return 0; }
@@ -1980,6 +1984,19 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
     const bool padded = l == 1 && h->CP != h->Cin;   // D1 with padding channels: gradient of the padded kernel, then drop the pad rows
     if (l == 1 && d1_gemm_ok(h)) {
       RD_TRY(launch_d1_wgrad(h, in, h->du[1], grad + h->doff[0], NBt, st, grad + h->doff[1], (long)2 * B * h->dL[1]));
+    } else if (a16 && l == 2 && h->d2_wgrad_slab && h->nd == 16) {
+      // a wave owns one tap: its [64 x 128] product stays in registers over the workgroup's share of the batch
+      ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+      LaunchScope ls(h, pl, RD_KIND_WGRAD, NBt, plan_flops(h->plans[pl], NBt), st);
+      RD_KNAME(h, "k_d2_wgrad_slab16<bf16>");
+      h->flops_acc += plan_flops(h->plans[pl], NBt);
+      const int G = NBt >= 64 ? 64 : 8;
+      if ((size_t)G * 27 * RD_D2W_TILE > h->wpartial_cap) return bad_arg(h, "d2 wgrad: partial workspace too small");
+      RD_TRY(ensure_lds(h, (const void*)k_d2_wgrad_slab16, RD_D2W_LDS));
+      hipLaunchKernelGGL(k_d2_wgrad_slab16, dim3(4 * G), dim3(512), RD_D2W_LDS, st, (const rd_bf16_t*)in, (const rd_bf16_t*)h->du[2],
+                         h->wpartial, NBt, G);
+      hipLaunchKernelGGL(k_d2_wgrad_fold, dim3((27 * RD_D2W_TILE / 4 + 255) / 256), dim3(256), 0, st, h->wpartial, G, grad + h->doff[2]);
+      RD_CHECK(h, hipGetLastError());
     } else if (a16 && l >= 2) {      // layers 2-4: bf16 activations against bf16 output gradients
       if (!wgrad16_ok(h->plans[pl], NBt)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this critic layer");
       RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], grad + h->doff[2 * (l - 1)], h->wpartial,
@@ -2574,6 +2591,30 @@ extern "C" int rdgan_op_upconv_wgrad_slab16(const float* x, const float* dy, flo
   if (rc == 0) {
     hipLaunchKernelGGL(k_upconv_wgrad_slab16, dim3(8 * G), dim3(512), RD_UWG_LDS, st, (const rd_bf16_t*)xb, (const rd_bf16_t*)yb, part, B, G);
     hipLaunchKernelGGL(k_upconv_wgrad_fold, dim3(64 * RD_UWG_TILE / 4 / 256), dim3(256), 0, st, part, G, dWc);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {xb, yb, (void*)part}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// Weight gradient of the critic's second layer through the slab kernel alone (rdgan_d2wgrad16.hip.h), ndomain 16: x [B,11,7,7,64]
+// (layer 1's output) and dy [B,6,4,4,128] are rounded to bf16 on the device; dW [3,3,3,64,128] fp32.
+extern "C" int rdgan_op_d2_wgrad_slab16(const float* x, const float* dy, float* dW, int B, void* stream) {
+  if (!x || !dy || !dW || B < 1) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long nx = (long)B * 539 * 64, ny = (long)B * 96 * 128;
+  const int G = B >= 64 ? 64 : 8;
+  void *xb = nullptr, *yb = nullptr; float* part = nullptr;
+  int rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc((void**)&part, (size_t)G * 27 * RD_D2W_TILE * sizeof(float));
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) rc = launch_to_bf16(nullptr, dy, yb, ny, st);
+  if (rc == 0) rc = ensure_lds(nullptr, (const void*)k_d2_wgrad_slab16, RD_D2W_LDS);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_d2_wgrad_slab16, dim3(4 * G), dim3(512), RD_D2W_LDS, st, (const rd_bf16_t*)xb, (const rd_bf16_t*)yb, part, B, G);
+    hipLaunchKernelGGL(k_d2_wgrad_fold, dim3((27 * RD_D2W_TILE / 4 + 255) / 256), dim3(256), 0, st, part, G, dW);
     rc = (int)hipGetLastError();
   }
   if (rc == 0) rc = (int)hipStreamSynchronize(st);

@@ -164,6 +164,32 @@ def test_d2_slab_kernel_equals_the_streaming_gemm(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [2, 30])
+def test_d2_wgrad_slab_equals_the_streaming_wgrad(B):
+    """"d2_wgrad_slab" (default on at ndomain 16): critic layer 2's weight gradient in the slab kernel k_d2_wgrad_slab16 against
+    k_wgrad_gemm_ws16<128,128> of the same engine over the 3 B batch [real; fake; second-sweep r1]: the same bf16 products summed in
+    fp32 in another order -- that kernel gradient within 2e-5 of its largest entry, the rest of the critic-step slab bit for bit."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 65)
+        x, cond, z = ot.synthetic_batch(B, 16, 56)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("d2_wgrad_slab", on)
+            res[on] = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 28).clone()
+            assert torch.equal(res[on], eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 28))
+        a, b = res[0].cpu().numpy(), res[1].cpu().numpy()
+        o2 = 27 * 2 * 64 + 64; n2 = 27 * 64 * 128
+        e = np.abs(a[o2:o2 + n2] - b[o2:o2 + n2]).max() / np.abs(a[o2:o2 + n2]).max()
+        print(f"B {B} d2_wgrad_slab 1 vs 0: layer-2 kernel gradient differs by {e:.2e} of its largest entry")
+        assert 0 <= e < 2e-5
+        assert np.array_equal(a[:o2], b[:o2]) and np.array_equal(a[o2 + n2:], b[o2 + n2:])
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [4, 40])
 def test_upwgrad_slab_equals_the_streaming_wgrad(B):
     """"upwgrad_slab" (default on at ndomain 16): generator block 3's weight gradient in the slab kernel k_upconv_wgrad_slab16

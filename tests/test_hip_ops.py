@@ -355,3 +355,29 @@ def test_upconv_wgrad_slab_kernel_vs_definition(B):
     out2 = torch.empty_like(out)
     assert lib().rdgan_op_upconv_wgrad_slab16(ptr(xd), ptr(dyd), ptr(out2), B, stream()) == 0
     assert torch.equal(out, out2)                                   # deterministic
+
+
+@pytest.mark.parametrize("B", [1, 5, 70])
+def test_d2_wgrad_slab_kernel_vs_definition(B):
+    """k_d2_wgrad_slab16 alone (rdgan_op_d2_wgrad_slab16): weight gradient of the critic's second layer (backward of T:291,
+    stride 2, 'same': dW[tap] = sum_o x[2 o + tap - 1] (outer) dy[o]) against torch autograd of the definition in fp64 on the
+    bf16-rounded operands; fp32 accumulation of exact bf16 products: 2e-5 of the largest entry.  B = 70: 64 groups of workgroups,
+    B = 1, 5: 8 groups, some without a sample."""
+    g = torch.Generator(); g.manual_seed(400 + B)
+    x = torch.randn((B, 11, 7, 7, 64), generator=g)
+    dy = torch.randn((B, 6, 4, 4, 128), generator=g)
+    xr, dyr = x.bfloat16().double(), dy.bfloat16().double()
+    w = torch.zeros((3, 3, 3, 64, 128), dtype=torch.float64, requires_grad=True)
+    y = ot._conv3d_tf(xr, w, torch.zeros(128, dtype=torch.float64), 2, (1, 1, 1), (6, 4, 4))
+    (ref,) = torch.autograd.grad((y * dyr).sum(), w)
+    ref = ref.numpy()
+    xd, dyd = dev(x.numpy()), dev(dy.numpy())
+    out = torch.full((3, 3, 3, 64, 128), float("nan"), device="cuda")
+    assert lib().rdgan_op_d2_wgrad_slab16(ptr(xd), ptr(dyd), ptr(out), B, stream()) == 0
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(got))
+    err = np.abs(got - ref).max(axis=(3, 4)) / np.abs(ref).max()
+    assert err.max() < 2e-5, err
+    out2 = torch.empty_like(out)
+    assert lib().rdgan_op_d2_wgrad_slab16(ptr(xd), ptr(dyd), ptr(out2), B, stream()) == 0
+    assert torch.equal(out, out2)                                   # deterministic
