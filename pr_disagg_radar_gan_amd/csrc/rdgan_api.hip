@@ -376,6 +376,7 @@ struct rdgan_handle {
   size_t ws_bytes = 0;
   float *xcat, *h0, *h1, *r1, *h2, *r2, *h3, *r3, *P9, *fake, *dl, *gh3, *gup3, *dy2, *gup2, *dy1, *gup1, *ga0;
   float *cin, *dh[5], *du[5], *v, *P1, *g0, *gpv;
+  float* ubias_part = nullptr;    // k_upconv_wgrad_slab16's bias-gradient partials [32 groups][8 phases][64]
   float *wpartial, *cpartial, *kpartial;
   size_t wpartial_cap = 0, cpartial_cap = 0, kpartial_cap = 0;
   float *DWT[5], *W1T, *GWT[4], *W9T, *W1P, *dW1P;
@@ -1255,6 +1256,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     }
     { float* f = nullptr; carve(f, 64); if (pass == 1) h->d_flag = (int*)f; }
     carve(h->g9b_tmp, 64);
+    carve(h->ubias_part, 32 * 8 * 64);
     carve(h->gp_part, (size_t)MB * 64);
     carve(h->dw6_part, (size_t)16 * h->F);
     if (pass == 0) {
@@ -2225,6 +2227,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       }
     } else if (col) {
       int plf = PL_G1FC + l - 1, plb = PL_G1BC + l - 1;
+      bool bias_done = false;         // (the slab kernel delivers the bias gradient too)
       if (a16 && l == 3 && h->upwgrad_slab && h->nd == 16) {
         // each workgroup owns one phase and keeps its eight tap products in registers over its share of the batch
         ProfScope ps(h, RDGAN_TAG_GCONV_WGRAD, st);
@@ -2235,8 +2238,10 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
         if ((size_t)G * 64 * RD_UWG_TILE > h->wpartial_cap) return bad_arg(h, "upconv wgrad: partial workspace too small");
         RD_TRY(ensure_lds(h, (const void*)k_upconv_wgrad_slab16, RD_UWG_LDS));
         hipLaunchKernelGGL(k_upconv_wgrad_slab16, dim3(8 * G), dim3(512), RD_UWG_LDS, st, (const rd_bf16_t*)hs[l - 1],
-                           (const rd_bf16_t*)dys[l], h->wpartial, B, G);
+                           (const rd_bf16_t*)dys[l], h->wpartial, B, G, h->ubias_part);
         hipLaunchKernelGGL(k_upconv_wgrad_fold, dim3(64 * RD_UWG_TILE / 4 / 256), dim3(256), 0, st, h->wpartial, G, h->dWc);
+        hipLaunchKernelGGL(k_upconv_bias_fold, dim3(1), dim3(64), 0, st, h->ubias_part, 8 * G, grad + h->goff[2 * l + 1]);
+        bias_done = true;
         RD_CHECK(h, hipGetLastError());
       } else if (a16) {
         if (!wgrad16_ok(h->plans[plf], B)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this block");
@@ -2247,6 +2252,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
                           st, RDGAN_TAG_GCONV_WGRAD));
       hipLaunchKernelGGL(k_fold_collapsed_wgrad, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->dWc,
                          grad + h->goff[2 * l], (int)cc);
+      if (!bias_done)
       RD_TRY(launch_colsum(h, dys[l], (long)B * h->gpix[l], h->gch[l], grad + h->goff[2 * l + 1], side_fork(h, st), a16));   // bias gradient, beside the GEMMs (dys[l] is read-only from here on)
       if (a16) {      // the collapsed forms re-ordered by tap are already [N = Cin][K = Cout]
         RdSliceMap map;

@@ -194,7 +194,8 @@ def test_d2_wgrad_slab_equals_the_streaming_wgrad(B):
 def test_upwgrad_slab_equals_the_streaming_wgrad(B):
     """"upwgrad_slab" (default on at ndomain 16): generator block 3's weight gradient in the slab kernel k_upconv_wgrad_slab16
     against k_wgrad_gemm_ws16<256,64> of the same engine: the same bf16 products summed in fp32 in another order -- block 3's
-    kernel gradient within 2e-5 of its largest entry, every other entry of the generator-step slab equal bit for bit."""
+    kernel gradient within 2e-5 of its largest entry; the block's bias gradient comes out of the same kernel (column sums of the
+    output-gradient fragments it multiplies) instead of a column-sum pass: 1e-5; every other entry of the slab equal bit for bit."""
     eng = Engine(ndomain=16, max_batch=B)
     try:
         g, d = _params(16, 63)
@@ -214,7 +215,10 @@ def test_upwgrad_slab_equals_the_streaming_wgrad(B):
         e = np.abs(a[o3:o3 + n3] - b[o3:o3 + n3]).max() / np.abs(a[o3:o3 + n3]).max()
         print(f"B {B} upwgrad_slab 1 vs 0: block-3 kernel gradient differs by {e:.2e} of its largest entry")
         assert e < 2e-5
-        assert np.array_equal(a[:o3], b[:o3]) and np.array_equal(a[o3 + n3:], b[o3 + n3:])
+        eb = np.abs(a[o3 + n3:o3 + n3 + 64] - b[o3 + n3:o3 + n3 + 64]).max() / np.abs(a[o3 + n3:o3 + n3 + 64]).max()
+        print(f"B {B} upwgrad_slab 1 vs 0: block-3 bias gradient differs by {eb:.2e} of its largest entry")
+        assert eb < 1e-5
+        assert np.array_equal(a[:o3], b[:o3]) and np.array_equal(a[o3 + n3 + 64:], b[o3 + n3 + 64:])
     finally:
         eng.close()
 
