@@ -157,7 +157,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "upwgrad_slab" (default 1; bf16 storage mode, ndomain 16, collapsed form): the weight gradient of generator block 3 runs in the slab
  * kernel k_upconv_wgrad_slab16: a workgroup owns one output-parity phase and keeps its eight tap products (eight 128 x 64 fp32
  * tiles, one per wave) in registers over its share of the batch; source planes and output-gradient rows arrive by LDS-DMA in two
- * stages, both MFMA operands are read transposed from the position-major images (rdgan_upwgrad16.hip.h).  0 = k_wgrad_gemm_ws16<256,64>.
+ * stages, both MFMA operands are read transposed from the position-major images (rdgan_upwgrad16.hip.h); block 2 the same way with a
+ * workgroup per (phase, quarter of the 256 input channels) (k_upconv2_wgrad_slab16).  Both deliver the block's bias gradient from
+ * the output-gradient fragments they multiply.  0 = k_wgrad_gemm_ws16 + column-sum passes.
  * "d1_dgrad_fused" (default 1; bf16 storage mode, ndomain 16, one condition channel): the first critic layer's input gradient
  * with respect to the sample channel (the penalty's dD/dx_hat and the generator step's dL/dfake) in one pass per sample
  * (k_d1_dgrad_sample16: the 539 x 27 tap products of a sample stay in LDS, the outputs gather from there); same sums in the same

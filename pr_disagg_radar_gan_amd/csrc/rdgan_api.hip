@@ -22,6 +22,7 @@
 #include "rdgan_edge.hip.h"
 #include "rdgan_d2slab16.hip.h"
 #include "rdgan_upwgrad16.hip.h"
+#include "rdgan_upwgrad16b.hip.h"
 #include "rdgan_d2wgrad16.hip.h"
 static_assert(RDGAN_LOSS_SLOTS == 8, "k_critic_losses / k_gen_loss write slots 0..7");
 // k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
@@ -1170,6 +1171,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
       wneed = std::max(wneed, (size_t)std::min<long>(((long)MB * h->gpix[3] + 127) / 128, 768) * 1728);
   }
   if (nd == 16) wneed = std::max(wneed, (size_t)64 * 27 * RD_D2W_TILE);    // k_d2_wgrad_slab16: [64 groups][27][64][128]
+  if (nd == 16) wneed = std::max(wneed, (size_t)8 * 64 * RD_UW2_TILE);      // k_upconv2_wgrad_slab16: [8 groups][64][256][128]
   if (nd == 16) wneed = std::max(wneed, (size_t)32 * 64 * RD_UWG_TILE);     // k_upconv_wgrad_slab16: [32 groups][64][128][64]
   h->wpartial_cap = wneed;
   h->cpartial_cap = (size_t)1024 * std::max(h->n_nodes, 256);
@@ -2241,6 +2243,21 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
                            (const rd_bf16_t*)dys[l], h->wpartial, B, G, h->ubias_part);
         hipLaunchKernelGGL(k_upconv_wgrad_fold, dim3(64 * RD_UWG_TILE / 4 / 256), dim3(256), 0, st, h->wpartial, G, h->dWc);
         hipLaunchKernelGGL(k_upconv_bias_fold, dim3(1), dim3(64), 0, st, h->ubias_part, 8 * G, grad + h->goff[2 * l + 1]);
+        bias_done = true;
+        RD_CHECK(h, hipGetLastError());
+      } else if (a16 && l == 2 && h->upwgrad_slab && h->nd == 16) {
+        // the same on block 2's geometry: a workgroup owns (phase, quarter of the 256 input channels)
+        ProfScope ps(h, RDGAN_TAG_GCONV_WGRAD, st);
+        LaunchScope ls(h, plf, RD_KIND_WGRAD, B, plan_flops(h->plans[plf], B), st);
+        RD_KNAME(h, "k_upconv2_wgrad_slab16<bf16>");
+        h->flops_acc += plan_flops(h->plans[plf], B);
+        const int G = 8;
+        if ((size_t)G * 64 * RD_UW2_TILE > h->wpartial_cap) return bad_arg(h, "upconv wgrad: partial workspace too small");
+        RD_TRY(ensure_lds(h, (const void*)k_upconv2_wgrad_slab16, RD_UW2_LDS));
+        hipLaunchKernelGGL(k_upconv2_wgrad_slab16, dim3(32 * G), dim3(512), RD_UW2_LDS, st, (const rd_bf16_t*)hs[l - 1],
+                           (const rd_bf16_t*)dys[l], h->wpartial, B, G, h->ubias_part);
+        hipLaunchKernelGGL(k_upconv2_wgrad_fold, dim3(64 * RD_UW2_TILE / 4 / 256), dim3(256), 0, st, h->wpartial, G, h->dWc);
+        hipLaunchKernelGGL(k_upconv2_bias_fold, dim3(1), dim3(128), 0, st, h->ubias_part, 8 * G, grad + h->goff[2 * l + 1]);
         bias_done = true;
         RD_CHECK(h, hipGetLastError());
       } else if (a16) {
