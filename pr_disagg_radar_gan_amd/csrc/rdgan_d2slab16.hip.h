@@ -174,10 +174,19 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
   rd_u32x2 gate[MB][8];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    const rd_bf16_t* arow = aux + (long)(srow[mb] >= 0 ? orow[mb] : (int)b0 * RD_D2S_OPOS) * 64 + 4 * lhalf;
+    // 16 bytes per lane (lane half h takes the 8-channel chunks 2 P + h), then each half hands the other the four channels it
+    // does not own (the inverse of the store path below): 4 instead of 8 load instructions per row block, 32 B per row and
+    // instruction instead of 16
+    const rd_bf16_t* arow = aux + (long)(srow[mb] >= 0 ? orow[mb] : (int)b0 * RD_D2S_OPOS) * 64 + 8 * lhalf;
 #pragma unroll
 #ifndef RD_D2S_ABL_NOGATE            // (diagnostic builds: no gate loads)
-    for (int G = 0; G < 8; ++G) gate[mb][G] = *(const rd_u32x2*)(arow + 8 * G);
+    for (int P = 0; P < 4; ++P) {
+      const u32x4_t w = *(const u32x4_t*)(arow + 16 * P);
+      const auto sx = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+      gate[mb][2 * P].x = sx[0]; gate[mb][2 * P + 1].x = sx[1];
+      gate[mb][2 * P].y = sy[0]; gate[mb][2 * P + 1].y = sy[1];
+    }
 #else
     for (int G = 0; G < 8; ++G) { gate[mb][G].x = 0x3F803F80u + G + orow[mb]; gate[mb][G].y = 0xBF803F80u; }
 #endif
