@@ -14,6 +14,10 @@
 // of 16 positions = one output hour plane each); both MFMA operands are read transposed from the position-major images
 // (ds_read_b64_tr_b16).  The four types of a group walk the same samples at the same time on the same XCD (output gradient from L2 for
 // three of them).  partial[group][tap][64][128], folded in a fixed order (k_d2_wgrad_fold).
+// (Measured and not kept: three stages with the sample two items ahead in flight and a counted `s_waitcnt vmcnt(n)` at the end of an
+// item -- 0.314 against 0.307 ms at 6144 samples: the waves do not wait for the DMA's latency.  SQ counters of the two-stage
+// kernel, profiles/r03_sq_counters_bf16_bs256.csv: matrix pipe busy 0.27 of the SIMD cycles -- 0.84 of the waves have a tap -- 0.46
+// of the wave cycles waiting at the per-item barrier or for an issue slot.)
 #pragma once
 #include "rdgan_gemm_ws16.hip.h"
 
