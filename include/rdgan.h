@@ -146,6 +146,10 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * planes + their halo resident in LDS for all 8 phases x 8 taps, weights streamed global -> VGPR in MFMA-fragment order, bias +
  * PixelNorm + LeakyReLU + bf16 rounding in registers (rdgan_upconv16.hip.h).  Same products as the streaming GEMM it replaces,
  * summed in another order: outputs agree to one bf16 ulp.  0 = the streaming GEMM (k_conv_gemm_ws<256, 64, ..., bf16>).
+ * "upconv2_slab" (default 1; same conditions): the forward of generator block 2 (256 -> 128 channels onto the 12 x 8 x 8 grid) in the
+ * slab kernel k_upconv2_slab16: a sample's whole block input (48 KB) resident in LDS for all 8 phases x 8 taps, the four waves of a
+ * workgroup split the 128 output channels (each streams its own weight fragments) and exchange the PixelNorm row sums of squares
+ * through LDS once per phase (rdgan_upconv16b.hip.h).  0 = the streaming GEMM (k_conv_gemm_ws<128, 128, ..., bf16>).
  * "d2_slab" (default 1; bf16 storage mode, ndomain 16): the input gradient of the critic's second layer (128 -> 64 channels onto
  * the 11 x 7 x 7 grid, eight parity phases of 8 ... 1 taps) runs in the slab kernel k_d2_dgrad_slab16: two samples' output
  * gradient resident in LDS for all phases and taps, weights streamed in MFMA-fragment order, LeakyReLU' x dropout gate + bf16
@@ -296,6 +300,10 @@ int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, int B, int nd
  * back as fp32 (the bf16 output widened), rinv [B,24,16,16] = 1/l2 per grid point; dbg: NULL, or [B*24*16*16][4] floats (test
  * hook: row sum of squares and 1/l2 as the two lane halves of a row computed them). */
 int rdgan_op_upconv_slab16(const float* x, const float* w, const float* bias, float* y, float* rinv, float* dbg, int B, void* stream);
+/* Generator block 2 forward of the bf16 storage mode (T:335-338 on the 6 x 4 x 4 x 256 input of ndomain 16) through the slab kernel
+ * alone (k_upconv2_slab16): x and w [3,3,3,256,128] are rounded to bf16 on the device, y [B,12,8,8,128] = LeakyReLU(PixelNorm(
+ * upconv(x) + bias)) comes back as fp32 (the bf16 output widened), rinv [B,12,8,8] = 1/l2 per grid point. */
+int rdgan_op_upconv2_slab16(const float* x, const float* w, const float* bias, float* y, float* rinv, int B, void* stream);
 /* Weight gradient of generator block 3 in the collapsed form (backward of T:340-341 on the 12 x 8 x 8 x 128 input of ndomain 16)
  * through the slab kernel of the bf16 storage mode alone (k_upconv_wgrad_slab16): x [B,12,8,8,128] and dy [B,24,16,16,64] (gradient
  * at the conv output) are rounded to bf16 on the device; dWc [64 = phase*8 + tap][128][64] fp32 -- entry (phase, tap) is the sum over

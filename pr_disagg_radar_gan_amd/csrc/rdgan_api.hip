@@ -17,6 +17,7 @@
 #include "rdgan_gemm_ws.hip.h"
 #include "rdgan_gemm_ws16.hip.h"
 #include "rdgan_upconv16.hip.h"
+#include "rdgan_upconv16b.hip.h"
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
 #include "rdgan_edge.hip.h"
@@ -394,6 +395,8 @@ struct rdgan_handle {
   void *bG1F[4], *bG1B, *bW1B;
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
+  void* bW2I = nullptr;           // weight image of the slab kernel of generator block 2 (rdgan_upconv16b.hip.h): 4 MB
+  int upconv2_slab = 1;           // 1: the same for block 2 (k_upconv2_slab16)
   void* bW2S;                     // weight image of the slab kernel of critic layer 2's input gradient (rdgan_d2slab16.hip.h): 432 KB
   int d2_wgrad_slab = 1;          // 1: bf16 storage mode, ndomain 16: weight gradient of critic layer 2 by k_d2_wgrad_slab16
   int upwgrad_slab = 1;           // 1: bf16 storage mode, ndomain 16, collapsed form: weight gradient of generator block 3 by k_upconv_wgrad_slab16
@@ -1252,6 +1255,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
         carve(p, 32L * h->ldp1 + 8); h->bW1B = p;
         carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3I = p;
+        carve(p, (long)RD_UP2_KSTEPS * 4 * 64 * 4 + 8); h->bW2I = p;
         carve(p, (long)RD_D2S_KSTEPS * 2 * 64 * 4 + 8); h->bW2S = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
@@ -1321,6 +1325,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "upconv2_slab")) { h->upconv2_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_wgrad_slab")) { h->d2_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
@@ -1477,6 +1482,9 @@ static bool gen_block_fast(const rdgan_handle* h, int l, int enabled) {
 static bool upconv_slab_on(const rdgan_handle* h, int l) {
   return h->upconv_slab && h->a16 && h->collapse && l == 3 && h->nd == 16 && !gen_block_fast(h, 3, fast_fwd_on(h));
 }
+static bool upconv2_slab_on(const rdgan_handle* h, int l) {
+  return h->upconv2_slab && h->a16 && h->collapse && l == 2 && h->nd == 16 && !gen_block_fast(h, 2, fast_fwd_on(h));
+}
 
 // `ws`: stream of the weight-only kernels (the handle's side stream, forked by the caller, or `st` itself): the weight forms of
 // block l are complete behind event ev_g[l], which `st` waits for in front of the block's GEMM
@@ -1487,7 +1495,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   RD_TRY(a16_check(h));
   // ---- weight forms (read only the weights): skipped when the caller vouches that the forms in the workspace were built from
   // these very weights (same slab, same content version, same form options)
-  const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0) | (h->upconv_slab ? 8 : 0);
+  const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0) | (h->upconv_slab ? 8 : 0) | (h->upconv2_slab ? 16 : 0);
   const bool forms_cached = h->gver_in != 0 && gp == h->gcache_ptr && h->gver_in == h->gcache_ver && gcfg == h->gcache_cfg;
   if (!forms_cached) {
   h->form_builds[0]++;
@@ -1505,6 +1513,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     } else if (h->collapse) {
       hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * cc)), dim3(256), 0, ws, Wl, h->GWC[l], (int)cc);
       if (upconv_slab_on(h, l)) hipLaunchKernelGGL(k_upconv_wimg, dim3(256), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW3I);
+      else if (upconv2_slab_on(h, l)) hipLaunchKernelGGL(k_upconv2_wimg, dim3(RD_UP2_KSTEPS), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW2I);
       else if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
     }
     if (ws != st) RD_CHECK(h, hipEventRecord(h->ev_g[l], ws));
@@ -1581,6 +1590,17 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       RD_TRY(ensure_lds(h, (const void*)k_upconv_slab16<1>, RD_UPC_LDS));
       hipLaunchKernelGGL(k_upconv_slab16<1>, dim3((unsigned)std::min(6 * B, 512)), dim3(256), RD_UPC_LDS, st, (const rd_bf16_t*)hs[l - 1],
                          (const rd_bf16_t*)h->bW3I, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B);
+      RD_CHECK(h, hipGetLastError());
+      continue;
+    }
+    if (upconv2_slab_on(h, l)) {    // block 2, bf16 storage: a sample resident in LDS, the four waves split the 128 channels
+      ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
+      LaunchScope ls(h, pl, RD_KIND_CONV, B, plan_flops(h->plans[pl], B), st);
+      RD_KNAME(h, "k_upconv2_slab16<bf16>");
+      h->flops_acc += plan_flops(h->plans[pl], B);
+      RD_TRY(ensure_lds(h, (const void*)k_upconv2_slab16, RD_UP2_LDS));
+      hipLaunchKernelGGL(k_upconv2_slab16, dim3((unsigned)std::min(B, 512)), dim3(256), RD_UP2_LDS, st, (const rd_bf16_t*)hs[l - 1],
+                         (const rd_bf16_t*)h->bW2I, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B);
       RD_CHECK(h, hipGetLastError());
       continue;
     }
@@ -2673,6 +2693,35 @@ extern "C" int rdgan_op_d2_dgrad_slab16(const float* gy, const float* w, const f
   }
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   for (void* p : {yb, ab, xb, wi}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// Generator block 2 forward of the bf16 storage mode through the slab kernel alone (rdgan_upconv16b.hip.h): x [B,6,4,4,256] and the
+// Conv3D kernel w [3,3,3,256,128] are rounded to bf16 on the device (the kernel after the upsample collapse), y [B,12,8,8,128] =
+// LeakyReLU(PixelNorm(upconv(x) + bias)) comes back as fp32 (the kernel's bf16 output widened), rinv [B,12,8,8].
+extern "C" int rdgan_op_upconv2_slab16(const float* x, const float* w, const float* bias, float* y, float* rinv, int B, void* stream) {
+  if (!x || !w || !bias || !y || !rinv || B < 1) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long nx = (long)B * 96 * 256, ny = (long)B * 768 * 128;
+  void *xb = nullptr, *yb = nullptr, *wi = nullptr; float* wc = nullptr;
+  int rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc(&wi, (long)RD_UP2_KSTEPS * 4 * 64 * 16);
+  if (rc == 0) rc = (int)hipMalloc((void**)&wc, 64L * 256 * 128 * sizeof(float));
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * 256 * 128)), dim3(256), 0, st, w, wc, 256 * 128);
+    hipLaunchKernelGGL(k_upconv2_wimg, dim3(RD_UP2_KSTEPS), dim3(256), 0, st, wc, (unsigned short*)wi);
+    rc = ensure_lds(nullptr, (const void*)k_upconv2_slab16, RD_UP2_LDS);
+  }
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_upconv2_slab16, dim3((unsigned)std::min(B, 512)), dim3(256), RD_UP2_LDS, st, (const rd_bf16_t*)xb,
+                       (const rd_bf16_t*)wi, bias, (rd_bf16_t*)yb, rinv, B);
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(ny)), dim3(256), 0, st, (const rd_bf16_t*)yb, y, ny);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {xb, yb, wi, (void*)wc}) if (p) (void)hipFree(p);
   return rc;
 }
 

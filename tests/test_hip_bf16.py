@@ -281,6 +281,35 @@ def test_d1_wgrad16_equals_the_fp32_pipe_kernel_up_to_operand_rounding(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [3, 96, 600])
+def test_upconv2_slab_kernel_equals_the_streaming_gemm_to_one_bf16_ulp(B):
+    """"upconv2_slab" (default on at ndomain 16): the forward of generator block 2 in the slab kernel k_upconv2_slab16 against the
+    streaming bf16 GEMM of the same engine -- the same bf16 products, summed in another order in fp32 and rounded to bf16 once: the
+    stored block output h2 differs by at most one bf16 ulp in a small share of the elements, and the generator output follows."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 67)
+        x, cond, z = ot.synthetic_batch(min(B, 64), 16, 58)
+        rep = lambda a: np.concatenate([a] * (B // a.shape[0] + 1))[:B]
+        cond, z = rep(cond), rep(z)
+        gs = eng.to_slab(g)
+        eng.set_option("bf16", 1)
+        res = {}
+        for slab in (0, 1):
+            eng.set_option("upconv2_slab", slab)
+            out = eng.gen_forward(gs, dev(z), dev(cond)).clone()
+            res[slab] = (out, eng.debug_activation(2, (B, 12, 8, 8, 128)).clone())
+            assert torch.equal(out, eng.gen_forward(gs, dev(z), dev(cond)))   # run-to-run deterministic
+        (o0, h0), (o1, h1) = res[0], res[1]
+        assert bool(torch.isfinite(h1).all())
+        rel = (h1 - h0).abs() / h0.abs().clamp_min(1e-3)
+        assert float(rel.max()) <= 2.0 ** -7 + 1e-6, float(rel.max())
+        assert float((h1 != h0).float().mean()) < 5e-3
+        assert float((o1 - o0).abs().max()) < 2e-3 * float(o0.max())
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:

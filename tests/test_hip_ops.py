@@ -381,3 +381,41 @@ def test_d2_wgrad_slab_kernel_vs_definition(B):
     out2 = torch.empty_like(out)
     assert lib().rdgan_op_d2_wgrad_slab16(ptr(xd), ptr(dyd), ptr(out2), B, stream()) == 0
     assert torch.equal(out, out2)                                   # deterministic
+
+
+@pytest.mark.parametrize("B", [1, 3, 520])
+def test_upconv2_slab_kernel_vs_oracle(B):
+    """k_upconv2_slab16 alone (rdgan_op_upconv2_slab16): generator block 2 of the bf16 storage mode -- UpSampling3D(2) + Conv3D(256
+    -> 128, 3x3x3, 'same') + bias + PixelNorm + LeakyReLU(0.2) (T:335-338) on a 6 x 4 x 4 x 256 input -- against the fp64 oracle on
+    the bf16-rounded input.  The kernel rounds the COLLAPSED weights (sums of up to 8 taps) and its output to bf16: 2^-8 each, so
+    2e-2 of the largest output; the per-pixel 1/l2 at 1e-2.  B = 520: persistent workgroups walk two samples."""
+    g = torch.Generator(); g.manual_seed(500 + B)
+    nref = min(B, 3)
+    x = torch.randn((B, 6, 4, 4, 256), generator=g)
+    w = 0.02 * torch.randn((3, 3, 3, 256, 128), generator=g)
+    bias = 0.05 * torch.randn((128,), generator=g)
+    sel = [0, B // 2, B - 1][:nref]
+    u = ot.upsample3d(x[sel].to(torch.bfloat16).double())
+    pre = ot._conv3d_tf(u, w.double(), bias.double(), 1, (1, 1, 1), u.shape[1:4])
+    ref = ot._lrelu(ot.pixel_norm(pre)).numpy()
+    rinv_ref = (1.0 / torch.sqrt((pre * pre).mean(-1) + 1e-8)).numpy()
+    xd, wd, bd = dev(x.numpy()), dev(w.numpy()), dev(bias.numpy())
+    y = torch.full((B, 12, 8, 8, 128), float("nan"), device="cuda")
+    rinv = torch.full((B, 12, 8, 8), float("nan"), device="cuda")
+    assert lib().rdgan_op_upconv2_slab16(ptr(xd), ptr(wd), ptr(bd), ptr(y), ptr(rinv), B, stream()) == 0
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(rinv).all())
+    assert rel_err(y[sel].cpu().numpy(), ref) < 2e-2
+    assert rel_err(rinv[sel].cpu().numpy(), rinv_ref) < 1e-2
+    # one-hot probe: a single kernel tap and channel pair moves exactly the source voxel the definition names (PixelNorm of a
+    # one-channel row = sign * sqrt(128) up to eps, so compare supports and signs through rinv * pre)
+    x1 = torch.zeros((1, 6, 4, 4, 256)); x1[..., 77] = (torch.arange(96, dtype=torch.float32).reshape(1, 6, 4, 4) % 61) + 1
+    for tap in (0, 13, 26, 5):
+        w1 = torch.zeros((3, 3, 3, 256, 128)); w1[tap // 9, (tap // 3) % 3, tap % 3, 77, 5] = 1.0
+        u1 = ot.upsample3d(x1.double())
+        want = ot._conv3d_tf(u1, w1.double(), torch.zeros(128).double(), 1, (1, 1, 1), u1.shape[1:4])[..., 5].numpy()
+        x1d, w1d, b1d = dev(x1.numpy()), dev(w1.numpy()), dev(np.zeros(128, np.float32))
+        y1 = torch.empty((1, 12, 8, 8, 128), device="cuda"); r1 = torch.empty((1, 12, 8, 8), device="cuda")
+        assert lib().rdgan_op_upconv2_slab16(ptr(x1d), ptr(w1d), ptr(b1d), ptr(y1), ptr(r1), 1, stream()) == 0
+        got = (y1[..., 5] / r1.clamp_max(1e3)).cpu().numpy()          # = pre (bf16-rounded) where the row is not empty
+        np.testing.assert_allclose(got * (want != 0), want, rtol=2.0 ** -7, atol=1e-3), tap
+        assert float(y1[..., :5].abs().max()) == 0 and float(y1[..., 6:].abs().max()) == 0
