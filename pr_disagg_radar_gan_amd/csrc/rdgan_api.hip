@@ -1599,7 +1599,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       RD_KNAME(h, "k_upconv2_slab16<bf16>");
       h->flops_acc += plan_flops(h->plans[pl], B);
       RD_TRY(ensure_lds(h, (const void*)k_upconv2_slab16, RD_UP2_LDS));
-      hipLaunchKernelGGL(k_upconv2_slab16, dim3((unsigned)std::min(B, 512)), dim3(256), RD_UP2_LDS, st, (const rd_bf16_t*)hs[l - 1],
+      hipLaunchKernelGGL(k_upconv2_slab16, dim3((unsigned)std::min(B, 256 * RD_UP2_WGS)), dim3(256), RD_UP2_LDS, st, (const rd_bf16_t*)hs[l - 1],
                          (const rd_bf16_t*)h->bW2I, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B);
       RD_CHECK(h, hipGetLastError());
       continue;
@@ -2715,7 +2715,7 @@ extern "C" int rdgan_op_upconv2_slab16(const float* x, const float* w, const flo
     rc = ensure_lds(nullptr, (const void*)k_upconv2_slab16, RD_UP2_LDS);
   }
   if (rc == 0) {
-    hipLaunchKernelGGL(k_upconv2_slab16, dim3((unsigned)std::min(B, 512)), dim3(256), RD_UP2_LDS, st, (const rd_bf16_t*)xb,
+    hipLaunchKernelGGL(k_upconv2_slab16, dim3((unsigned)std::min(B, 256 * RD_UP2_WGS)), dim3(256), RD_UP2_LDS, st, (const rd_bf16_t*)xb,
                        (const rd_bf16_t*)wi, bias, (rd_bf16_t*)yb, rinv, B);
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(ny)), dim3(256), 0, st, (const rd_bf16_t*)yb, y, ny);
     rc = (int)hipGetLastError();

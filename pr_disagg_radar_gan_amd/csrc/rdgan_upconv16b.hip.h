@@ -20,6 +20,9 @@
 #define RD_UP2_SS (RD_UP2_ZERO + 512)                // [2][96][4] floats: per-wave partial sums of squares of a phase's rows
 #define RD_UP2_BIAS (RD_UP2_SS + 2 * 96 * 4 * 4)     // 128 floats
 #define RD_UP2_LDS (RD_UP2_BIAS + 512)
+#ifndef RD_UP2_WGS
+#define RD_UP2_WGS 3                                 // workgroups per CU (50 KB of LDS and <= 168 VGPRs each)
+#endif
 #define RD_UP2_KSTEPS 1024                           // 64 (phase, tap) x 16 steps of 16 input channels
 
 // Weight image from the collapsed forms Wc [64 = phase*8 + tap][256 ci][128 co] (fp32): for k-step g = (phase*8 + tap)*16 + j and
@@ -47,7 +50,7 @@ __device__ __forceinline__ void rd_up2_wait(u32x4_t& d) { asm volatile("s_waitcn
 
 // x [B][6][4][4][256] bf16 -> out [B][12][8][8][128] bf16 = LeakyReLU(PixelNorm(upconv(x) + bias)), rinv [B][12][8][8] = 1/l2.
 // grid: min(B, 2 per CU) persistent workgroups of 256 threads; dynamic LDS RD_UP2_LDS.
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, RD_UP2_WGS)
 k_upconv2_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ wimg, const float* __restrict__ bias,
                  rd_bf16_t* __restrict__ out, float* __restrict__ rinv, int B) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
