@@ -150,6 +150,10 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * slab kernel k_upconv2_slab16: a sample's whole block input (48 KB) resident in LDS for all 8 phases x 8 taps, the four waves of a
  * workgroup split the 128 output channels (each streams its own weight fragments) and exchange the PixelNorm row sums of squares
  * through LDS once per phase (rdgan_upconv16b.hip.h).  0 = the streaming GEMM (k_conv_gemm_ws<128, 128, ..., bf16>).
+ * "d2_fwd_slab" (default 0 -- measured no faster than the streaming GEMM, kept parity-tested; bf16 storage mode, ndomain 16): the forward of the critic's second layer in the slab kernel
+ * k_d2_fwd_slab16: a sample's layer-1 output (69 KB) resident in LDS for all 27 taps, the four waves of a workgroup split the 128
+ * output channels and stream their own weight fragments, bias + LeakyReLU + dropout in registers (rdgan_d2fwd16.hip.h); the
+ * penalty's second sweep keeps the streaming GEMM.  Same dropout counter as 0 = k_conv_gemm_ws<128, 128, ..., bf16>.
  * "d2_slab" (default 1; bf16 storage mode, ndomain 16): the input gradient of the critic's second layer (128 -> 64 channels onto
  * the 11 x 7 x 7 grid, eight parity phases of 8 ... 1 taps) runs in the slab kernel k_d2_dgrad_slab16: two samples' output
  * gradient resident in LDS for all phases and taps, weights streamed in MFMA-fragment order, LeakyReLU' x dropout gate + bf16
@@ -309,6 +313,10 @@ int rdgan_op_upconv2_slab16(const float* x, const float* w, const float* bias, f
  * at the conv output) are rounded to bf16 on the device; dWc [64 = phase*8 + tap][128][64] fp32 -- entry (phase, tap) is the sum over
  * samples and source positions r of x[r + off(phase, tap)] (outer) dy[2 r + phase], off = phase - 1 + tap per axis. */
 int rdgan_op_upconv_wgrad_slab16(const float* x, const float* dy, float* dWc, int B, void* stream);
+/* Forward of the critic's second layer (T:291-293, Conv3D(128, 3x3x3, stride 2, 'same') on 11 x 7 x 7 x 64 + bias + LeakyReLU +
+ * dropout) through the slab kernel of the bf16 storage mode alone (k_d2_fwd_slab16): x [B,11,7,7,64] and w [3,3,3,64,128] are rounded
+ * to bf16 on the device, y [B,6,4,4,128] comes back as fp32 (the bf16 output widened); seed = 0: dropout off. */
+int rdgan_op_d2_fwd_slab16(const float* x, const float* w, const float* bias, float* y, int B, uint64_t seed, void* stream);
 /* Weight gradient of the critic's second layer (backward of T:291, Conv3D(128, 3x3x3, stride 2, 'same') on 11 x 7 x 7 x 64) through
  * the slab kernel of the bf16 storage mode alone (k_d2_wgrad_slab16): x [B,11,7,7,64] (layer 1's output) and dy [B,6,4,4,128] are
  * rounded to bf16 on the device; dW [3,3,3,64,128] fp32 = sum over samples and output positions o of x[2 o + tap - 1] (outer) dy[o]. */

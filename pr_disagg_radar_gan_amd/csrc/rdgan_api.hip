@@ -22,6 +22,7 @@
 #include "rdgan_data.hip.h"
 #include "rdgan_edge.hip.h"
 #include "rdgan_d2slab16.hip.h"
+#include "rdgan_d2fwd16.hip.h"
 #include "rdgan_upwgrad16.hip.h"
 #include "rdgan_upwgrad16b.hip.h"
 #include "rdgan_d2wgrad16.hip.h"
@@ -402,6 +403,8 @@ struct rdgan_handle {
   int upwgrad_slab = 1;           // 1: bf16 storage mode, ndomain 16, collapsed form: weight gradient of generator block 3 by k_upconv_wgrad_slab16
   int d1_dgrad_fused = 1;         // 1: bf16 storage mode, ndomain 16: dD/d(sample) of layer 1 in one pass per sample (k_d1_dgrad_sample16)
   int d1_wgrad16 = 1;             // 1: bf16 storage mode: layer-1 weight gradient + bias gradient on the bf16 matrix pipe (k_d1_wgrad16)
+  void* bW2F = nullptr;           // weight image of the slab kernel of critic layer 2's forward (rdgan_d2fwd16.hip.h): 448 KB
+  int d2_fwd_slab = 0;            // 1: bf16 storage mode, ndomain 16: forward of critic layer 2 by k_d2_fwd_slab16 (measured: no faster than the streaming GEMM, default off)
   int d2_slab = 1;                // 1: bf16 storage mode, ndomain 16: input gradient of critic layer 2 by k_d2_dgrad_slab16
   int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
   int g9_direct = 1;              // 1: backward of the 64 -> 1 conv straight from the dlogits (no im2col matrix), fused with block 3's PixelNorm backward
@@ -1257,6 +1260,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3I = p;
         carve(p, (long)RD_UP2_KSTEPS * 4 * 64 * 4 + 8); h->bW2I = p;
         carve(p, (long)RD_D2S_KSTEPS * 2 * 64 * 4 + 8); h->bW2S = p;
+        carve(p, (long)RD_D2F_KSTEPS * 4 * 64 * 4 + 8); h->bW2F = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
     }
@@ -1330,6 +1334,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_wgrad16")) { h->d1_wgrad16 = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "d2_fwd_slab")) { h->d2_fwd_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
   if (!strcmp(name, "d2_slab")) { h->d2_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
   if (!strcmp(name, "dense_wgrad_slices")) { h->dense_slices = value; return 0; }
   if (!strcmp(name, "keep_gates")) {
@@ -1709,9 +1714,10 @@ extern "C" int rdgan_check_numerics(rdgan_handle* h, void* stream) {
 // critic
 // ------------------------------------------------------------------------------------
 static bool d2_slab_on(const rdgan_handle* h) { return h->d2_slab && h->a16 && h->nd == 16; }
+static bool d2_fwd_slab_on(const rdgan_handle* h) { return h->d2_fwd_slab && h->a16 && h->nd == 16; }
 static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st) {
   // (skipped when the forms in the workspace were built from these very weights: see rdgan_set_weight_versions)
-  const int ccfg = (h->a16 ? 1 : 0) | (h->d2_slab ? 2 : 0);
+  const int ccfg = (h->a16 ? 1 : 0) | (h->d2_slab ? 2 : 0) | (h->d2_fwd_slab ? 4 : 0);
   if (h->cver_in != 0 && dp == h->ccache_ptr && h->cver_in == h->ccache_ver && ccfg == h->ccache_cfg) return 0;
   h->form_builds[1]++;
   h->ccache_ptr = dp; h->ccache_ver = h->cver_in; h->ccache_cfg = ccfg;
@@ -1732,6 +1738,8 @@ static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st)
       a.K[l - 2] = h->dch[l - 1]; a.N[l - 2] = h->dch[l];
     }
     hipLaunchKernelGGL(k_weights3_to_bf16, dim3(8, 8, 3 * 27), dim3(256), 0, st, a);
+    if (d2_fwd_slab_on(h))
+      hipLaunchKernelGGL(k_d2f_wimg, dim3(RD_D2F_KSTEPS), dim3(256), 0, st, dp + h->doff[2], (unsigned short*)h->bW2F);
     if (d2_slab_on(h))
       hipLaunchKernelGGL(k_d2s_wimg, dim3((RD_D2S_KSTEPS * 2 * 64 + 255) / 256), dim3(256), 0, st, dp + h->doff[2], (unsigned short*)h->bW2S);
     hipLaunchKernelGGL(k_w1_to_bf16, dim3(ew_blocks(64L * h->ldp1)), dim3(256), 0, st, dp + h->doff[0], (rd_bf16_t*)h->bW1B,
@@ -1821,7 +1829,16 @@ static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64
     else if (a16 && l == 1)
       RD_TRY(launch_conv_a16(h, h->plans[pl], h->d_plans + pl, NBt, in, d1_weights(h, dp), h->dch[l], h->dh[l], ep, st,
                              RDGAN_TAG_CRITIC_GEMM, false, true));
-    else if (a16)
+    else if (l == 2 && d2_fwd_slab_on(h)) {      // a sample's layer-1 output resident in LDS, the four waves split the 128 channels
+      ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+      LaunchScope ls(h, pl, RD_KIND_CONV, NBt, plan_flops(h->plans[pl], NBt), st);
+      RD_KNAME(h, "k_d2_fwd_slab16<bf16>");
+      h->flops_acc += plan_flops(h->plans[pl], NBt);
+      RD_TRY(ensure_lds(h, (const void*)k_d2_fwd_slab16, RD_D2F_LDS));
+      hipLaunchKernelGGL(k_d2_fwd_slab16, dim3((unsigned)std::min(NBt, 512)), dim3(256), RD_D2F_LDS, st, (const rd_bf16_t*)in,
+                         (const rd_bf16_t*)h->bW2F, dp + h->doff[3], (rd_bf16_t*)h->dh[2], NBt, use_drop, ep.key, 0u);
+      RD_CHECK(h, hipGetLastError());
+    } else if (a16)
       RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->bWF[l], h->dh[l], ep, st, RDGAN_TAG_CRITIC_GEMM));
     else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
@@ -2638,6 +2655,33 @@ extern "C" int rdgan_op_upconv_wgrad_slab16(const float* x, const float* dy, flo
   }
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   for (void* p : {xb, yb, (void*)part}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// Forward of the critic's second layer through the slab kernel alone (rdgan_d2fwd16.hip.h), ndomain 16: x [B,11,7,7,64] and the layer's
+// kernel w [3,3,3,64,128] are rounded to bf16 on the device; y [B,6,4,4,128] = dropout(LeakyReLU(conv(x; stride 2, 'same') + bias))
+// comes back as fp32 (the bf16 output widened); seed = 0: no dropout, otherwise the layer-2 mask of `seed` (counter = flat index of y).
+extern "C" int rdgan_op_d2_fwd_slab16(const float* x, const float* w, const float* bias, float* y, int B, uint64_t seed, void* stream) {
+  if (!x || !w || !bias || !y || B < 1) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long nx = (long)B * 539 * 64, ny = (long)B * 96 * 128;
+  void *xb = nullptr, *yb = nullptr, *wi = nullptr;
+  int rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc(&wi, (long)RD_D2F_KSTEPS * 4 * 64 * 16);
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_d2f_wimg, dim3(RD_D2F_KSTEPS), dim3(256), 0, st, w, (unsigned short*)wi);
+    rc = ensure_lds(nullptr, (const void*)k_d2_fwd_slab16, RD_D2F_LDS);
+  }
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_d2_fwd_slab16, dim3((unsigned)std::min(B, 512)), dim3(256), RD_D2F_LDS, st, (const rd_bf16_t*)xb,
+                       (const rd_bf16_t*)wi, bias, (rd_bf16_t*)yb, B, seed != 0, rd_make_key(seed, RD_STREAM_D1 + 1), 0u);
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(ny)), dim3(256), 0, st, (const rd_bf16_t*)yb, y, ny);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {xb, yb, wi}) if (p) (void)hipFree(p);
   return rc;
 }
 

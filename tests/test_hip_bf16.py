@@ -310,6 +310,41 @@ def test_upconv2_slab_kernel_equals_the_streaming_gemm_to_one_bf16_ulp(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [2, 50])
+def test_d2_fwd_slab_kernel_equals_the_streaming_gemm(B):
+    """"d2_fwd_slab" (default off: measured no faster; ndomain 16): the forward of critic layer 2 in the slab kernel k_d2_fwd_slab16
+    against the streaming bf16 GEMM of the same engine: the same bf16 products in the same tap and k order; the slab kernel starts
+    its fp32 accumulators at the bias, the streaming kernel adds it at the end, so sums differ in the last fp32 bit and the stored
+    bf16 activation in at most one ulp in a small share of the elements; same dropout mask.  Critic-step gradients follow: 3e-3."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 69)
+        x, cond, z = ot.synthetic_batch(B, 16, 60)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("d2_fwd_slab", on)
+            v = eng.critic_forward(ds, dev(x), dev(cond), 31).clone()
+            h2 = eng.debug_activation(5, (B, 6, 4, 4, 128)).clone()
+            c = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 33).clone()
+            assert torch.equal(c, eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 33))
+            res[on] = (v, h2, c)
+        (v0, a0, c0), (v1, a1, c1) = res[0], res[1]
+        assert bool(torch.isfinite(a1).all())
+        assert torch.equal(a0 == 0, a1 == 0)                                  # the same elements dropped
+        rel = (a1 - a0).abs() / a0.abs().clamp_min(1e-3)
+        assert float(rel.max()) <= 2.0 ** -7 + 1e-6, float(rel.max())
+        assert float((a1 != a0).float().mean()) < 5e-3
+        assert float((v1 - v0).abs().max()) < 2e-3 * (1.0 + float(v0.abs().max()))
+        n = eng.n_critic
+        e = float((c1[:n] - c0[:n]).abs().max() / c0[:n].abs().max())
+        print(f"B {B} d2_fwd_slab 1 vs 0: critic-step gradients differ by {e:.2e} of the largest entry")
+        assert e < 3e-3
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:

@@ -419,3 +419,25 @@ def test_upconv2_slab_kernel_vs_oracle(B):
         got = (y1[..., 5] / r1.clamp_max(1e3)).cpu().numpy()          # = pre (bf16-rounded) where the row is not empty
         np.testing.assert_allclose(got * (want != 0), want, rtol=2.0 ** -7, atol=1e-3), tap
         assert float(y1[..., :5].abs().max()) == 0 and float(y1[..., 6:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B", [1, 3, 520])
+def test_d2_fwd_slab_kernel_vs_oracle(B):
+    """k_d2_fwd_slab16 alone (rdgan_op_d2_fwd_slab16): forward of the critic's second layer (T:291-293: Conv3D(128, 3x3x3, stride 2,
+    'same') + bias + LeakyReLU + dropout) on an 11 x 7 x 7 x 64 input against the fp64 oracle on bf16-rounded operands: fp32
+    accumulation, one rounding of the output to bf16 (2^-8 per element); with a seed the oracle's layer-2 mask (oracle/rng.py) times
+    1/0.75.  B = 520: persistent workgroups walk two samples."""
+    g = torch.Generator(); g.manual_seed(600 + B)
+    x = torch.randn((B, 11, 7, 7, 64), generator=g)
+    w = 0.05 * torch.randn((3, 3, 3, 64, 128), generator=g)
+    bias = 0.1 * torch.randn((128,), generator=g)
+    pre = ot._conv3d_tf(x.bfloat16().double(), w.bfloat16().double(), bias.double(), 2, (1, 1, 1), (6, 4, 4))
+    ref = ot._lrelu(pre).numpy()
+    xd, wd, bd = dev(x.numpy()), dev(w.numpy()), dev(bias.numpy())
+    for seed in (0, 0x1234ABCD5):
+        want = ref * (orng.dropout_scale_mask(seed, orng.STREAM_D2, ref.shape).astype(np.float64) if seed else 1.0)
+        y = torch.full((B, 6, 4, 4, 128), float("nan"), device="cuda")
+        assert lib().rdgan_op_d2_fwd_slab16(ptr(xd), ptr(wd), ptr(bd), ptr(y), B, seed, stream()) == 0
+        got = y.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(got))
+        np.testing.assert_allclose(got, want, rtol=2.0 ** -8 + 1e-5, atol=2e-5 * np.abs(want).max())
