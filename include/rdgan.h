@@ -162,6 +162,8 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * kernel k_d2_wgrad_slab16: a wave owns one of the 27 taps and keeps its 64 x 128 product in registers over the workgroup's share
  * of the batch; by input parity the taps fall into 8 classes, each a dense sub-grid of layer 1's output on which its taps are shifts
  * (rdgan_d2wgrad16.hip.h).  0 = k_wgrad_gemm_ws16<128,128>.
+ * "d3_wgrad_slab" (default 1; same conditions): critic layer 3's weight gradient the same way (k_d3_wgrad_slab16: a wave owns a tap
+ * and a quarter of the 256 output channels; a sample has 12 output positions, so an item is four samples); 0 = k_wgrad_gemm_ws16.
  * "upwgrad_slab" (default 1; bf16 storage mode, ndomain 16, collapsed form): the weight gradient of generator block 3 runs in the slab
  * kernel k_upconv_wgrad_slab16: a workgroup owns one output-parity phase and keeps its eight tap products (eight 128 x 64 fp32
  * tiles, one per wave) in registers over its share of the batch; source planes and output-gradient rows arrive by LDS-DMA in two
@@ -321,6 +323,10 @@ int rdgan_op_d2_fwd_slab16(const float* x, const float* w, const float* bias, fl
  * the slab kernel of the bf16 storage mode alone (k_d2_wgrad_slab16): x [B,11,7,7,64] (layer 1's output) and dy [B,6,4,4,128] are
  * rounded to bf16 on the device; dW [3,3,3,64,128] fp32 = sum over samples and output positions o of x[2 o + tap - 1] (outer) dy[o]. */
 int rdgan_op_d2_wgrad_slab16(const float* x, const float* dy, float* dW, int B, void* stream);
+/* Weight gradient of the critic's third layer (backward of T:295, Conv3D(256, 3x3x3, stride 2, 'same') on 6 x 4 x 4 x 128 ->
+ * 3 x 2 x 2 x 256) through the slab kernel of the bf16 storage mode alone (k_d3_wgrad_slab16): x [B,6,4,4,128] (layer 2's output) and
+ * dy [B,3,2,2,256] are rounded to bf16 on the device; dW [3,3,3,128,256] fp32 = sum over samples and o of x[2 o + tap] (outer) dy[o]. */
+int rdgan_op_d3_wgrad_slab16(const float* x, const float* dy, float* dW, int B, void* stream);
 /* Input gradient of the critic's second layer (backward of T:291, Conv3D(128, 3x3x3, stride 2, 'same') on the 11 x 7 x 7 x 64
  * output of layer 1, ndomain 16) through the slab kernel of the bf16 storage mode alone (k_d2_dgrad_slab16): gy [B,6,4,4,128], the
  * layer's kernel w [3,3,3,64,128] and aux [B,11,7,7,64] (layer 1's output) are rounded to bf16 on the device;

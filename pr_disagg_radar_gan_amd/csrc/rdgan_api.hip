@@ -26,6 +26,7 @@
 #include "rdgan_upwgrad16.hip.h"
 #include "rdgan_upwgrad16b.hip.h"
 #include "rdgan_d2wgrad16.hip.h"
+#include "rdgan_d3wgrad16.hip.h"
 static_assert(RDGAN_LOSS_SLOTS == 8, "k_critic_losses / k_gen_loss write slots 0..7");
 // k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
 static bool g9w_mfma_ok(int nd, long npix) { return nd >= 8 && nd <= 128 && (nd & (nd - 1)) == 0 && npix < 0x7FFFFFFFL; }
@@ -399,6 +400,7 @@ struct rdgan_handle {
   void* bW2I = nullptr;           // weight image of the slab kernel of generator block 2 (rdgan_upconv16b.hip.h): 4 MB
   int upconv2_slab = 1;           // 1: the same for block 2 (k_upconv2_slab16)
   void* bW2S;                     // weight image of the slab kernel of critic layer 2's input gradient (rdgan_d2slab16.hip.h): 432 KB
+  int d3_wgrad_slab = 1;          // 1: bf16 storage mode, ndomain 16: weight gradient of critic layer 3 by k_d3_wgrad_slab16
   int d2_wgrad_slab = 1;          // 1: bf16 storage mode, ndomain 16: weight gradient of critic layer 2 by k_d2_wgrad_slab16
   int upwgrad_slab = 1;           // 1: bf16 storage mode, ndomain 16, collapsed form: weight gradient of generator block 3 by k_upconv_wgrad_slab16
   int d1_dgrad_fused = 1;         // 1: bf16 storage mode, ndomain 16: dD/d(sample) of layer 1 in one pass per sample (k_d1_dgrad_sample16)
@@ -1176,6 +1178,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     if (g9w_mfma_ok(nd, (long)MB * h->gpix[3]))                            // k_g9_wgrad_mfma: [27][64] per persistent workgroup
       wneed = std::max(wneed, (size_t)std::min<long>(((long)MB * h->gpix[3] + 127) / 128, 768) * 1728);
   }
+  if (nd == 16) wneed = std::max(wneed, (size_t)16 * 27 * RD_D3W_TILE);    // k_d3_wgrad_slab16: [16 groups][27][128][256]
   if (nd == 16) wneed = std::max(wneed, (size_t)64 * 27 * RD_D2W_TILE);    // k_d2_wgrad_slab16: [64 groups][27][64][128]
   if (nd == 16) wneed = std::max(wneed, (size_t)8 * 64 * RD_UW2_TILE);      // k_upconv2_wgrad_slab16: [8 groups][64][256][128]
   if (nd == 16) wneed = std::max(wneed, (size_t)32 * 64 * RD_UWG_TILE);     // k_upconv_wgrad_slab16: [32 groups][64][128][64]
@@ -1330,6 +1333,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv2_slab")) { h->upconv2_slab = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "d3_wgrad_slab")) { h->d3_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_wgrad_slab")) { h->d2_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
@@ -2038,6 +2042,19 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
                          h->wpartial, NBt, G);
       hipLaunchKernelGGL(k_d2_wgrad_fold, dim3((27 * RD_D2W_TILE / 4 + 255) / 256), dim3(256), 0, st, h->wpartial, G, grad + h->doff[2]);
       RD_CHECK(h, hipGetLastError());
+    } else if (a16 && l == 3 && h->d3_wgrad_slab && h->nd == 16) {
+      // a wave owns (tap, quarter of the output channels); items of four samples (12 output positions each)
+      ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+      LaunchScope ls(h, pl, RD_KIND_WGRAD, NBt, plan_flops(h->plans[pl], NBt), st);
+      RD_KNAME(h, "k_d3_wgrad_slab16<bf16>");
+      h->flops_acc += plan_flops(h->plans[pl], NBt);
+      const int G = NBt >= 256 ? 16 : 8;
+      if ((size_t)G * 27 * RD_D3W_TILE > h->wpartial_cap) return bad_arg(h, "d3 wgrad: partial workspace too small");
+      RD_TRY(ensure_lds(h, (const void*)k_d3_wgrad_slab16, RD_D3W_LDS));
+      hipLaunchKernelGGL(k_d3_wgrad_slab16, dim3(16 * G), dim3(512), RD_D3W_LDS, st, (const rd_bf16_t*)in, (const rd_bf16_t*)h->du[3],
+                         h->wpartial, NBt, G);
+      hipLaunchKernelGGL(k_d3_wgrad_fold, dim3((27 * RD_D3W_TILE / 4 + 255) / 256), dim3(256), 0, st, h->wpartial, G, grad + h->doff[4]);
+      RD_CHECK(h, hipGetLastError());
     } else if (a16 && l >= 2) {      // layers 2-4: bf16 activations against bf16 output gradients
       if (!wgrad16_ok(h->plans[pl], NBt)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this critic layer");
       RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], grad + h->doff[2 * (l - 1)], h->wpartial,
@@ -2682,6 +2699,30 @@ extern "C" int rdgan_op_d2_fwd_slab16(const float* x, const float* w, const floa
   }
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   for (void* p : {xb, yb, wi}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// Weight gradient of the critic's third layer through the slab kernel alone (rdgan_d3wgrad16.hip.h), ndomain 16: x [B,6,4,4,128]
+// (layer 2's output) and dy [B,3,2,2,256] are rounded to bf16 on the device; dW [3,3,3,128,256] fp32.
+extern "C" int rdgan_op_d3_wgrad_slab16(const float* x, const float* dy, float* dW, int B, void* stream) {
+  if (!x || !dy || !dW || B < 1) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long nx = (long)B * 96 * 128, ny = (long)B * 12 * 256;
+  const int G = B >= 256 ? 16 : 8;
+  void *xb = nullptr, *yb = nullptr; float* part = nullptr;
+  int rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc((void**)&part, (size_t)G * 27 * RD_D3W_TILE * sizeof(float));
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) rc = launch_to_bf16(nullptr, dy, yb, ny, st);
+  if (rc == 0) rc = ensure_lds(nullptr, (const void*)k_d3_wgrad_slab16, RD_D3W_LDS);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_d3_wgrad_slab16, dim3(16 * G), dim3(512), RD_D3W_LDS, st, (const rd_bf16_t*)xb, (const rd_bf16_t*)yb, part, B, G);
+    hipLaunchKernelGGL(k_d3_wgrad_fold, dim3((27 * RD_D3W_TILE / 4 + 255) / 256), dim3(256), 0, st, part, G, dW);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {xb, yb, (void*)part}) if (p) (void)hipFree(p);
   return rc;
 }
 

@@ -164,6 +164,31 @@ def test_d2_slab_kernel_equals_the_streaming_gemm(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [3, 90])
+def test_d3_wgrad_slab_equals_the_streaming_wgrad(B):
+    """"d3_wgrad_slab" (default on at ndomain 16): critic layer 3's weight gradient in k_d3_wgrad_slab16 against k_wgrad_gemm_ws16 of the
+    same engine over the 3 B batch: that kernel gradient within 2e-5 of its largest entry, the rest of the slab bit for bit."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 75)
+        x, cond, z = ot.synthetic_batch(B, 16, 66)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("d3_wgrad_slab", on)
+            res[on] = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 43).clone()
+            assert torch.equal(res[on], eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 43))
+        a, b = res[0].cpu().numpy(), res[1].cpu().numpy()
+        o3 = 27 * 2 * 64 + 64 + 27 * 64 * 128 + 128; n3 = 27 * 128 * 256
+        e = np.abs(a[o3:o3 + n3] - b[o3:o3 + n3]).max() / np.abs(a[o3:o3 + n3]).max()
+        print(f"B {B} d3_wgrad_slab 1 vs 0: layer-3 kernel gradient differs by {e:.2e} of its largest entry")
+        assert 0 < e < 2e-5
+        assert np.array_equal(a[:o3], b[:o3]) and np.array_equal(a[o3 + n3:], b[o3 + n3:])
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [2, 30])
 def test_d2_wgrad_slab_equals_the_streaming_wgrad(B):
     """"d2_wgrad_slab" (default on at ndomain 16): critic layer 2's weight gradient in the slab kernel k_d2_wgrad_slab16 against

@@ -441,3 +441,28 @@ def test_d2_fwd_slab_kernel_vs_oracle(B):
         got = y.cpu().numpy().astype(np.float64)
         assert np.all(np.isfinite(got))
         np.testing.assert_allclose(got, want, rtol=2.0 ** -8 + 1e-5, atol=2e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("B", [1, 6, 300])
+def test_d3_wgrad_slab_kernel_vs_definition(B):
+    """k_d3_wgrad_slab16 alone (rdgan_op_d3_wgrad_slab16): weight gradient of the critic's third layer (backward of T:295, stride 2,
+    no padding in front: dW[tap] = sum_o x[2 o + tap] (outer) dy[o]) against torch autograd of the definition in fp64 on the
+    bf16-rounded operands: 2e-5 of the largest entry.  B = 1, 6: items with fewer than four samples; B = 300: 16 groups."""
+    g = torch.Generator(); g.manual_seed(700 + B)
+    x = torch.randn((B, 6, 4, 4, 128), generator=g)
+    dy = torch.randn((B, 3, 2, 2, 256), generator=g)
+    xr, dyr = x.bfloat16().double(), dy.bfloat16().double()
+    w = torch.zeros((3, 3, 3, 128, 256), dtype=torch.float64, requires_grad=True)
+    y = ot._conv3d_tf(xr, w, torch.zeros(256, dtype=torch.float64), 2, (0, 0, 0), (3, 2, 2))
+    (ref,) = torch.autograd.grad((y * dyr).sum(), w)
+    ref = ref.numpy()
+    xd, dyd = dev(x.numpy()), dev(dy.numpy())
+    out = torch.full((3, 3, 3, 128, 256), float("nan"), device="cuda")
+    assert lib().rdgan_op_d3_wgrad_slab16(ptr(xd), ptr(dyd), ptr(out), B, stream()) == 0
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(got))
+    err = np.abs(got - ref).max(axis=(3, 4)) / np.abs(ref).max()
+    assert err.max() < 2e-5, err
+    out2 = torch.empty_like(out)
+    assert lib().rdgan_op_d3_wgrad_slab16(ptr(xd), ptr(dyd), ptr(out2), B, stream()) == 0
+    assert torch.equal(out, out2)
