@@ -72,7 +72,7 @@ k_upconv_wgrad_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restri
 
   // bias gradient = column sums of dy: the eight phases partition the block's output positions, so the tap-0 wave of every
   // workgroup also sums the output-gradient fragments it multiplies (lane: column 32 j + l31, the 8 positions of its k-group)
-  // -> bias_partial[group][phase][64], folded by k_upconv_bias_fold: the column-sum pass over dy (1.6 GB at 2048 samples,
+  // -> bias_partial[group][phase][64], folded by k_reduce_partials: the column-sum pass over dy (1.6 GB at 2048 samples,
   // 0.78 ms beside the GEMMs) is gone
   float bsum[2] = {0.f, 0.f};
   const bool do_bias = bias_partial != nullptr && wave == 0;
@@ -160,13 +160,6 @@ k_upconv_wgrad_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restri
       if (lhalf == 0) bias_partial[((long)group * 8 + phase) * 64 + j * 32 + l31] = v;
     }
   }
-}
-// db[c] = sum over (group, phase) of bias_partial[.][c] in a fixed order
-__global__ void k_upconv_bias_fold(const float* __restrict__ bias_partial, int n, float* __restrict__ db) {
-  const int c = threadIdx.x;
-  float s = 0.f;
-  for (int i = 0; i < n; ++i) s += bias_partial[(long)i * 64 + c];
-  db[c] = s;
 }
 
 // dWc[i] = sum over groups of partial[g][i], i < 64 * RD_UWG_TILE, in the order of the groups (deterministic)

@@ -157,9 +157,3 @@ k_upconv2_wgrad_fold(const float* __restrict__ partial, int G, float* __restrict
   for (int g = 1; g < G; ++g) s += *(const f32x4*)(partial + (long)g * 64 * RD_UW2_TILE + i4 * 4);
   *(f32x4*)(dWc + i4 * 4) = s;
 }
-__global__ void k_upconv2_bias_fold(const float* __restrict__ bias_partial, int n, float* __restrict__ db) {
-  const int c = threadIdx.x;
-  float s = 0.f;
-  for (int i = 0; i < n; ++i) s += bias_partial[(long)i * 128 + c];
-  db[c] = s;
-}
