@@ -150,6 +150,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * slab kernel k_upconv2_slab16: a sample's whole block input (48 KB) resident in LDS for all 8 phases x 8 taps, the four waves of a
  * workgroup split the 128 output channels (each streams its own weight fragments) and exchange the PixelNorm row sums of squares
  * through LDS once per phase (rdgan_upconv16b.hip.h).  0 = the streaming GEMM (k_conv_gemm_ws<128, 128, ..., bf16>).
+ * "d2_gate_bits" (default 1; with "d2_slab" and the layer-1 edge kernels): the forward of layer 1 also writes its gate -- per element
+ * LeakyReLU' = 1 or alpha, dropped or kept -- as 2 bits (16 bytes per row), and the slab kernel of layer 2's input gradient reads
+ * that instead of layer 1's stored output (128 bytes per row): identical results.
  * "d2_fwd_slab" (default 0 -- measured no faster than the streaming GEMM, kept parity-tested; bf16 storage mode, ndomain 16): the forward of the critic's second layer in the slab kernel
  * k_d2_fwd_slab16: a sample's layer-1 output (69 KB) resident in LDS for all 27 taps, the four waves of a workgroup split the 128
  * output channels and stream their own weight fragments, bias + LeakyReLU + dropout in registers (rdgan_d2fwd16.hip.h); the
@@ -342,7 +345,9 @@ int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* r
  * and dropout ([B] samples after a generator step or a critic forward; [3B] = real | fake | interpolated after a critic step,
  * whose interpolated third is only meaningful with the option "keep_gates": without it the second sweep of the gradient penalty
  * has overwritten it).  The gradient parity tests take the LeakyReLU slope pattern of the run from here, so that the fp64
- * oracle differentiates the same piecewise-linear branch. */
+ * oracle differentiates the same piecewise-linear branch.  which = 8 (bf16 storage mode, ndomain 16, option "d2_gate_bits"): the packed
+ * gate bytes of critic layer 1 as floats, 16 per row: byte q of a row = channels 4 q .. 4 q + 3, two bits each (bit 0: output > 0,
+ * bit 1: dropped). */
 int rdgan_debug_activation(rdgan_handle* h, int which, float* out, long n, void* stream);
 /* dropout keep-scale mask (0 or 1/0.75) and uniforms of the counter RNG, for pinning it to oracle/rng.py */
 int rdgan_op_rng(uint64_t seed, uint32_t stream_id, float* mask_out, float* uniform_out, long n,

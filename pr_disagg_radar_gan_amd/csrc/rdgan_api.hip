@@ -407,6 +407,8 @@ struct rdgan_handle {
   int d1_wgrad16 = 1;             // 1: bf16 storage mode: layer-1 weight gradient + bias gradient on the bf16 matrix pipe (k_d1_wgrad16)
   void* bW2F = nullptr;           // weight image of the slab kernel of critic layer 2's forward (rdgan_d2fwd16.hip.h): 448 KB
   int d2_fwd_slab = 0;            // 1: bf16 storage mode, ndomain 16: forward of critic layer 2 by k_d2_fwd_slab16 (measured: no faster than the streaming GEMM, default off)
+  unsigned char* g1bits = nullptr; // layer 1's gate in 2 bits per element (written by k_d1_gemm_fwd, read by k_d2_dgrad_slab16): 16 B per row
+  int d2_gate_bits = 1;           // 1: the slab kernel of layer 2's input gradient reads the packed gate instead of layer 1's output
   int d2_slab = 1;                // 1: bf16 storage mode, ndomain 16: input gradient of critic layer 2 by k_d2_dgrad_slab16
   int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
   int g9_direct = 1;              // 1: backward of the 64 -> 1 conv straight from the dlogits (no im2col matrix), fused with block 3's PixelNorm backward
@@ -1263,6 +1265,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3I = p;
         carve(p, (long)RD_UP2_KSTEPS * 4 * 64 * 4 + 8); h->bW2I = p;
         carve(p, (long)RD_D2S_KSTEPS * 2 * 64 * 4 + 8); h->bW2S = p;
+        if (nd == 16) { carve(p, NB * h->dL[1] * 4 + 8); if (pass == 1) h->g1bits = (unsigned char*)p; }
         carve(p, (long)RD_D2F_KSTEPS * 4 * 64 * 4 + 8); h->bW2F = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
@@ -1339,6 +1342,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_wgrad16")) { h->d1_wgrad16 = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_fwd_slab")) { h->d2_fwd_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
+  if (!strcmp(name, "d2_gate_bits")) { h->d2_gate_bits = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_slab")) { h->d2_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
   if (!strcmp(name, "dense_wgrad_slices")) { h->dense_slices = value; return 0; }
   if (!strcmp(name, "keep_gates")) {
@@ -1759,8 +1763,10 @@ static inline const float* d1_weights(const rdgan_handle* h, const float* dp) {
 
 // First critic layer as one K = 64 GEMM per tile (rdgan_edge.hip.h): one condition channel (2 floats per voxel), any ndomain
 static bool d1_gemm_ok(const rdgan_handle* h) { return h->edge_kernels && h->CP == 2 && h->Cin == 2; }
+static bool d2_gate_bits_on(const rdgan_handle* h) { return h->d2_gate_bits && h->d2_slab && h->a16 && h->nd == 16 && h->g1bits; }
 static int launch_d1_fwd(rdgan_handle* h, const float* in, const float* w, const float* bias, float* out, const float* aux, int NBt,
                          int mode, int use_drop, uint32_t key, uint32_t idx_base, hipStream_t st) {
+  unsigned char* gbits = mode == 0 && d2_gate_bits_on(h) ? h->g1bits : nullptr;
   ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
   const long rows = (long)NBt * h->dL[1];
   LaunchScope ls(h, PL_D1F, RD_KIND_EDGE, NBt, 2.0 * rows * 54 * 64, st);
@@ -1773,7 +1779,7 @@ static int launch_d1_fwd(rdgan_handle* h, const float* in, const float* w, const
   do {                                                                                                                     \
     RD_TRY(ensure_lds(h, (const void*)k_d1_gemm_fwd<TO, MODE>, lds));                                                      \
     hipLaunchKernelGGL((k_d1_gemm_fwd<TO, MODE>), grid, dim3(256), lds, st, in, w, bias, (TO*)out, (const TO*)aux, rows, nd, \
-                       Do, Ho, Wo, use_drop, key, idx_base);                                                               \
+                       Do, Ho, Wo, use_drop, key, idx_base, gbits);                                                        \
   } while (0)
   if (h->a16) { if (mode == 0) RD_D1F(rd_bf16_t, 0); else RD_D1F(rd_bf16_t, 1); }
   else { if (mode == 0) RD_D1F(float, 0); else RD_D1F(float, 1); }
@@ -1882,7 +1888,7 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
       RD_TRY(ensure_lds(h, (const void*)k_d2_dgrad_slab16, RD_D2S_LDS));
       hipLaunchKernelGGL(k_d2_dgrad_slab16, dim3((unsigned)std::min((NBt + 1) / 2, 512)), dim3(256), RD_D2S_LDS, st,
                          (const rd_bf16_t*)h->du[2], (const rd_bf16_t*)h->bW2S, (const rd_bf16_t*)h->dh[1], (rd_bf16_t*)h->du[1], NBt,
-                         use_drop);
+                         use_drop, d2_gate_bits_on(h) && d1_gemm_ok(h) ? h->g1bits : nullptr);
       RD_CHECK(h, hipGetLastError());
       continue;
     }
@@ -2824,7 +2830,16 @@ extern "C" int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* hh, co
 
 // test hook: the activations the last forward left in the workspace (generator h0..h3: which = 0..3, critic layers 1..4
 // after LeakyReLU and dropout: which = 4..7), first n floats, as fp32
+__global__ void k_bytes_to_f32(const unsigned char* in, float* out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
 extern "C" int rdgan_debug_activation(rdgan_handle* h, int which, float* out, long n, void* stream) {
+  if (h && out && which == 8 && n >= 1) {      // test hook: layer 1's packed gate bytes (16 per row) as floats
+    if (!h->g1bits || n > (long)h->NB * h->dL[1] * 16) return bad_arg(h, "debug_activation: no gate bytes");
+    hipLaunchKernelGGL(k_bytes_to_f32, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, h->g1bits, out, n);
+    RD_CHECK(h, hipGetLastError());
+    return 0;
+  }
   if (!h || !out || which < 0 || which > 7 || n < 1) return bad_arg(h, "debug_activation: bad argument");
   const float* src; long cap;
   if (which < 4) {

@@ -70,7 +70,7 @@ __constant__ int rd_d2s_tiles[4][4] = {
 template <int MB>
 __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, unsigned wvoff, int cls, int row0, int ns, long b0,
                                             const rd_bf16_t* __restrict__ aux, rd_bf16_t* __restrict__ out, int use_drop,
-                                            int l31, int lhalf) {
+                                            int l31, int lhalf, const unsigned char* __restrict__ gbits) {
   const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
   const int cd = 5 + pd, chh = 3 + ph, cw = 3 + pw;            // the phase's sub-grid (positions 2 l + 1 - parity)
   const int chw = chh * cw, cnt = cd * chw;
@@ -171,7 +171,15 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
   // inside the epilogue loop -- a divergent `continue` for rows past the item's end kept hipcc from hoisting them -- and paid a
   // round trip per 32-row block: 0.16 of the kernel's 0.38 ms at 6144 samples, scratch/d2s_abl.py.)  Rows past the end read the
   // item's first row instead of branching.
+  // gbits != nullptr: the forward of layer 1 (k_d1_gemm_fwd) left the gate in 2 bits per element, 16 bytes per row: ONE 16-byte
+  // load per row block instead of four + eight half exchanges, an eighth of the bytes (the epilogue was 0.17 of this kernel's 0.34 ms)
   rd_u32x2 gate[MB][8];
+  u32x4_t gcode[MB];
+  if (gbits) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      gcode[mb] = *(const u32x4_t*)(gbits + (long)(srow[mb] >= 0 ? orow[mb] : (int)b0 * RD_D2S_OPOS) * 16);
+  } else {
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     // 16 bytes per lane (lane half h takes the 8-channel chunks 2 P + h), then each half hands the other the four channels it
@@ -190,6 +198,7 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
 #else
     for (int G = 0; G < 8; ++G) { gate[mb][G].x = 0x3F803F80u + G + orow[mb]; gate[mb][G].y = 0xBF803F80u; }
 #endif
+  }
   }
 #ifdef RD_D2S_ABL_NOEPI              // (diagnostic builds: K loops only; one element of every accumulator keeps the MFMAs alive)
   {
@@ -211,10 +220,21 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int nb = (G + u) >> 2, g = (G + u) & 3;
-        const f32x4 ga = rd_unpack_bf16x4(gate[mb][G + u]);
         float v[4];
+        if (gbits) {
+          // quad 2 (G + u) + lhalf of the row: byte (2 ((G + u) & 1) + lhalf) of dword (G + u) >> 1
+          const unsigned byte = gcode[mb][(G + u) >> 1] >> (16 * ((G + u) & 1) + 8 * lhalf);
+          const float s1 = use_drop ? (1.0f / 0.75f) : 1.0f, s2 = RD_LRELU_ALPHA * s1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * g + e] * rd_gate_from_out(ga[e], use_drop);
+          for (int e = 0; e < 4; ++e) {
+            const unsigned code = (byte >> (2 * e)) & 3u;
+            v[e] = acc[mb][nb][4 * g + e] * ((code & 2u) ? 0.f : ((code & 1u) ? s1 : s2));
+          }
+        } else {
+          const f32x4 ga = rd_unpack_bf16x4(gate[mb][G + u]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * g + e] * rd_gate_from_out(ga[e], use_drop);
+        }
         lo[u] = rd_pack_bf16(v[0], v[1]); hi[u] = rd_pack_bf16(v[2], v[3]);
       }
       const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
@@ -234,7 +254,7 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
 // grid: min((B + 1) / 2, 2 per CU) persistent workgroups of 256 threads; dynamic LDS RD_D2S_LDS.
 __global__ void __launch_bounds__(256, 2)
 k_d2_dgrad_slab16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restrict__ wimg, const rd_bf16_t* __restrict__ aux,
-                  rd_bf16_t* __restrict__ gx, int B, int use_drop) {
+                  rd_bf16_t* __restrict__ gx, int B, int use_drop, const unsigned char* __restrict__ gbits = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -266,8 +286,8 @@ k_d2_dgrad_slab16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restrict_
       const int desc = rd_d2s_tiles[wave][t];
       const int cls = desc & 15, row0 = (desc >> 4) & 255, mbs = desc >> 12;
       if (mbs == 0) break;
-      if (mbs == 3) rd_d2s_tile<3>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf);
-      else rd_d2s_tile<2>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf);
+      if (mbs == 3) rd_d2s_tile<3>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, gbits);
+      else rd_d2s_tile<2>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, gbits);
     }
   }
 }

@@ -382,7 +382,8 @@ k_g9_wgrad_mfma(const float* __restrict__ dl, const T* __restrict__ h3, float* _
 template <typename TO, int MODE>
 __global__ void __launch_bounds__(256, 3)
 k_d1_gemm_fwd(const float* __restrict__ cin, const float* __restrict__ w, const float* __restrict__ bias, TO* out, const TO* aux,
-              long rows, int nd, int Do, int Ho, int Wo, int use_drop, uint32_t key, uint32_t idx_base) {
+              long rows, int nd, int Do, int Ho, int Wo, int use_drop, uint32_t key, uint32_t idx_base,
+              unsigned char* __restrict__ gbits = nullptr) {
   constexpr int BM = 128;
   constexpr bool BF = sizeof(TO) == 2;    // bf16 storage mode: operands rounded to bf16, v_mfma_f32_32x32x16_bf16
   constexpr int NSG = (BM * 9 + 255) / 256;             // segments per thread (5; the last one only for tid < 128)
@@ -548,6 +549,17 @@ k_d1_gemm_fwd(const float* __restrict__ cin, const float* __restrict__ w, const 
           float t = rd_lrelu(v[e]);
           if (use_drop) t = rd_drop_apply_w(t, rd_drop_word(key, (uint32_t)idx + idx_base), e);
           v[e] = t;
+        }
+        // MODE 0, optional: the layer's gate in 2 bits per element for k_d2_dgrad_slab16 -- bit 0: output > 0 (LeakyReLU' = 1),
+        // bit 1: dropped (+0.0 under dropout, rd_drop_apply); one byte per channel quad, 16 bytes per row
+        if (gbits) {
+          unsigned code = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ve = v[e];       // (by value: __builtin_bit_cast on the vector ELEMENT v[e] read element 0 for every e)
+            code |= ((ve > 0.f ? 1u : 0u) | ((use_drop && __builtin_bit_cast(unsigned, ve) == 0u) ? 2u : 0u)) << (2 * e);
+          }
+          gbits[m * 16 + (tid & 15)] = (unsigned char)code;
         }
       } else {
         const f32x4 a4 = rd_ld4(aux + idx);

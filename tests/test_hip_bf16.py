@@ -370,6 +370,43 @@ def test_d2_fwd_slab_kernel_equals_the_streaming_gemm(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B", [3, 70])
+def test_d2_gate_bits_change_nothing(B):
+    """"d2_gate_bits" (default on): layer 1's gate handed to the layer-2 input-gradient slab kernel as 2 bits per element written by
+    the forward (k_d1_gemm_fwd) instead of being read back from the stored activation: the same gate (LeakyReLU' from the sign,
+    dropped = +0.0 under dropout), so the critic step and the generator step are equal bit for bit -- with dropout (seed != 0) and
+    without (the engine's frozen-critic paths)."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 77)
+        x, cond, z = ot.synthetic_batch(B, 16, 68)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("d2_gate_bits", on)
+            res[on] = (eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 45).clone(), eng.gen_grad(ds, gs, dev(z), dev(cond), 47).clone(),
+                       eng.gen_grad(ds, gs, dev(z), dev(cond), 0).clone())
+        for a, b in zip(res[0], res[1]):
+            assert bool(torch.isfinite(b).all())
+            assert torch.equal(a, b)
+        # the bytes themselves against the stored activation (a first version took every element's "dropped" bit from element 0
+        # of its quad: __builtin_bit_cast applied to a vector ELEMENT)
+        for seed in (0, 51):
+            eng.critic_forward(ds, dev(x), dev(cond), seed)
+            h1 = eng.debug_activation(4, (B, 539, 64)).cpu()
+            got = eng.debug_activation(8, (B, 539, 16)).cpu().numpy().astype(np.uint8)
+            pos = (h1 > 0).numpy().astype(np.uint8)
+            drp = ((h1.view(torch.int32) == 0).numpy() & (seed != 0)).astype(np.uint8)
+            code = (pos | (drp << 1)).reshape(B, 539, 16, 4)
+            want = code[..., 0] | (code[..., 1] << 2) | (code[..., 2] << 4) | (code[..., 3] << 6)
+            assert np.array_equal(got, want.astype(np.uint8))
+            if seed:
+                assert 0.2 < drp.mean() < 0.3
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:
