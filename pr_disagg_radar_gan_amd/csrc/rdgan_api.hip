@@ -399,6 +399,9 @@ struct rdgan_handle {
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
   void* bW2I = nullptr;           // weight image of the slab kernel of generator block 2 (rdgan_upconv16b.hip.h): 4 MB
   int upconv2_slab = 1;           // 1: the same for block 2 (k_upconv2_slab16)
+  int g9_fused = 1;               // 1: with the block-3 slab kernel, the last conv's tap products come out of that kernel's epilogue
+                                  // (no pass over h3; critic steps do not store h3 at all)
+  void* bW9I;                     // A-fragment image of the 64 -> 1 kernel for that epilogue (k_g9_wimg): 4 KB
   void* bW2S;                     // weight image of the slab kernel of critic layer 2's input gradient (rdgan_d2slab16.hip.h): 432 KB
   int d3_wgrad_slab = 1;          // 1: bf16 storage mode, ndomain 16: weight gradient of critic layer 3 by k_d3_wgrad_slab16
   int d2_wgrad_slab = 1;          // 1: bf16 storage mode, ndomain 16: weight gradient of critic layer 2 by k_d2_wgrad_slab16
@@ -1263,6 +1266,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
         carve(p, 32L * h->ldp1 + 8); h->bW1B = p;
         carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3I = p;
+        carve(p, 4L * 64 * 4 + 8); h->bW9I = p;
         carve(p, (long)RD_UP2_KSTEPS * 4 * 64 * 4 + 8); h->bW2I = p;
         carve(p, (long)RD_D2S_KSTEPS * 2 * 64 * 4 + 8); h->bW2S = p;
         if (nd == 16) { carve(p, NB * h->dL[1] * 4 + 8); if (pass == 1) h->g1bits = (unsigned char*)p; }
@@ -1336,6 +1340,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv2_slab")) { h->upconv2_slab = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "g9_fused")) { h->g9_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d3_wgrad_slab")) { h->d3_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_wgrad_slab")) { h->d2_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
@@ -1501,19 +1506,25 @@ static bool upconv2_slab_on(const rdgan_handle* h, int l) {
 
 // `ws`: stream of the weight-only kernels (the handle's side stream, forked by the caller, or `st` itself): the weight forms of
 // block l are complete behind event ev_g[l], which `st` waits for in front of the block's GEMM
+static bool g9_fused_on(const rdgan_handle* h) { return h->g9_fused && h->tapgather && upconv_slab_on(h, 3); }
+
+// keep_h3: block 3's output and 1/l2 are needed afterwards (generator step: its backward; rdgan_gen_forward: the test hook) --
+// a critic step passes false, and with the fused last conv the 1.6 GB tensor (2048 samples) is then never written
 static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, const float* cond, float* out, int B,
-                            hipStream_t st, hipStream_t ws) {
+                            hipStream_t st, hipStream_t ws, bool keep_h3 = true) {
   const int nd = h->nd;
   const bool a16 = h->a16 != 0;
   RD_TRY(a16_check(h));
   // ---- weight forms (read only the weights): skipped when the caller vouches that the forms in the workspace were built from
   // these very weights (same slab, same content version, same form options)
-  const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0) | (h->upconv_slab ? 8 : 0) | (h->upconv2_slab ? 16 : 0);
+  const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0) | (h->upconv_slab ? 8 : 0) | (h->upconv2_slab ? 16 : 0) |
+                   (h->g9_fused && h->tapgather ? 32 : 0);
   const bool forms_cached = h->gver_in != 0 && gp == h->gcache_ptr && h->gver_in == h->gcache_ver && gcfg == h->gcache_cfg;
   if (!forms_cached) {
   h->form_builds[0]++;
   // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
   RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, ws));
+  if (g9_fused_on(h)) hipLaunchKernelGGL(k_g9_wimg, dim3(1), dim3(256), 0, ws, gp + h->goff[8], (unsigned short*)h->bW9I);
   for (int l = 1; l <= 3; ++l) {
     const float* Wl = gp + h->goff[2 * l];
     const long cc = (long)h->gch[l - 1] * h->gch[l];
@@ -1600,8 +1611,25 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       LaunchScope ls(h, pl, RD_KIND_CONV, B, plan_flops(h->plans[pl], B), st);
       RD_KNAME(h, "k_upconv_slab16<bf16>");
       h->flops_acc += plan_flops(h->plans[pl], B);
+      const dim3 ug((unsigned)std::min(6 * B, 512));
+      if (g9_fused_on(h)) {         // + the last conv's tap products (Q12 in P9) from the rows while they are in registers
+        float* nodbg = nullptr;
+        if (keep_h3) {
+          RD_TRY(ensure_lds(h, (const void*)k_upconv_slab16<1, true, true>, RD_UPC_LDS_G9));
+          hipLaunchKernelGGL((k_upconv_slab16<1, true, true>), ug, dim3(256), RD_UPC_LDS_G9, st, (const rd_bf16_t*)hs[l - 1],
+                             (const rd_bf16_t*)h->bW3I, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B, nodbg,
+                             (const unsigned short*)h->bW9I, h->P9);
+        } else {
+          RD_TRY(ensure_lds(h, (const void*)k_upconv_slab16<1, true, false>, RD_UPC_LDS_G9));
+          hipLaunchKernelGGL((k_upconv_slab16<1, true, false>), ug, dim3(256), RD_UPC_LDS_G9, st, (const rd_bf16_t*)hs[l - 1],
+                             (const rd_bf16_t*)h->bW3I, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B, nodbg,
+                             (const unsigned short*)h->bW9I, h->P9);
+        }
+        RD_CHECK(h, hipGetLastError());
+        continue;
+      }
       RD_TRY(ensure_lds(h, (const void*)k_upconv_slab16<1>, RD_UPC_LDS));
-      hipLaunchKernelGGL(k_upconv_slab16<1>, dim3((unsigned)std::min(6 * B, 512)), dim3(256), RD_UPC_LDS, st, (const rd_bf16_t*)hs[l - 1],
+      hipLaunchKernelGGL(k_upconv_slab16<1>, ug, dim3(256), RD_UPC_LDS, st, (const rd_bf16_t*)hs[l - 1],
                          (const rd_bf16_t*)h->bW3I, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B);
       RD_CHECK(h, hipGetLastError());
       continue;
@@ -1633,7 +1661,16 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // sums the in-tile taps itself and writes 3 (9) floats per grid point instead of 32.
   const int gq = 256 % (nd * nd) == 0 ? 3 : (256 % nd == 0 ? 9 : 0);
   const long ncol = (long)B * nd * nd;
-  if (!a16 && h->tapgather && h->edge_kernels == 1 && g9w_mfma_ok(nd, (long)B * h->gpix[3])) {
+  if (g9_fused_on(h)) {
+    // the tap products left the block-3 slab kernel as Q12: the sums over kd and the source classes, bias, softmax
+    ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
+    const long rows9 = (long)B * h->gpix[3];
+    LaunchScope ls(h, PL_G9F, RD_KIND_EDGE, B, 2.0 * rows9 * 64 * 27, st);
+    RD_KNAME(h, "k_tapsum_softmax12 (products: slab kernel)");
+    h->flops_acc += 2.0 * rows9 * 64 * 27;
+    hipLaunchKernelGGL((k_tapsum_softmax12<RDGAN_NHOURS>), dim3((unsigned)((ncol / 4 + 63) / 64)), dim3(256), 0, st, h->P9,
+                       gp + h->goff[9], out, B, h->d_flag);
+  } else if (!a16 && h->tapgather && h->edge_kernels == 1 && g9w_mfma_ok(nd, (long)B * h->gpix[3])) {
     // fp32 storage: pipelined streaming kernel on 128-pixel tiles (rdgan_edge.hip.h), nine kw-sums per grid point
     ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
     const long rows9 = (long)B * h->gpix[3];
@@ -1962,7 +1999,7 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   // The weight-only kernels (generator weight forms, then the critic's transposes / bf16 images behind the "critic ready"
   // event) go to the side stream beside the generator forward; the compute stream waits for them where it needs them.
   hipStream_t ws = side_fork(h, st);
-  RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st, ws));
+  RD_TRY(gen_forward_impl(h, gp, z, cond, h->fake, B, st, ws, false));    // nothing differentiates through the generator here
   if (critic_ready_event) RD_CHECK(h, hipStreamWaitEvent(ws, (hipEvent_t)critic_ready_event, 0));
   RD_TRY(prep_critic_weights(h, dp, ws));
   RD_TRY(side_join(h, st, h->ev_cw));

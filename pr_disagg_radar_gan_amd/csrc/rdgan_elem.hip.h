@@ -390,6 +390,75 @@ k_tapsum_softmax(const float* __restrict__ Q, const float* __restrict__ bias, fl
   if (bad && live) atomicOr(nonfinite, 1);
 }
 
+// The same tail behind the slab kernel with the fused last conv (k_upconv_slab16<.., G9 = true>, bf16 storage mode, ndomain 16):
+// Q12[b][plane][p][kd][q][64] = the sum over (kh, kw) of the tap products that SOURCE parity class p = 2 (y & 1) + (x & 1) of plane
+// `plane` sends to the grid points of TARGET class q (class position (y >> 1) * 8 + (x >> 1)).  logit(d, y, x) = bias + sum over
+// kd (source plane d + kd - 1) and over the four source classes, in that fixed order; then the softmax over the hours.
+// A lane owns FOUR consecutive class positions (one 16-byte load per Q12 row) and six hours; lanes l, l + 16, l + 32, l + 48 share
+// the columns as in k_tapsum_softmax (with one column and 4-byte loads per lane the 0.6 GB of Q12 came in at 3.5 TB/s).
+template <int D>
+__global__ void __launch_bounds__(256)
+k_tapsum_softmax12(const float* __restrict__ Q12, const float* __restrict__ bias, float* __restrict__ out, int B,
+                   int* __restrict__ nonfinite) {
+  static_assert(D % 4 == 0, "hours per lane");
+  constexpr int DP = D / 4, H = 16, W = 16;
+  const long ngrp = (long)B * (H * W / 4);                   // groups of four columns
+  const int lane = threadIdx.x & 63, part = lane >> 4;
+  const long grp = (blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (lane & 15);
+  const bool live = grp < ngrp;
+  const long gid = live ? grp : 0;
+  // columns of a sample in class-major order: cidx = q * 64 + class position
+  const int cidx = (int)(gid % (W * H / 4)) * 4, qc = cidx >> 6, pos = cidx & 63;
+  const int h = 2 * (pos >> 3) + (qc >> 1), w0 = 2 * (pos & 7) + (qc & 1);      // the four columns: w0, w0 + 2, w0 + 4, w0 + 6
+  const long b = gid / (W * H / 4);
+  const float bv = bias[0];
+  const float* q = Q12 + b * D * 3072 + cidx;
+  f32x4 lg[DP];
+  f32x4 mx = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+  for (int i = 0; i < DP; ++i) {
+    const int d = part * DP + i;
+    f32x4 s = {bv, bv, bv, bv};
+#pragma unroll
+    for (int td = 0; td < 3; ++td) {
+      const int sd = d + td - 1;
+      if (sd < 0 || sd >= D) continue;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s += *(const f32x4*)(q + ((long)sd * 12 + p * 3 + td) * 256);
+    }
+    lg[i] = s;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mx[c] = fmaxf(mx[c], s[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 16, 64));
+    mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], 32, 64));
+  }
+  f32x4 den = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < DP; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { lg[i][c] = expf(lg[i][c] - mx[c]); den[c] += lg[i][c]; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    den[c] += __shfl_xor(den[c], 16, 64);
+    den[c] += __shfl_xor(den[c], 32, 64);
+  }
+  bool bad = false;
+  const long hw = (long)H * W;
+  float* o = out + b * D * hw + (long)h * W + w0;
+#pragma unroll
+  for (int i = 0; i < DP; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float pr = lg[i][c] / den[c];
+      bad |= !(fabsf(pr) <= 3.0e38f);
+      if (live) o[(part * DP + i) * hw + 2 * c] = pr;
+    }
+  if (bad && live) atomicOr(nonfinite, 1);
+}
+
 // softmax-over-hours backward: dl = p * (g - sum_d p*g), one thread per (sample,h,w) column.
 __global__ void k_softmax_bwd(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ dl,
                               int B, int D, int H, int W) {

@@ -33,6 +33,10 @@
 #define RD_UPC_ZERO (RD_UPC_NSLOT * RD_UPC_SLOT)     // a 256-byte row of zeros: taps that fall outside the (h, w) picture
 #define RD_UPC_BIAS (RD_UPC_ZERO + 256)   // 64 floats
 #define RD_UPC_LDS (RD_UPC_BIAS + 256)
+// fused last conv (G9 = true): per-wave scratch [64 class rows][11: 9 (kh, kw) products + dummy + pad] fp32 behind the bias row
+#define RD_UPC_PW RD_UPC_LDS
+#define RD_UPC_PW_WAVE (64 * 11 * 4)          // row stride 11 floats: 9 products, a dummy column, odd for the banks
+#define RD_UPC_LDS_G9 (RD_UPC_PW + 4 * RD_UPC_PW_WAVE)
 
 // Weight image of the slab kernel from the collapsed forms Wc [64 = phase*8 + tap][128 ci][64 co] (fp32, k_collapse_weights):
 // for k-step g = (phase*8 + tap)*8 + j (j = 16-channel step 0..7) and column block nb, lane l holds the 8 bf16
@@ -49,6 +53,39 @@ __global__ void k_upconv_wimg(const float* __restrict__ Wc, unsigned short* __re
   for (int e = 0; e < 8; ++e) v[e] = Wc[((long)pt * 128 + k0 + e) * 64 + n];
   u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
   *(u32x4_t*)(wimg + (long)idx * 8) = o;
+}
+
+// Fused last generator conv (T:345, Conv3D 64 -> 1, 3 x 3 x 3 'same'; template flag G9).  The block's output rows are in registers
+// as packed bf16 when the epilogue stores them -- lane (l31, lhalf) of row block mb holds channels 32 nb + 8 g + 4 lhalf + 0..3 of
+// row l31 -- and the pair of channel groups (nb, 2 gp), (nb, 2 gp + 1) that makes one 16-byte store is exactly one B fragment of
+// v_mfma_f32_32x32x16_bf16 if the contraction index is read in that order.  k_g9_wimg stores the 27 x 64 kernel as the matching A
+// fragments (k-step ks = 2 nb + gp; lane (MFMA row m = l & 31, half = l >> 5) holds W9[tap(m)][32 nb + 16 gp + 4 half + e] for
+// e = 0..3 and W9[tap(m)][32 nb + 16 gp + 8 + 4 half + e - 4] for e = 4..7): four MFMAs per 32-row block (128 for the block itself)
+// give the tap products P[m][row] the separate pass over h3 (k_g9_fwd, 1.6 GB read at 2048 samples) recomputed.  MFMA row m <-> tap:
+// m = 8 kd + j for the first eight (kh, kw) taps j = 3 kh + kw of hour offset kd, m = 24 + kd for the ninth (2, 2), rows 27..31
+// zero -- accumulator register e of lane (l31, half) is row (e & 3) + 8 (e >> 2) + 4 half, so the products of one kd are
+// registers 4 kd .. 4 kd + 3 of both halves plus register 12 + kd of the lower half: five unconditional LDS stores per kd.
+// The sums over (kh, kw) stay inside an output plane, and a wave's tile covers ONE (h, w) parity class of two planes: per plane
+// and kd the wave passes its [64 class rows][9] products through a private 2.3 KB of LDS, and lane L = class position (L >> 3, L & 7)
+// of each of the four TARGET classes adds up the 1 / 2 / 2 / 4 products that land on it (a source of class p feeds a target of the
+// same class through the centre tap only, a target of the other parity along an axis through the two outer taps of that axis: one
+// from its own class position, one from the neighbour's).  Out: Q12[sample][plane][source class p][kd][target class][64] fp32 --
+// 48 B per grid point instead of the 128 B of h3; k_tapsum_softmax12 adds the four source classes and the three kd planes in a
+// fixed order.  No barrier, no cross-wave traffic.  With ST = false (critic steps: nothing differentiates through the generator)
+// h3 and 1/l2 are not stored at all.
+__global__ void k_g9_wimg(const float* __restrict__ w9 /* [27][64] */, unsigned short* __restrict__ img /* [4][64][8] */) {
+  const int idx = threadIdx.x;                    // (ks, lane)
+  const int lane = idx & 63, ks = idx >> 6, nb = ks >> 1, gp = ks & 1;
+  const int m = lane & 31, half = lane >> 5;
+  const int tap = m < 24 ? 9 * (m >> 3) + (m & 7) : 9 * (m - 24) + 8;        // rows 24, 25, 26: tap (kd, 2, 2)
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 32 * nb + 16 * gp + 8 * (e >> 2) + 4 * half + (e & 3);
+    v[e] = m < 27 ? w9[tap * 64 + c] : 0.f;
+  }
+  u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
+  *(u32x4_t*)(img + (long)idx * 8) = o;
 }
 
 // A weight fragment (1 KB per wave-instruction): global -> VGPR by an inline-asm load that hipcc does not see, so that it cannot
@@ -82,10 +119,11 @@ __device__ __forceinline__ void rd_upc_wait(u32x4_t& d0, u32x4_t& d1) {
 // data (1.5-1.7 GHz, MI355X_MICROARCH.md DVFS item 5), i.e. the attainable roof is ~0.66 of the nominal 2.5 PFLOP/s; + weight
 // stream and fragment reads 1.20; + epilogue arithmetic 1.28; + stores 1.36 = the kernel (0.50 of nominal, 0.74 of attainable).
 // grid: min(6 B, 2 CUs) persistent workgroups; dynamic LDS RD_UPC_LDS.  NAMETAG: own symbol for the profiler.
-template <int NAMETAG>
+template <int NAMETAG, bool G9 = false, bool ST = true>
 __global__ void __launch_bounds__(256, 2)
 k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ wimg, const float* __restrict__ bias,
-                rd_bf16_t* __restrict__ out, float* __restrict__ rinv, int B, float* __restrict__ dbg = nullptr) {
+                rd_bf16_t* __restrict__ out, float* __restrict__ rinv, int B, float* __restrict__ dbg = nullptr,
+                const unsigned short* __restrict__ w9img = nullptr, float* __restrict__ Q12 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,6 +251,16 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
 #endif
       // ---- epilogue, in registers: lane (l31, lhalf) of block mb holds 32 channels of output row m = 32 mb + l31 of the wave's
       // 128 rows (channels 32 nb + 8 g + 4 lhalf + 0..3), lane ^ 32 the other 32
+      u32x4_t w9f[4];
+      if constexpr (G9) {
+        // the last conv's A fragments (4 KB image, L1 / L2 resident): loaded here, per tile -- as loop invariants they would sit in
+        // 16 registers the K loop does not have
+        const unsigned short* wp = w9img;
+        asm volatile("" : "+s"(wp));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) w9f[ks] = *(const u32x4_t*)(wp + (ks * 64 + lane) * 8);
+      }
+      f32x16 pacc[2];
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         // (two-wide float arithmetic -- v_pk_fma_f32 / v_pk_mul_f32, 416 instead of ~700 instructions per tile -- was measured:
@@ -227,9 +275,13 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
         const int r = 32 * (mb & 1) + l31;
         const int dsrc = d0 + (mb >> 1);
         const long pix = (((long)b * 24 + 2 * dsrc + pd) * 16 + 2 * (r >> 3) + ph) * 16 + 2 * (r & 7) + pw;
-        if (lhalf == 0) rinv[pix] = ri;
+        if (ST && lhalf == 0) rinv[pix] = ri;
         if (dbg) { dbg[pix * 4 + lhalf] = ss; dbg[pix * 4 + 2 + lhalf] = ri; }      // (op-level test hook: both halves' row sums)
         char* orow = (char*)out + pix * 128 + lhalf * 16;
+        if constexpr (G9) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) pacc[mb & 1][e] = 0.f;
+        }
 #pragma unroll
         for (int G = 0; G < 8; G += 2) {             // channel groups 8 G .. 8 G + 7 and 8 (G + 1) .. : one 16-byte store per lane
           unsigned lo[2], hi[2];
@@ -244,15 +296,73 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
             }
             lo[u] = rd_pack_bf16(v[0], v[1]); hi[u] = rd_pack_bf16(v[2], v[3]);
           }
-          // lanes 0-31 keep their group G and take the upper half's group G; lanes 32-63 take the lower half's group G + 1
-          const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
-          const auto sy = __builtin_amdgcn_permlane32_swap(hi[0], hi[1], false, false);
-          const u32x4_t o = {sx[0], sy[0], sx[1], sy[1]};
+          if constexpr (G9) {
+            // k-step G / 2 of the last conv: this lane's eight channels (groups G, G + 1) of its row against the kernel image
+            const u32x4_t bfr = {lo[0], hi[0], lo[1], hi[1]};
+            pacc[mb & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, w9f[G >> 1]),
+                                                                  __builtin_bit_cast(rd_bf16x8, bfr), pacc[mb & 1], 0, 0, 0);
+          }
+          if constexpr (ST) {
+            // lanes 0-31 keep their group G and take the upper half's group G; lanes 32-63 take the lower half's group G + 1
+            const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(hi[0], hi[1], false, false);
+            const u32x4_t o = {sx[0], sy[0], sx[1], sy[1]};
 #ifdef RD_UPC_ABL_NOST               // (diagnostic builds: no output stores)
-          if (o.x == 0x12345678u)
+            if (o.x == 0x12345678u)
 #endif
-          *(u32x4_t*)(orow + G * 16) = o;      // (non-temporal stores: 25 % slower -- the four 16-byte pieces of a row's 128-byte line
-          //                                       leave this lane in four instructions and want to meet in L2)
+            *(u32x4_t*)(orow + G * 16) = o;    // (non-temporal stores: 25 % slower -- the four 16-byte pieces of a row's 128-byte line
+            //                                     leave this lane in four instructions and want to meet in L2)
+          }
+        }
+        if constexpr (G9) {
+          if (mb & 1) {
+            // ---- the plane (d0 + (mb >> 1), pd) is complete in pacc[0] (class rows 0..31) and pacc[1] (32..63): register e of
+            // lane (l31, lhalf) = MFMA row (e & 3) + 8 (e >> 2) + 4 lhalf of class row l31
+            float* Pw = (float*)(lds + RD_UPC_PW + wave * RD_UPC_PW_WAVE);
+            const int th = lane >> 3, tw = lane & 7;
+            // the (up to) nine sources of this lane's four targets: class position + validity, the same for every kd
+            int srow[2][2]; bool sok[2][2];         // [axis][outer tap 0 / 2]: offset of the source class position
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int dh = i ? 1 - ph : -ph, dw = i ? 1 - pw : -pw;
+              srow[0][i] = dh; sok[0][i] = (unsigned)(th + dh) < 8u;
+              srow[1][i] = dw; sok[1][i] = (unsigned)(tw + dw) < 8u;
+            }
+            float* qout = Q12 + ((((long)b * 24 + 2 * dsrc + pd) * 4 + q) * 3) * 256 + lane;
+            float* pwr = Pw + l31 * 11 + 4 * lhalf;
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pwr[u * 32 * 11 + e] = pacc[u][4 * kd + e];
+                Pw[(32 * u + l31) * 11 + 8 + lhalf] = pacc[u][12 + kd];          // upper half: a zero row into the dummy column
+              }
+              asm volatile("" ::: "memory");        // (one wave: the LDS executes its accesses in program order)
+#pragma unroll
+              for (int eh = 0; eh < 2; ++eh)
+#pragma unroll
+                for (int ew = 0; ew < 2; ++ew) {
+                  float sum = 0.f;
+#pragma unroll
+                  for (int ih = 0; ih <= eh; ++ih) {
+                    const int kh = eh ? 2 * ih : 1;
+                    const int dh = eh ? srow[0][ih] : 0;
+                    const bool okh = eh ? sok[0][ih] : true;
+#pragma unroll
+                    for (int iw = 0; iw <= ew; ++iw) {
+                      const int kw = ew ? 2 * iw : 1;
+                      const int dw = ew ? srow[1][iw] : 0;
+                      const bool ok = okh && (ew ? sok[1][iw] : true);
+                      const float pv = Pw[(ok ? lane + dh * 8 + dw : lane) * 11 + kh * 3 + kw];
+                      sum += ok ? pv : 0.f;
+                    }
+                  }
+                  qout[kd * 256 + ((ph ^ eh) * 2 + (pw ^ ew)) * 64] = sum;
+                }
+              asm volatile("" ::: "memory");
+            }
+          }
         }
       }
     }
