@@ -823,6 +823,11 @@ static bool conv16_rows_owned(const RdPlan& hp) { return hp.N == 128 || hp.N == 
 
 static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
+// workgroups a weight-gradient launch aims for (two rounds of the 512 slots of 256 CUs x 2); RDGAN_WGRAD_WGS: diagnostic override
+static long wgrad_target_wgs() {
+  static const long v = [] { const char* e = getenv("RDGAN_WGRAD_WGS"); long x = e ? atol(e) : 0; return x >= 64 && x <= 8192 ? x : 1024L; }();
+  return v;
+}
 static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int& nsplit) {
   RdWgradTiling T; memset(&T, 0, sizeof(T));
   const RdPhase& q = p.ph[0];
@@ -841,7 +846,7 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   T.NT = p.N / BN;
   long rows = (long)B * q.L;
   long tiles = (long)T.RT * T.NT * p.nphases;
-  long want = std::max(1L, (1024 + tiles - 1) / tiles);
+  long want = std::max(1L, (wgrad_target_wgs() + tiles - 1) / tiles);
   long maxs = std::max(1L, (rows + 127) / 128);
   long s = std::min(want, maxs);
   long rps = (rows + s - 1) / s;
@@ -1608,9 +1613,11 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     ep.nametag = a16 && l == 3;
     if (upconv_slab_on(h, l)) {     // block 3, bf16 storage: source slab resident in LDS, weights streamed in fragment order
       ProfScope ps(h, RDGAN_TAG_GCONV3_FWD, st);
-      LaunchScope ls(h, pl, RD_KIND_CONV, B, plan_flops(h->plans[pl], B), st);
-      RD_KNAME(h, "k_upconv_slab16<bf16>");
-      h->flops_acc += plan_flops(h->plans[pl], B);
+      // (with the fused last conv the launch also carries that layer's 2 * rows * 64 * 27 FLOPs)
+      const double fl3 = plan_flops(h->plans[pl], B) + (g9_fused_on(h) ? 2.0 * B * h->gpix[3] * 64 * 27 : 0.0);
+      LaunchScope ls(h, pl, RD_KIND_CONV, B, fl3, st);
+      RD_KNAME(h, g9_fused_on(h) ? "k_upconv_slab16<bf16, +conv 64->1>" : "k_upconv_slab16<bf16>");
+      h->flops_acc += fl3;
       const dim3 ug((unsigned)std::min(6 * B, 512));
       if (g9_fused_on(h)) {         // + the last conv's tap products (Q12 in P9) from the rows while they are in registers
         float* nodbg = nullptr;
@@ -1663,11 +1670,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   const long ncol = (long)B * nd * nd;
   if (g9_fused_on(h)) {
     // the tap products left the block-3 slab kernel as Q12: the sums over kd and the source classes, bias, softmax
-    ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
-    const long rows9 = (long)B * h->gpix[3];
-    LaunchScope ls(h, PL_G9F, RD_KIND_EDGE, B, 2.0 * rows9 * 64 * 27, st);
-    RD_KNAME(h, "k_tapsum_softmax12 (products: slab kernel)");
-    h->flops_acc += 2.0 * rows9 * 64 * 27;
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL((k_tapsum_softmax12<RDGAN_NHOURS>), dim3((unsigned)((ncol / 4 + 63) / 64)), dim3(256), 0, st, h->P9,
                        gp + h->goff[9], out, B, h->d_flag);
   } else if (!a16 && h->tapgather && h->edge_kernels == 1 && g9w_mfma_ok(nd, (long)B * h->gpix[3])) {

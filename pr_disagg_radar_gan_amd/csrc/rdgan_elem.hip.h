@@ -391,9 +391,10 @@ k_tapsum_softmax(const float* __restrict__ Q, const float* __restrict__ bias, fl
 }
 
 // The same tail behind the slab kernel with the fused last conv (k_upconv_slab16<.., G9 = true>, bf16 storage mode, ndomain 16):
-// Q12[b][plane][p][kd][q][64] = the sum over (kh, kw) of the tap products that SOURCE parity class p = 2 (y & 1) + (x & 1) of plane
-// `plane` sends to the grid points of TARGET class q (class position (y >> 1) * 8 + (x >> 1)).  logit(d, y, x) = bias + sum over
-// kd (source plane d + kd - 1) and over the four source classes, in that fixed order; then the softmax over the hours.
+// QT[b][item][tp][p][q][64]: work item `item` = planes 4 item .. 4 item + 3; tp = 0..5 = TARGET plane 4 item - 1 + tp; the sum over
+// (kh, kw) and over the hour taps inside the item of the tap products that SOURCE parity class p = 2 (y & 1) + (x & 1) sends to the
+// grid points of target class q (class position (y >> 1) * 8 + (x >> 1)).  logit(d, y, x) = bias + [the item below's tp 5] + the
+// own item's tp (d & 3) + 1 + [the item above's tp 0], four source classes each, in that fixed order; then the softmax over hours.
 // A lane owns FOUR consecutive class positions (one 16-byte load per Q12 row) and six hours; lanes l, l + 16, l + 32, l + 48 share
 // the columns as in k_tapsum_softmax (with one column and 4-byte loads per lane the 0.6 GB of Q12 came in at 3.5 TB/s).
 template <int D>
@@ -412,19 +413,23 @@ k_tapsum_softmax12(const float* __restrict__ Q12, const float* __restrict__ bias
   const int h = 2 * (pos >> 3) + (qc >> 1), w0 = 2 * (pos & 7) + (qc & 1);      // the four columns: w0, w0 + 2, w0 + 4, w0 + 6
   const long b = gid / (W * H / 4);
   const float bv = bias[0];
-  const float* q = Q12 + b * D * 3072 + cidx;
+  const float* q = Q12 + b * (D / 4 * 6 * 1024) + cidx;
   f32x4 lg[DP];
   f32x4 mx = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
   for (int i = 0; i < DP; ++i) {
     const int d = part * DP + i;
     f32x4 s = {bv, bv, bv, bv};
+    const int it = d >> 2, k = d & 3;                 // the plane's work item and its place in it
+    if (k == 0 && it > 0) {                           // the item below reaches it through its last plane (hour tap kd = 0)
 #pragma unroll
-    for (int td = 0; td < 3; ++td) {
-      const int sd = d + td - 1;
-      if (sd < 0 || sd >= D) continue;
+      for (int p = 0; p < 4; ++p) s += *(const f32x4*)(q + ((long)((it - 1) * 6 + 5) * 4 + p) * 256);
+    }
 #pragma unroll
-      for (int p = 0; p < 4; ++p) s += *(const f32x4*)(q + ((long)sd * 12 + p * 3 + td) * 256);
+    for (int p = 0; p < 4; ++p) s += *(const f32x4*)(q + ((long)(it * 6 + k + 1) * 4 + p) * 256);
+    if (k == 3 && it < D / 4 - 1) {                   // the item above through its first plane (kd = 2)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s += *(const f32x4*)(q + ((long)((it + 1) * 6) * 4 + p) * 256);
     }
     lg[i] = s;
 #pragma unroll

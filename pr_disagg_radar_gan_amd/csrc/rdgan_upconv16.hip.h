@@ -69,9 +69,10 @@ __global__ void k_upconv_wimg(const float* __restrict__ Wc, unsigned short* __re
 // and kd the wave passes its [64 class rows][9] products through a private 2.3 KB of LDS, and lane L = class position (L >> 3, L & 7)
 // of each of the four TARGET classes adds up the 1 / 2 / 2 / 4 products that land on it (a source of class p feeds a target of the
 // same class through the centre tap only, a target of the other parity along an axis through the two outer taps of that axis: one
-// from its own class position, one from the neighbour's).  Out: Q12[sample][plane][source class p][kd][target class][64] fp32 --
-// 48 B per grid point instead of the 128 B of h3; k_tapsum_softmax12 adds the four source classes and the three kd planes in a
-// fixed order.  No barrier, no cross-wave traffic.  With ST = false (critic steps: nothing differentiates through the generator)
+// from its own class position, one from the neighbour's).  The sum over kd is taken as far as the work item reaches: its four planes feed
+// six target planes (the two outer ones belong to the neighbouring items), Out: QT[sample][item][6 target planes][source class p][target
+// class][64] fp32 -- 24 B per grid point instead of the 128 B of h3; k_tapsum_softmax12 adds the four source classes and the
+// neighbouring items' outer planes in a fixed order.  No barrier, no cross-wave traffic.  With ST = false (critic steps: nothing differentiates through the generator)
 // h3 and 1/l2 are not stored at all.
 __global__ void k_g9_wimg(const float* __restrict__ w9 /* [27][64] */, unsigned short* __restrict__ img /* [4][64][8] */) {
   const int idx = threadIdx.x;                    // (ks, lane)
@@ -261,8 +262,31 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
         for (int ks = 0; ks < 4; ++ks) w9f[ks] = *(const u32x4_t*)(wp + (ks * 64 + lane) * 8);
       }
       f32x16 pacc[2];
+      // The item's four planes A0..A3 = 2 d0 .. 2 d0 + 3 (this pass: A_pd and A_(pd+2)) feed six target planes A0 - 1 .. A3 + 1
+      // (source plane A_a, hour tap kd -> target plane index tp = a + 2 - kd): QT[sample][item][tp][source class][target class][64].
+      // pd = 0 stores its share; pd = 1 adds to the four targets both passes reach (read back here, one round trip in front of the
+      // epilogue arithmetic; the same lane wrote them, behind a K loop that ended in vmcnt(0)).  Fixed order per target.
+      float hold[4] = {0.f, 0.f, 0.f, 0.f}, rmw[8];
+      // (the offset goes through an asm statement so that hipcc computes it HERE, behind the K loop's final wait: as a per-slab
+      // invariant it and the store addresses derived from it were kept in ~60 registers across the K loop, i.e. spilled)
+      int qtoff = (((b * 6 + (d0 >> 1)) * 6) * 4 + q) * 256 + lane;
+      if constexpr (G9) asm volatile("" : "+v"(qtoff));
+      float* qt = Q12 + qtoff;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
+        if constexpr (G9) {
+          if ((mb & 1) == 0) {      // the two targets plane mb >> 1 of this pass adds to (tp = 2 (mb >> 1) + 1, + 2): two row blocks ahead
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rmw[i] = 0.f;
+            if (pd == 1) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi)
+                  rmw[t * 4 + qi] = qt[(2 * (mb >> 1) + 1 + t) * 1024 + ((ph ^ (qi >> 1)) * 2 + (pw ^ (qi & 1))) * 64];
+            }
+          }
+        }
         // (two-wide float arithmetic -- v_pk_fma_f32 / v_pk_mul_f32, 416 instead of ~700 instructions per tile -- was measured:
         // 3 % SLOWER, scratch/upc_abl.py; packed fp32 issues at half rate beside the partner's MFMAs)
         float ss = 0.f;
@@ -328,7 +352,7 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
               srow[0][i] = dh; sok[0][i] = (unsigned)(th + dh) < 8u;
               srow[1][i] = dw; sok[1][i] = (unsigned)(tw + dw) < 8u;
             }
-            float* qout = Q12 + ((((long)b * 24 + 2 * dsrc + pd) * 4 + q) * 3) * 256 + lane;
+            const int pl = mb >> 1;
             float* pwr = Pw + l31 * 11 + 4 * lhalf;
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd) {
@@ -358,7 +382,16 @@ k_upconv_slab16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ w
                       sum += ok ? pv : 0.f;
                     }
                   }
-                  qout[kd * 256 + ((ph ^ eh) * 2 + (pw ^ ew)) * 64] = sum;
+                  const int qi = eh * 2 + ew, off = ((ph ^ eh) * 2 + (pw ^ ew)) * 64;
+                  if (pl == 0 && kd == 0) hold[qi] = sum;                      // completed by plane A_(pd+2), tap kd = 2
+                  else if (pd == 0) {
+                    if (pl == 1 && kd == 2) qt[2 * 1024 + off] = hold[qi] + sum;
+                    else qt[(2 * pl + 2 - kd) * 1024 + off] = sum;
+                  } else {
+                    if (pl == 1 && kd == 2) qt[3 * 1024 + off] = rmw[qi] + (hold[qi] + sum);
+                    else if (pl == 1 && kd == 0) qt[5 * 1024 + off] = sum;
+                    else qt[(2 * pl + 3 - kd) * 1024 + off] = rmw[(2 - kd) * 4 + qi] + sum;
+                  }
                 }
               asm volatile("" ::: "memory");
             }

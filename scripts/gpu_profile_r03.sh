@@ -33,4 +33,13 @@ d=$O/pmc_grbm_bf16
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $d -- python3 $R/scripts/wl_iteration.py --bf16 1 > $d.log 2>&1 || { echo "pmc grbm failed"; tail -5 $d.log; }
 find $d -name "*counter_collection.csv" -exec cp {} $O/pmc_grbm_bf16.csv \;
 rm -rf $d
+# the same two passes over the fp32 iteration (the weight-gradient kernels of the metric configuration)
+d=$O/pmc_sq_fp32
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $d -- python3 $R/scripts/wl_iteration.py --bf16 0 > $d.log 2>&1 || { echo "pmc sq fp32 failed"; tail -5 $d.log; }
+find $d -name "*counter_collection.csv" -exec cp {} $O/pmc_sq_fp32.csv \;
+rm -rf $d
+d=$O/pmc_grbm_fp32
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $d -- python3 $R/scripts/wl_iteration.py --bf16 0 > $d.log 2>&1 || { echo "pmc grbm fp32 failed"; tail -5 $d.log; }
+find $d -name "*counter_collection.csv" -exec cp {} $O/pmc_grbm_fp32.csv \;
+rm -rf $d
 ls -la $O

@@ -76,12 +76,17 @@ for mode, bf in (("fp32", False), ("bf16", True)):
     f = os.path.join(dst, f"{tag}_hbm_traffic_{mode}_bs256.csv")
     if not os.path.exists(f):
         continue
-    for r in csv.DictReader(open(f)):
-        if re.match(r"k_conv_gemm_ws<256, 64, 4, 1, \d, (true|false), 1", r["Name"]) or r["Name"].startswith("k_upconv_slab16<1>"):
-            by = (float(r["fetch_MB_per_launch_x2_corrected"]) + float(r["write_MB_per_launch"])) * 1e6
-            dom["entries"].append({"bf16": bf, "ndomain": 16, "batch": 256, "bytes_per_launch": by, "kernel": r["Name"],
-                                   "source": f"profiles/{tag}_hbm_traffic_{mode}_bs256.csv (separate rocprofv3 --pmc passes: FETCH_SIZE x 2 "
-                                             f"+ WRITE_SIZE per launch)"})
+    # the dominant launch's kernel symbol(s): with the fused last conv the slab kernel has one symbol for the launches that store
+    # their output (generator step) and one for those that do not (critic steps) -> launch-weighted mean
+    hits = [r for r in csv.DictReader(open(f))
+            if re.match(r"k_conv_gemm_ws<256, 64, 4, 1, \d, (true|false), 1", r["Name"]) or r["Name"].startswith("k_upconv_slab16<1")]
+    if hits:
+        n = sum(float(r["launches_in_2_iterations"]) for r in hits)
+        by = sum((float(r["fetch_MB_per_launch_x2_corrected"]) + float(r["write_MB_per_launch"])) * 1e6 * float(r["launches_in_2_iterations"])
+                 for r in hits) / n
+        dom["entries"].append({"bf16": bf, "ndomain": 16, "batch": 256, "bytes_per_launch": by, "kernel": " + ".join(r["Name"] for r in hits),
+                               "source": f"profiles/{tag}_hbm_traffic_{mode}_bs256.csv (separate rocprofv3 --pmc passes: FETCH_SIZE x 2 "
+                                         f"+ WRITE_SIZE per launch; launch-weighted mean over the listed symbols)"})
 if dom["entries"]:
     with open(os.path.join(dst, "hbm_traffic_dominant.json"), "w") as o:
         json.dump(dom, o, indent=1)
@@ -114,35 +119,36 @@ for mode, run in (("0", "fp32_bs256"), ("1", "bf16_bs256")):
 
 # SQ counters of the bf16 GEMM launches (one --pmc pass; SQ_* count quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES, which counts cycles:
 # MI355X_MICROARCH.md constants table): per kernel name, means per launch and the shares of wave time
-f = os.path.join(src, "pmc_sq_bf16.csv")
-if os.path.exists(f):
-    acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
-    for r in csv.DictReader(open(f)):
-        acc[short(r["Kernel_Name"])][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    grbm = defaultdict(lambda: defaultdict(float))
-    g = os.path.join(src, "pmc_grbm_bf16.csv")
-    if os.path.exists(g):
-        for r in csv.DictReader(open(g)):
-            grbm[short(r["Kernel_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    out = os.path.join(dst, f"{tag}_sq_counters_bf16_bs256.csv")
-    with open(out, "w", newline="") as o:
-        w = csv.writer(o)
-        cols = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
-                "SQ_INSTS_VALU_MFMA_MOPS_BF16"]
-        w.writerow(["Name", "launches"] + [c + "_per_launch" for c in cols] + ["wait_any_share_of_wave_cycles", "wait_inst_share", "active_share",
-                   "mfma_busy_cycles_per_SIMD_cycle (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)", "GRBM_GUI_ACTIVE_per_launch"])
-        rows = []
-        for n, d in acc.items():
-            m = {k: sum(v.values()) / max(len(v), 1) for k, v in d.items()}
-            if m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0:
-                continue
-            wc = max(m.get("SQ_WAVE_CYCLES", 0.0), 1.0)
-            ga = sum(grbm[n].values()) / max(len(grbm[n]), 1) if n in grbm else float("nan")
-            busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (ga / 8 * 1024) if ga == ga and ga > 0 else float("nan")
-            rows.append([n, len(d.get("SQ_WAVE_CYCLES", {}))] + [f"{m.get(c, 0.0):.0f}" for c in cols] +
-                        [f"{m.get('SQ_WAIT_ANY', 0) / wc:.3f}", f"{m.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}", f"{m.get('SQ_ACTIVE_INST_ANY', 0) / wc:.3f}",
-                         f"{busy:.3f}", f"{ga:.0f}"])
-        rows.sort(key=lambda r: -float(r[8]))
-        for r in rows:
-            w.writerow(r)
-    print("wrote", out)
+for sqmode, mops in (("bf16", "SQ_INSTS_VALU_MFMA_MOPS_BF16"), ("fp32", "SQ_INSTS_VALU_MFMA_MOPS_F32")):
+    f = os.path.join(src, f"pmc_sq_{sqmode}.csv")
+    if os.path.exists(f):
+        acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        grbm = defaultdict(lambda: defaultdict(float))
+        g = os.path.join(src, f"pmc_grbm_{sqmode}.csv")
+        if os.path.exists(g):
+            for r in csv.DictReader(open(g)):
+                grbm[short(r["Kernel_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        out = os.path.join(dst, f"{tag}_sq_counters_{sqmode}_bs256.csv")
+        with open(out, "w", newline="") as o:
+            w = csv.writer(o)
+            cols = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
+                    mops]
+            w.writerow(["Name", "launches"] + [c + "_per_launch" for c in cols] + ["wait_any_share_of_wave_cycles", "wait_inst_share", "active_share",
+                       "mfma_busy_cycles_per_SIMD_cycle (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)", "GRBM_GUI_ACTIVE_per_launch"])
+            rows = []
+            for n, d in acc.items():
+                m = {k: sum(v.values()) / max(len(v), 1) for k, v in d.items()}
+                if m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0:
+                    continue
+                wc = max(m.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+                ga = sum(grbm[n].values()) / max(len(grbm[n]), 1) if n in grbm else float("nan")
+                busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (ga / 8 * 1024) if ga == ga and ga > 0 else float("nan")
+                rows.append([n, len(d.get("SQ_WAVE_CYCLES", {}))] + [f"{m.get(c, 0.0):.0f}" for c in cols] +
+                            [f"{m.get('SQ_WAIT_ANY', 0) / wc:.3f}", f"{m.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}", f"{m.get('SQ_ACTIVE_INST_ANY', 0) / wc:.3f}",
+                             f"{busy:.3f}", f"{ga:.0f}"])
+            rows.sort(key=lambda r: -float(r[8]))
+            for r in rows:
+                w.writerow(r)
+        print("wrote", out)
