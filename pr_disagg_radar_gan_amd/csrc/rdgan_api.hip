@@ -61,6 +61,75 @@ static RdPlan plan_conv_fwd(int D, int H, int W, int Cin, int Cout, int Do, int 
   return p;
 }
 
+// The same convolution with the output grid cut into at most RD_MAX_PHASES boxes by BORDER CLASS (option "border_boxes").  A
+// strided 'same' conv on a small grid multiplies many zeros: a tap that leaves the picture is a zero row of the implicit GEMM, and
+// on the critic's 6x4x4 / 3x2x2 / 2x1x1 output grids that is 38 % / 38 % / 70 % of all (position, tap) pairs (T:291-299).  Per axis
+// the outputs fall into runs with the same set of valid taps (first / middle / last); a box = a product of such runs and lists
+// only the taps valid somewhere in it (rows for which a listed tap is invalid keep their zero row through the validity mask), so
+// the products that remain are the same, in the same tap order: results identical to the one-phase plan up to the K-split
+// boundaries.  More than RD_MAX_PHASES boxes are merged greedily, adjacent pair with the least added (row, tap) work first.
+// Phases come out longest tap list first (the launchers run unequal phases in that order).
+struct RdAxisRun { int lo, cnt, mask; };
+static RdPlan plan_conv_fwd_boxes(int D, int H, int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride,
+                                  int pd, int ph_, int pw) {
+  RdPlan p = plan_conv_fwd(D, H, W, Cin, Cout, Do, Ho, Wo, stride, pd, ph_, pw, 0);
+  const int S[3] = {D, H, W}, O[3] = {Do, Ho, Wo}, pad[3] = {pd, ph_, pw};
+  std::vector<RdAxisRun> runs[3];
+  for (int a = 0; a < 3; ++a)
+    for (int o = 0; o < O[a]; ++o) {
+      int m = 0;
+      for (int k = 0; k < 3; ++k) { const int v = o * stride + k - pad[a]; if (v >= 0 && v < S[a]) m |= 1 << k; }
+      if (!runs[a].empty() && runs[a].back().mask == m) runs[a].back().cnt++;
+      else runs[a].push_back({o, 1, m});
+    }
+  struct Box { RdAxisRun r[3]; };
+  auto cost = [](const Box& b) { long c = 1; for (int a = 0; a < 3; ++a) c *= (long)b.r[a].cnt * __builtin_popcount(b.r[a].mask); return c; };
+  std::vector<Box> boxes;
+  for (const RdAxisRun& rd : runs[0]) for (const RdAxisRun& rh : runs[1]) for (const RdAxisRun& rw : runs[2]) boxes.push_back({{rd, rh, rw}});
+  while ((int)boxes.size() > RD_MAX_PHASES) {
+    long best = -1; size_t bi = 0, bj = 0; Box bm{};
+    for (size_t i = 0; i < boxes.size(); ++i)
+      for (size_t j = 0; j < boxes.size(); ++j) {
+        if (i == j) continue;
+        for (int a = 0; a < 3; ++a) {
+          bool ok = boxes[i].r[a].lo + boxes[i].r[a].cnt == boxes[j].r[a].lo;
+          for (int x = 0; x < 3; ++x) if (x != a && (boxes[i].r[x].lo != boxes[j].r[x].lo || boxes[i].r[x].cnt != boxes[j].r[x].cnt)) ok = false;
+          if (!ok) continue;
+          Box m = boxes[i];
+          for (int x = 0; x < 3; ++x) m.r[x].mask |= boxes[j].r[x].mask;
+          m.r[a].cnt += boxes[j].r[a].cnt;
+          const long inc = cost(m) - cost(boxes[i]) - cost(boxes[j]);
+          if (best < 0 || inc < best) { best = inc; bi = i; bj = j; bm = m; }
+        }
+      }
+    if (best < 0) return p;                 // (cannot happen for a product partition; keep the one-phase plan)
+    boxes.erase(boxes.begin() + std::max(bi, bj)); boxes.erase(boxes.begin() + std::min(bi, bj));
+    boxes.push_back(bm);
+  }
+  if (boxes.size() < 2 && cost(boxes[0]) == (long)Do * Ho * Wo * 27) return p;      // nothing to skip
+  std::stable_sort(boxes.begin(), boxes.end(), [](const Box& x, const Box& y) {
+    auto nt = [](const Box& b) { return __builtin_popcount(b.r[0].mask) * __builtin_popcount(b.r[1].mask) * __builtin_popcount(b.r[2].mask); };
+    return nt(x) > nt(y);
+  });
+  p.nphases = (int)boxes.size();
+  p.boxes = 1;
+  for (int i = 0; i < p.nphases; ++i) {
+    const Box& b = boxes[i];
+    RdPhase& q = p.ph[i];
+    phase_defaults(q, b.r[0].cnt, b.r[1].cnt, b.r[2].cnt);
+    for (int a = 0; a < 3; ++a) { q.s_mul[a] = stride; q.s_off[a] = b.r[a].lo * stride; q.o_off[a] = b.r[a].lo; }
+    q.ntaps = 0;
+    for (int t = 0; t < 27; ++t) {
+      const int k[3] = {t / 9, (t / 3) % 3, t % 3};
+      if (!((b.r[0].mask >> k[0]) & 1) || !((b.r[1].mask >> k[1]) & 1) || !((b.r[2].mask >> k[2]) & 1)) continue;
+      const int n = q.ntaps++;
+      for (int a = 0; a < 3; ++a) q.tap_off[n][a] = (int8_t)(k[a] - pad[a]);
+      q.tap[n].w = t;
+    }
+  }
+  return p;
+}
+
 // D1 (T:286): 2-channel input, stride 2, 'valid'.  (kw, ci) is contiguous in NDHWC with C = 2, so the
 // 27 x CP taps are gathered as 9 taps (kd,kh) x 3*CP contiguous floats (CP = floats per voxel: 2, or 4 with the
 // extra condition channels of the revision-1 variants).
@@ -319,7 +388,7 @@ static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
           RdRow e = {0, 0, 0, 0};
           long so = 0, dof = 0;
           for (int a = 0; a < 3; ++a) {
-            int pre = l[a] * q.s_mul[a];
+            int pre = l[a] * q.s_mul[a] + q.s_off[a];
             so = so * S[a] + (pre >> p.s_shift);
             dof = dof * Dd[a] + (l[a] * q.o_mul[a] + q.o_off[a]);
             for (int off = -1; off <= 2; ++off) {
@@ -350,7 +419,9 @@ enum {
   PL_D1F, PL_D2F, PL_D3F, PL_D4F, PL_D2B, PL_D3B, PL_D4B, PL_D1B,
   PL_G1FC, PL_G2FC, PL_G3FC, PL_G1BC, PL_G2BC, PL_G3BC,
   PL_F1WA, PL_F2WA, PL_F3WA, PL_F1WS, PL_F2WS, PL_F3WS, PL_F1WD, PL_F2WD, PL_F3WD,   // shared-centre backward (fast_bwd)
-  PL_F1BS, PL_F2BS, PL_F3BS, PL_F1BE, PL_F2BE, PL_F3BE, PL_F1FE, PL_F2FE, PL_F3FE, PL_COUNT
+  PL_F1BS, PL_F2BS, PL_F3BS, PL_F1BE, PL_F2BE, PL_F3BE, PL_F1FE, PL_F2FE, PL_F3FE,
+  PL_D2FX, PL_D3FX, PL_D4FX,          // critic layers 2-4 forward, output grid cut into border-class boxes (plan_conv_fwd_boxes)
+  PL_COUNT
 };
 
 // one GEMM launch under rdgan_profile_launches: which plan, through which kernel, how many samples and algorithmic FLOPs
@@ -411,6 +482,7 @@ struct rdgan_handle {
   void* bW2F = nullptr;           // weight image of the slab kernel of critic layer 2's forward (rdgan_d2fwd16.hip.h): 448 KB
   int d2_fwd_slab = 0;            // 1: bf16 storage mode, ndomain 16: forward of critic layer 2 by k_d2_fwd_slab16 (measured: no faster than the streaming GEMM, default off)
   unsigned char* g1bits = nullptr; // layer 1's gate in 2 bits per element (written by k_d1_gemm_fwd, read by k_d2_dgrad_slab16): 16 B per row
+  int border_boxes = 1;           // 1: forward / second-sweep GEMMs of critic layers 2-4 skip the taps that leave the picture (plan_conv_fwd_boxes)
   int d2_gate_bits = 1;           // 1: the slab kernel of layer 2's input gradient reads the packed gate instead of layer 1's output
   int d2_slab = 1;                // 1: bf16 storage mode, ndomain 16: input gradient of critic layer 2 by k_d2_dgrad_slab16
   int a16 = 0;                    // 1: bf16 storage mode (option "bf16"; needs the collapsed + shared-centre forms)
@@ -743,7 +815,7 @@ static int launch_conv(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int 
       RD_CONV(128, 64, 2, 2);
     }
     // few rows, very long K (input gradient of the first generator block): producer/consumer kernel with its K split
-    if (ws_ok && h->ws_ksplit && hp.nphases == 1 && hp.d_cstride == hp.N && (long)hp.ph[0].ntaps * (hp.SC / 32) >= 96 &&
+    if (ws_ok && h->ws_ksplit && (hp.nphases == 1 || hp.boxes) && hp.d_cstride == hp.N && (long)hp.ph[0].ntaps * (hp.SC / 32) >= 96 &&
         plan_tiles(hp, B, 128) * (hp.N / 64) >= 32)
       return launch_conv_ws_cfg<128, 64, 2, 2>(h, hp, dp, B, src, W, ldw, dst, epi, st);
     RD_CONV(64, 64, 2, 2);
@@ -1157,6 +1229,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     const int* id = h->ddim[l - 1]; const int* od = h->ddim[l]; const int* pd = h->dpad[l - 1];
     h->plans[PL_D2F + l - 2] = plan_conv_fwd(id[0], id[1], id[2], dch[l - 1], dch[l], od[0], od[1], od[2], 2, pd[0], pd[1], pd[2], 0);
     h->plans[PL_D2B + l - 2] = plan_conv_dgrad_s2(id[0], id[1], id[2], dch[l - 1], od[0], od[1], od[2], dch[l], pd);
+    h->plans[PL_D2FX + l - 2] = plan_conv_fwd_boxes(id[0], id[1], id[2], dch[l - 1], dch[l], od[0], od[1], od[2], 2, pd[0], pd[1], pd[2]);
   }
   h->plans[PL_D1B] = plan_rows(h->ddim[1][0], h->ddim[1][1], h->ddim[1][2], 64, 64, h->ldp1, h->ldp1);
   hipError_t e = hipSuccess;
@@ -1346,6 +1419,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv2_slab")) { h->upconv2_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "g9_fused")) { h->g9_fused = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "border_boxes")) { h->border_boxes = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }    // 2 = at every size (tests)
   if (!strcmp(name, "d3_wgrad_slab")) { h->d3_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_wgrad_slab")) { h->d2_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
@@ -1409,7 +1483,8 @@ static const char* const RD_PLAN_NAMES[PL_COUNT] = {
   "gen block1 shared-centre E[s+1]", "gen block2 shared-centre E[s+1]", "gen block3 shared-centre E[s+1]",
   "gen block1 dgrad shared part", "gen block2 dgrad shared part", "gen block3 dgrad shared part",
   "gen block1 dgrad difference part", "gen block2 dgrad difference part", "gen block3 dgrad difference part",
-  "gen block1 fwd difference part", "gen block2 fwd difference part", "gen block3 fwd difference part"};
+  "gen block1 fwd difference part", "gen block2 fwd difference part", "gen block3 fwd difference part",
+  "critic layer2 (border boxes)", "critic layer3 (border boxes)", "critic layer4 (border boxes)"};
 
 extern "C" int rdgan_profile_launches(rdgan_handle* h, int on) {
   if (!h) return -2;
@@ -1511,6 +1586,17 @@ static bool upconv2_slab_on(const rdgan_handle* h, int l) {
 
 // `ws`: stream of the weight-only kernels (the handle's side stream, forked by the caller, or `st` itself): the weight forms of
 // block l are complete behind event ev_g[l], which `st` waits for in front of the block's GEMM
+// plan of the forward / second-sweep GEMM of critic layer l >= 2 over n samples: the border-class boxes where they pay -- with
+// few rows the boxes' short tap lists lose the K splits that fill the chip (layer 3 at 256 samples: 60 -> 68 us), so a small
+// launch keeps the one-phase plan unless the boxes drop more than half of the work (layer 4: 70 %)
+static int critic_fwd_plan(const rdgan_handle* h, int l, int n) {
+  const int one = PL_D2F + l - 2, box = PL_D2FX + l - 2;
+  if (!h->border_boxes || !h->plans[box].boxes) return one;
+  const long rows = (long)n * h->dL[l];
+  if (h->border_boxes >= 2 || rows >= 8192 || 2.0 * plan_flops(h->plans[box], 1) <= plan_flops(h->plans[one], 1)) return box;
+  return one;
+}
+
 static bool g9_fused_on(const rdgan_handle* h) { return h->g9_fused && h->tapgather && upconv_slab_on(h, 3); }
 
 // keep_h3: block 3's output and 1/l2 are needed afterwards (generator step: its backward; rdgan_gen_forward: the test hook) --
@@ -1870,7 +1956,7 @@ static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64
   const bool a16 = h->a16 != 0;
   const float* in = h->cin;
   for (int l = 1; l <= 4; ++l) {
-    int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
+    int pl = l == 1 ? PL_D1F : critic_fwd_plan(h, l, NBt);
     RdEpi ep = epi_make(RD_EPI_BIAS_LRELU_DROP, dp + h->doff[2 * (l - 1) + 1], nullptr, use_drop,
                         rd_make_key(seed, RD_STREAM_D1 + l - 1), 0);
     ep.out16 = a16;
@@ -2050,7 +2136,7 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   {
     const float* in = cin_hat;
     for (int l = 1; l <= 4; ++l) {
-      int pl = l == 1 ? PL_D1F : PL_D2F + l - 2;
+      int pl = l == 1 ? PL_D1F : critic_fwd_plan(h, l, B);
       long third = (long)2 * B * h->dL[l] * h->dch[l];
       float* dst = act_off(h, h->dh[l], third);
       RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, dst, use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 1), (uint32_t)third);

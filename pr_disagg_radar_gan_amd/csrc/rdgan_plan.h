@@ -2,7 +2,7 @@
 // folded nearest-upsample, its input gradient by parity phases, the Dense layers, the 1x1
 // "column" GEMMs) is one implicit GEMM   C[m][n] = sum_taps sum_c A_gather[m][tap][c] * W[tap_w][c][n]
 // described by this batch-independent plan.  Rows m enumerate (sample, ld, lh, lw) of a
-// loop space; per axis  src_pre = l*s_mul + tap_off  (valid iff 0 <= src_pre < S<<s_shift,
+// loop space; per axis  src_pre = l*s_mul + s_off + tap_off  (valid iff 0 <= src_pre < S<<s_shift,
 // src = src_pre >> s_shift)  and  dst = l*o_mul + o_off.
 #pragma once
 #include <stdint.h>
@@ -15,6 +15,7 @@ struct RdTap { int mask, delta, w, code; };
 struct RdPhase {
   int L, LD, LH, LW;           // rows per sample and loop extents
   int s_mul[3];
+  int s_off[3];                // source coordinate of loop index 0 before the tap offset: src_pre = l * s_mul + s_off + tap_off (host side)
   int o_mul[3], o_off[3];
   int ntaps;
   int w_off;                   // element offset added to W for this phase
@@ -47,6 +48,7 @@ struct RdPlan {
   int N;                       // GEMM N
   int interleave;              // all phases congruent: tile order is (row tile, phase) with the phase fastest, so
                                // the phases that re-read the same source rows run together
+  int boxes;                   // phases = border-class boxes of ONE output grid (plan_conv_fwd_boxes): same rows as the one-phase plan
   long src_sample, dst_sample; // floats per sample of the source / destination tensor
   const RdRow* tab;            // device pointer to the row tables of all phases
   RdPhase ph[RD_MAX_PHASES];

@@ -339,6 +339,41 @@ def test_side_stream_is_bit_identical(nd, B, bf16):
         eng.close()
 
 
+@pytest.mark.parametrize("nd,B,bf16", [(16, 5, 0), (16, 70, 0), (16, 70, 1), (8, 9, 0), (32, 3, 0), (64, 1, 1)])
+def test_border_boxes_skip_only_zero_products(nd, B, bf16):
+    """"border_boxes" (default on): the forward and second-sweep GEMMs of critic layers 2-4 (Conv3D 3x3x3, stride 2, 'same',
+    T:291-299) run on plans whose output grid is cut into border-class boxes that list only the taps that can land inside the
+    picture (plan_conv_fwd_boxes) -- 28 % / 38 % / 70 % fewer (row, tap) products at ndomain 16, every one of them a product with a
+    zero row.  The remaining products are the same and come in the same tap order; only where a K split cuts the tap list can the
+    fp32 summation order differ.  So: critic value, both gradient slabs (dropout on: the masks are keyed by destination index) equal
+    the one-phase plans' to rounding; and the box plans are the default every oracle test of this suite runs on."""
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 81)
+        x, cond, z = ot.synthetic_batch(min(B, 16), nd, 82)
+        rep = lambda a: np.concatenate([a] * (B // a.shape[0] + 1))[:B]
+        x, cond, z = rep(x), rep(cond), rep(z)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        if bf16:
+            eng.set_option("bf16", 1)
+        res = {}
+        for boxes in (0, 2):            # 2: the box plans at every size (1, the default, keeps the one-phase plan for small launches)
+            eng.set_option("border_boxes", boxes)
+            v = eng.critic_forward(ds, dev(x), dev(cond), seed=7).clone()
+            cg = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 11).clone()
+            gg = eng.gen_grad(ds, gs, dev(z), dev(cond), 13).clone()
+            assert torch.equal(cg, eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 11))
+            res[boxes] = [t.cpu().numpy() for t in (v, cg, gg)]
+        tol = 5e-3 if bf16 else 2e-5      # bf16 storage: a sum that moves by one fp32 ulp can round to the neighbouring bf16 value
+        for a, b, what in zip(res[0], res[2], ("critic value", "critic-step slab", "generator-step slab")):
+            assert np.all(np.isfinite(b))
+            e = np.abs(a - b).max() / np.abs(a).max()
+            print(f"nd {nd} B {B} bf16 {bf16} border boxes on vs off, {what}: {e:.2e}")
+            assert e < tol, (what, e)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("bf16", [0, 1])
 def test_side_stream_training_run_is_bit_identical(bf16):
     """40 whole iterations (2 critic updates + 1 generator update each, B = 48: the tiles of the big-batch step, back-to-back
