@@ -27,6 +27,7 @@
 #include "rdgan_upwgrad16b.hip.h"
 #include "rdgan_d2wgrad16.hip.h"
 #include "rdgan_d3wgrad16.hip.h"
+#include "rdgan_d1fwd16.hip.h"
 static_assert(RDGAN_LOSS_SLOTS == 8, "k_critic_losses / k_gen_loss write slots 0..7");
 // k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
 static bool g9w_mfma_ok(int nd, long npix) { return nd >= 8 && nd <= 128 && (nd & (nd - 1)) == 0 && npix < 0x7FFFFFFFL; }
@@ -482,6 +483,7 @@ struct rdgan_handle {
   void* bW2F = nullptr;           // weight image of the slab kernel of critic layer 2's forward (rdgan_d2fwd16.hip.h): 448 KB
   int d2_fwd_slab = 0;            // 1: bf16 storage mode, ndomain 16: forward of critic layer 2 by k_d2_fwd_slab16 (measured: no faster than the streaming GEMM, default off)
   unsigned char* g1bits = nullptr; // layer 1's gate in 2 bits per element (written by k_d1_gemm_fwd, read by k_d2_dgrad_slab16): 16 B per row
+  int d1_fwd_sample = 1;          // 1: bf16 storage mode, ndomain 16: layer-1 forward / second sweep with a sample resident in LDS (k_d1_fwd_sample16)
   int border_boxes = 1;           // 1: forward / second-sweep GEMMs of critic layers 2-4 skip the taps that leave the picture (plan_conv_fwd_boxes)
   int d2_gate_bits = 1;           // 1: the slab kernel of layer 2's input gradient reads the packed gate instead of layer 1's output
   int d2_slab = 1;                // 1: bf16 storage mode, ndomain 16: input gradient of critic layer 2 by k_d2_dgrad_slab16
@@ -1419,6 +1421,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv2_slab")) { h->upconv2_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "g9_fused")) { h->g9_fused = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "d1_fwd_sample")) { h->d1_fwd_sample = value ? 1 : 0; return 0; }
   if (!strcmp(name, "border_boxes")) { h->border_boxes = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }    // 2 = at every size (tests)
   if (!strcmp(name, "d3_wgrad_slab")) { h->d3_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_wgrad_slab")) { h->d2_wgrad_slab = value ? 1 : 0; return 0; }
@@ -1896,6 +1899,23 @@ static int launch_d1_fwd(rdgan_handle* h, const float* in, const float* w, const
   ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
   const long rows = (long)NBt * h->dL[1];
   LaunchScope ls(h, PL_D1F, RD_KIND_EDGE, NBt, 2.0 * rows * 54 * 64, st);
+  if (h->d1_fwd_sample && h->a16 && h->nd == 16 && h->CP == 2 && h->dL[1] == RD_D1S_NPOS && (mode == 0 || d2_gate_bits_on(h))) {
+    // a sample's input volume resident in LDS (rdgan_d1fwd16.hip.h).  Mode 1 (second sweep, in place over the x_hat third) takes the
+    // gate from the 2-bit codes the forward left for the rows at element offset idx_base
+    RD_KNAME(h, "k_d1_fwd_sample16<bf16,%d>", mode);
+    h->flops_acc += 2.0 * rows * 54 * 64;
+    const dim3 grid((unsigned)std::min(NBt, 768));
+    if (mode == 0) {
+      RD_TRY(ensure_lds(h, (const void*)k_d1_fwd_sample16<0>, RD_D1S_LDS));
+      hipLaunchKernelGGL(k_d1_fwd_sample16<0>, grid, dim3(256), RD_D1S_LDS, st, in, w, bias, (rd_bf16_t*)out, gbits, NBt, use_drop, key, idx_base);
+    } else {
+      RD_TRY(ensure_lds(h, (const void*)k_d1_fwd_sample16<1>, RD_D1S_LDS));
+      hipLaunchKernelGGL(k_d1_fwd_sample16<1>, grid, dim3(256), RD_D1S_LDS, st, in, w, bias, (rd_bf16_t*)out,
+                         h->g1bits + (size_t)(idx_base / 64) * 16, NBt, use_drop, key, idx_base);
+    }
+    RD_CHECK(h, hipGetLastError());
+    return 0;
+  }
   RD_KNAME(h, "k_d1_gemm_fwd<%s,%d>", h->a16 ? "bf16" : "f32", mode);
   h->flops_acc += 2.0 * rows * 54 * 64;
   constexpr size_t lds = (size_t)(128 * 64 + 64 * 64) * 4 + 2 * 128 * 8;

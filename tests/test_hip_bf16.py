@@ -378,6 +378,50 @@ def test_fused_last_conv_equals_the_separate_pass(B):
         eng.close()
 
 
+@pytest.mark.parametrize("B,seed", [(1, 31), (5, 0), (70, 35), (300, 37)])
+def test_d1_sample_kernel_equals_the_tile_kernel(B, seed):
+    """"d1_fwd_sample" (default on; bf16 storage mode, ndomain 16): forward and second sweep of the critic's FIRST layer with a
+    sample's input volume resident in LDS (k_d1_fwd_sample16) against the tile kernel k_d1_gemm_fwd<bf16>: the same bf16 operands
+    (im2col rows and kernel rounded alike), the contraction index dealt to the MFMA's k slots in another order and the bias in
+    the accumulator from the start, so sums differ in the last fp32 bits and the stored bf16 activation in at most one ulp in a
+    small share of the elements; same dropout mask, the 2-bit gate codes equal wherever the activations do.  The critic step --
+    whose second sweep reads its gate from those codes in the new kernel and from the stored activation in the old one -- follows.
+    B = 300: more samples (900 in the step) than the launch has workgroups."""
+    eng = Engine(ndomain=16, max_batch=B)
+    try:
+        g, d = _params(16, 73)
+        x, cond, z = ot.synthetic_batch(min(B, 32), 16, 63)
+        rep = lambda a: np.concatenate([a] * (B // a.shape[0] + 1))[:B]
+        x, cond, z = rep(x), rep(cond), rep(z)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("d1_fwd_sample", on)
+            v = eng.critic_forward(ds, dev(x), dev(cond), seed).clone()
+            h1 = eng.debug_activation(4, (B, 11, 7, 7, 64)).clone()
+            gb = eng.debug_activation(8, (B, 539, 16)).clone()
+            c = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), seed).clone()
+            assert torch.equal(c, eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), seed))
+            res[on] = (v, h1, gb, c)
+        (v0, a0, b0, c0), (v1, a1, b1, c1) = res[0], res[1]
+        assert bool(torch.isfinite(a1).all()) and bool(torch.isfinite(c1).all())
+        assert torch.equal(a0 == 0, a1 == 0) and torch.equal(torch.signbit(a0), torch.signbit(a1))      # same mask, same kept zeros
+        rel = (a1 - a0).abs() / a0.abs().clamp_min(1e-3)
+        assert float(rel.max()) <= 2.0 ** -7 + 1e-6, float(rel.max())
+        assert float((a1 != a0).float().mean()) < 5e-3
+        assert float((b1 != b0).float().mean()) < 1e-4            # a code can only move where an output sits at the kink
+        assert float((v1 - v0).abs().max()) < 2e-3 * (1.0 + float(v0.abs().max()))
+        n = eng.n_critic
+        e = float((c1[:n] - c0[:n]).abs().max() / c0[:n].abs().max())
+        print(f"B {B} d1_fwd_sample 1 vs 0: critic-step gradients differ by {e:.2e} of the largest entry, "
+              f"{float((a1 != a0).float().mean()):.1e} of the activations by one ulp")
+        assert e < 3e-3
+        np.testing.assert_allclose(c1[n:n + 4].cpu().numpy(), c0[n:n + 4].cpu().numpy(), rtol=2e-3, atol=2e-4)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [2, 50])
 def test_d2_fwd_slab_kernel_equals_the_streaming_gemm(B):
     """"d2_fwd_slab" (default off: measured no faster; ndomain 16): the forward of critic layer 2 in the slab kernel k_d2_fwd_slab16
@@ -425,6 +469,8 @@ def test_d2_gate_bits_change_nothing(B):
         x, cond, z = ot.synthetic_batch(B, 16, 68)
         gs, ds = eng.to_slab(g), eng.to_slab(d)
         eng.set_option("bf16", 1)
+        eng.set_option("d1_fwd_sample", 0)      # (the sample-resident layer-1 kernel takes its second-sweep gate from the codes only: with the
+        #                                          codes off the engine falls back to the tile kernel there -- another kernel, not the same bits)
         res = {}
         for on in (0, 1):
             eng.set_option("d2_gate_bits", on)
@@ -435,7 +481,8 @@ def test_d2_gate_bits_change_nothing(B):
             assert torch.equal(a, b)
         # the bytes themselves against the stored activation (a first version took every element's "dropped" bit from element 0
         # of its quad: __builtin_bit_cast applied to a vector ELEMENT)
-        for seed in (0, 51):
+        for seed, sample_kernel in ((0, 0), (51, 0), (0, 1), (51, 1)):       # the codes of both layer-1 forward kernels
+            eng.set_option("d1_fwd_sample", sample_kernel)
             eng.critic_forward(ds, dev(x), dev(cond), seed)
             h1 = eng.debug_activation(4, (B, 539, 64)).cpu()
             got = eng.debug_activation(8, (B, 539, 16)).cpu().numpy().astype(np.uint8)
