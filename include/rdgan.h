@@ -155,9 +155,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * (kh, kw) and the hour taps inside the work item; k_tapsum_softmax12 adds the source parity classes and the neighbouring items and
  * takes the softmax.  No pass over block 3's output (k_g9_fwd); a critic step does not store that output at all.  Same bf16 products
  * as 0, another fp32 summation order: fractions agree to ~3e-7 of the largest.
- * "border_boxes" (default 1; 2 = at every size, 0 = off): the forward and second-sweep GEMMs of critic layers 2-4 (stride-2 'same'
- * convs on 6x4x4 / 3x2x2 / 2x1x1 output grids) run on plans whose output grid is cut into at most eight border-class boxes, each
- * listing only the taps that can land inside the picture: 28 / 38 / 70 % fewer (row, tap) products at ndomain 16, all of them
+ * "border_boxes" (default 1; 2 = at every size, 0 = off): the forward, second-sweep and input-gradient GEMMs of critic layers 2-4
+ * (stride-2 'same' convs on 6x4x4 / 3x2x2 / 2x1x1 output grids) run on plans whose loop spaces are cut into border-class boxes,
+ * each listing only the taps that can land inside the picture: 38 / 38 / 70 % fewer (row, tap) products at ndomain 16, all of them
  * products with a zero row.  Same products in the same tap order as the one-phase plans; small launches (few rows) keep the
  * one-phase plan, whose long K the K split needs.
  * "d2_gate_bits" (default 1; with "d2_slab" and the layer-1 edge kernels): the forward of layer 1 also writes its gate -- per element

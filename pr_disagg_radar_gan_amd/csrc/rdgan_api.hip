@@ -62,73 +62,107 @@ static RdPlan plan_conv_fwd(int D, int H, int W, int Cin, int Cout, int Do, int 
   return p;
 }
 
-// The same convolution with the output grid cut into at most RD_MAX_PHASES boxes by BORDER CLASS (option "border_boxes").  A
-// strided 'same' conv on a small grid multiplies many zeros: a tap that leaves the picture is a zero row of the implicit GEMM, and
-// on the critic's 6x4x4 / 3x2x2 / 2x1x1 output grids that is 38 % / 38 % / 70 % of all (position, tap) pairs (T:291-299).  Per axis
-// the outputs fall into runs with the same set of valid taps (first / middle / last); a box = a product of such runs and lists
-// only the taps valid somewhere in it (rows for which a listed tap is invalid keep their zero row through the validity mask), so
-// the products that remain are the same, in the same tap order: results identical to the one-phase plan up to the K-split
-// boundaries.  More than RD_MAX_PHASES boxes are merged greedily, adjacent pair with the least added (row, tap) work first.
-// Phases come out longest tap list first (the launchers run unequal phases in that order).
-struct RdAxisRun { int lo, cnt, mask; };
-static RdPlan plan_conv_fwd_boxes(int D, int H, int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride,
-                                  int pd, int ph_, int pw) {
-  RdPlan p = plan_conv_fwd(D, H, W, Cin, Cout, Do, Ho, Wo, stride, pd, ph_, pw, 0);
-  const int S[3] = {D, H, W}, O[3] = {Do, Ho, Wo}, pad[3] = {pd, ph_, pw};
-  std::vector<RdAxisRun> runs[3];
-  for (int a = 0; a < 3; ++a)
-    for (int o = 0; o < O[a]; ++o) {
-      int m = 0;
-      for (int k = 0; k < 3; ++k) { const int v = o * stride + k - pad[a]; if (v >= 0 && v < S[a]) m |= 1 << k; }
-      if (!runs[a].empty() && runs[a].back().mask == m) runs[a].back().cnt++;
-      else runs[a].push_back({o, 1, m});
+// A plan with its loop spaces cut into boxes by BORDER CLASS (option "border_boxes").  A strided 'same' conv on a small grid
+// multiplies many zeros: a tap that leaves the picture is a zero row of the implicit GEMM, and on the critic's 6x4x4 / 3x2x2 /
+// 2x1x1 output grids that is 38 % / 38 % / 70 % of all (position, tap) pairs (T:291-299), the same share in the input gradients.
+// Per phase and axis the loop indices fall into runs with the same set of valid tap offsets (first / middle / last); a box = a
+// product of such runs, a phase of its own with the parent's weights and only the taps valid somewhere in it (rows for which a
+// listed tap is invalid keep their zero row through the validity mask), so the products that remain are the same, in the same tap
+// order: results identical to the parent plan up to the K-split boundaries.  More than RD_MAX_PHASES boxes are merged greedily
+// (same parent phase, adjacent pair with the least added (row, tap) work first).  Phases come out longest tap list first (the
+// launchers run unequal phases in that order).  Returns the plan unchanged when no box drops a tap.
+static RdPlan plan_boxes(const RdPlan& src) {
+  if (src.s_shift) return src;
+  const int S[3] = {src.SD, src.SH, src.SW};
+  struct Box { int parent, lo[3], cnt[3]; unsigned mask[3]; };
+  struct Run { int lo, cnt; unsigned mask; };
+  auto ntaps_of = [&](const Box& b) {
+    const RdPhase& q = src.ph[b.parent];
+    int n = 0;
+    for (int t = 0; t < q.ntaps; ++t) {
+      bool ok = true;
+      for (int a = 0; a < 3; ++a) ok = ok && ((b.mask[a] >> (q.tap_off[t][a] + 1)) & 1u);
+      n += ok;
     }
-  struct Box { RdAxisRun r[3]; };
-  auto cost = [](const Box& b) { long c = 1; for (int a = 0; a < 3; ++a) c *= (long)b.r[a].cnt * __builtin_popcount(b.r[a].mask); return c; };
+    return n;
+  };
+  auto cost = [&](const Box& b) { return (long)b.cnt[0] * b.cnt[1] * b.cnt[2] * ntaps_of(b); };
   std::vector<Box> boxes;
-  for (const RdAxisRun& rd : runs[0]) for (const RdAxisRun& rh : runs[1]) for (const RdAxisRun& rw : runs[2]) boxes.push_back({{rd, rh, rw}});
+  long full = 0;
+  for (int pi = 0; pi < src.nphases; ++pi) {
+    const RdPhase& q = src.ph[pi];
+    const int LL[3] = {q.LD, q.LH, q.LW};
+    full += (long)q.L * q.ntaps;
+    std::vector<Run> runs[3];
+    for (int a = 0; a < 3; ++a) {
+      unsigned used = 0;
+      for (int t = 0; t < q.ntaps; ++t) used |= 1u << (q.tap_off[t][a] + 1);
+      for (int l = 0; l < LL[a]; ++l) {
+        unsigned m = 0;
+        for (int off = -1; off <= 2; ++off) {
+          const int v = l * q.s_mul[a] + q.s_off[a] + off;
+          if (((used >> (off + 1)) & 1u) && v >= 0 && v < S[a]) m |= 1u << (off + 1);
+        }
+        if (!runs[a].empty() && runs[a].back().mask == m) runs[a].back().cnt++;
+        else runs[a].push_back({l, 1, m});
+      }
+    }
+    for (const Run& rd : runs[0]) for (const Run& rh : runs[1]) for (const Run& rw : runs[2])
+      boxes.push_back({pi, {rd.lo, rh.lo, rw.lo}, {rd.cnt, rh.cnt, rw.cnt}, {rd.mask, rh.mask, rw.mask}});
+  }
   while ((int)boxes.size() > RD_MAX_PHASES) {
     long best = -1; size_t bi = 0, bj = 0; Box bm{};
     for (size_t i = 0; i < boxes.size(); ++i)
       for (size_t j = 0; j < boxes.size(); ++j) {
-        if (i == j) continue;
+        if (i == j || boxes[i].parent != boxes[j].parent) continue;
         for (int a = 0; a < 3; ++a) {
-          bool ok = boxes[i].r[a].lo + boxes[i].r[a].cnt == boxes[j].r[a].lo;
-          for (int x = 0; x < 3; ++x) if (x != a && (boxes[i].r[x].lo != boxes[j].r[x].lo || boxes[i].r[x].cnt != boxes[j].r[x].cnt)) ok = false;
+          bool ok = boxes[i].lo[a] + boxes[i].cnt[a] == boxes[j].lo[a];
+          for (int x = 0; x < 3; ++x) if (x != a && (boxes[i].lo[x] != boxes[j].lo[x] || boxes[i].cnt[x] != boxes[j].cnt[x])) ok = false;
           if (!ok) continue;
           Box m = boxes[i];
-          for (int x = 0; x < 3; ++x) m.r[x].mask |= boxes[j].r[x].mask;
-          m.r[a].cnt += boxes[j].r[a].cnt;
+          for (int x = 0; x < 3; ++x) m.mask[x] |= boxes[j].mask[x];
+          m.cnt[a] += boxes[j].cnt[a];
           const long inc = cost(m) - cost(boxes[i]) - cost(boxes[j]);
           if (best < 0 || inc < best) { best = inc; bi = i; bj = j; bm = m; }
         }
       }
-    if (best < 0) return p;                 // (cannot happen for a product partition; keep the one-phase plan)
+    if (best < 0) return src;
     boxes.erase(boxes.begin() + std::max(bi, bj)); boxes.erase(boxes.begin() + std::min(bi, bj));
     boxes.push_back(bm);
   }
-  if (boxes.size() < 2 && cost(boxes[0]) == (long)Do * Ho * Wo * 27) return p;      // nothing to skip
-  std::stable_sort(boxes.begin(), boxes.end(), [](const Box& x, const Box& y) {
-    auto nt = [](const Box& b) { return __builtin_popcount(b.r[0].mask) * __builtin_popcount(b.r[1].mask) * __builtin_popcount(b.r[2].mask); };
-    return nt(x) > nt(y);
-  });
+  long left = 0;
+  for (const Box& b : boxes) left += cost(b);
+  if (left >= full) return src;                       // nothing to skip
+  std::stable_sort(boxes.begin(), boxes.end(), [&](const Box& x, const Box& y) { return ntaps_of(x) > ntaps_of(y); });
+  RdPlan p = src;
   p.nphases = (int)boxes.size();
   p.boxes = 1;
   for (int i = 0; i < p.nphases; ++i) {
     const Box& b = boxes[i];
+    const RdPhase& par = src.ph[b.parent];
     RdPhase& q = p.ph[i];
-    phase_defaults(q, b.r[0].cnt, b.r[1].cnt, b.r[2].cnt);
-    for (int a = 0; a < 3; ++a) { q.s_mul[a] = stride; q.s_off[a] = b.r[a].lo * stride; q.o_off[a] = b.r[a].lo; }
+    q = par;
+    q.LD = b.cnt[0]; q.LH = b.cnt[1]; q.LW = b.cnt[2]; q.L = q.LD * q.LH * q.LW;
+    for (int a = 0; a < 3; ++a) { q.s_off[a] = par.s_off[a] + b.lo[a] * par.s_mul[a]; q.o_off[a] = par.o_off[a] + b.lo[a] * par.o_mul[a]; }
     q.ntaps = 0;
-    for (int t = 0; t < 27; ++t) {
-      const int k[3] = {t / 9, (t / 3) % 3, t % 3};
-      if (!((b.r[0].mask >> k[0]) & 1) || !((b.r[1].mask >> k[1]) & 1) || !((b.r[2].mask >> k[2]) & 1)) continue;
+    for (int t = 0; t < par.ntaps; ++t) {
+      bool ok = true;
+      for (int a = 0; a < 3; ++a) ok = ok && ((b.mask[a] >> (par.tap_off[t][a] + 1)) & 1u);
+      if (!ok) continue;
       const int n = q.ntaps++;
-      for (int a = 0; a < 3; ++a) q.tap_off[n][a] = (int8_t)(k[a] - pad[a]);
-      q.tap[n].w = t;
+      for (int a = 0; a < 4; ++a) q.tap_off[n][a] = par.tap_off[t][a];
+      q.tap[n] = par.tap[t];
+    }
+    if (q.ntaps == 0) {       // (a box no tap reaches still owns its output rows: one tap, every row of it masked)
+      for (int a = 0; a < 4; ++a) q.tap_off[0][a] = par.tap_off[0][a];
+      q.tap[0] = par.tap[0]; q.ntaps = 1;
     }
   }
   return p;
+}
+static RdPlan plan_conv_fwd_boxes(int D, int H, int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride,
+                                  int pd, int ph_, int pw) {
+  return plan_boxes(plan_conv_fwd(D, H, W, Cin, Cout, Do, Ho, Wo, stride, pd, ph_, pw, 0));
 }
 
 // D1 (T:286): 2-channel input, stride 2, 'valid'.  (kw, ci) is contiguous in NDHWC with C = 2, so the
@@ -370,6 +404,7 @@ static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
   for (int pi = 0; pi < p.nphases; ++pi) {
     RdPhase& q = p.ph[pi];
     q.tab = first;
+    p.phL[pi] = q.L;
     for (int t = 0; t < q.ntaps; ++t) {
       int mask = 0;
       for (int a = 0; a < 3; ++a) {
@@ -421,7 +456,8 @@ enum {
   PL_G1FC, PL_G2FC, PL_G3FC, PL_G1BC, PL_G2BC, PL_G3BC,
   PL_F1WA, PL_F2WA, PL_F3WA, PL_F1WS, PL_F2WS, PL_F3WS, PL_F1WD, PL_F2WD, PL_F3WD,   // shared-centre backward (fast_bwd)
   PL_F1BS, PL_F2BS, PL_F3BS, PL_F1BE, PL_F2BE, PL_F3BE, PL_F1FE, PL_F2FE, PL_F3FE,
-  PL_D2FX, PL_D3FX, PL_D4FX,          // critic layers 2-4 forward, output grid cut into border-class boxes (plan_conv_fwd_boxes)
+  PL_D2FX, PL_D3FX, PL_D4FX,          // critic layers 2-4 forward, output grid cut into border-class boxes (plan_boxes)
+  PL_D2BX, PL_D3BX, PL_D4BX,          // their input gradients, every parity phase cut the same way
   PL_COUNT
 };
 
@@ -1232,6 +1268,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->plans[PL_D2F + l - 2] = plan_conv_fwd(id[0], id[1], id[2], dch[l - 1], dch[l], od[0], od[1], od[2], 2, pd[0], pd[1], pd[2], 0);
     h->plans[PL_D2B + l - 2] = plan_conv_dgrad_s2(id[0], id[1], id[2], dch[l - 1], od[0], od[1], od[2], dch[l], pd);
     h->plans[PL_D2FX + l - 2] = plan_conv_fwd_boxes(id[0], id[1], id[2], dch[l - 1], dch[l], od[0], od[1], od[2], 2, pd[0], pd[1], pd[2]);
+    h->plans[PL_D2BX + l - 2] = plan_boxes(h->plans[PL_D2B + l - 2]);
   }
   h->plans[PL_D1B] = plan_rows(h->ddim[1][0], h->ddim[1][1], h->ddim[1][2], 64, 64, h->ldp1, h->ldp1);
   hipError_t e = hipSuccess;
@@ -1487,7 +1524,8 @@ static const char* const RD_PLAN_NAMES[PL_COUNT] = {
   "gen block1 dgrad shared part", "gen block2 dgrad shared part", "gen block3 dgrad shared part",
   "gen block1 dgrad difference part", "gen block2 dgrad difference part", "gen block3 dgrad difference part",
   "gen block1 fwd difference part", "gen block2 fwd difference part", "gen block3 fwd difference part",
-  "critic layer2 (border boxes)", "critic layer3 (border boxes)", "critic layer4 (border boxes)"};
+  "critic layer2 (border boxes)", "critic layer3 (border boxes)", "critic layer4 (border boxes)",
+  "critic layer2 dgrad (border boxes)", "critic layer3 dgrad (border boxes)", "critic layer4 dgrad (border boxes)"};
 
 extern "C" int rdgan_profile_launches(rdgan_handle* h, int on) {
   if (!h) return -2;
@@ -1592,12 +1630,17 @@ static bool upconv2_slab_on(const rdgan_handle* h, int l) {
 // plan of the forward / second-sweep GEMM of critic layer l >= 2 over n samples: the border-class boxes where they pay -- with
 // few rows the boxes' short tap lists lose the K splits that fill the chip (layer 3 at 256 samples: 60 -> 68 us), so a small
 // launch keeps the one-phase plan unless the boxes drop more than half of the work (layer 4: 70 %)
-static int critic_fwd_plan(const rdgan_handle* h, int l, int n) {
-  const int one = PL_D2F + l - 2, box = PL_D2FX + l - 2;
+static int critic_box_plan(const rdgan_handle* h, int one, int box, long rows) {
   if (!h->border_boxes || !h->plans[box].boxes) return one;
-  const long rows = (long)n * h->dL[l];
   if (h->border_boxes >= 2 || rows >= 8192 || 2.0 * plan_flops(h->plans[box], 1) <= plan_flops(h->plans[one], 1)) return box;
   return one;
+}
+static int critic_fwd_plan(const rdgan_handle* h, int l, int n) {
+  return critic_box_plan(h, PL_D2F + l - 2, PL_D2FX + l - 2, (long)n * h->dL[l]);
+}
+// the same choice for the input gradient of layer l >= 2 (rows = the layer's input positions)
+static int critic_dgrad_plan(const rdgan_handle* h, int l, int n) {
+  return critic_box_plan(h, PL_D2B + l - 2, PL_D2BX + l - 2, (long)n * h->dL[l - 1]);
 }
 
 static bool g9_fused_on(const rdgan_handle* h) { return h->g9_fused && h->tapgather && upconv_slab_on(h, 3); }
@@ -2023,7 +2066,7 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
                             h->du[4], NBt, h->F, B, mode, use_drop, rd_make_key(seed, RD_STREAM_D1 + 3));
   }
   for (int l = 4; l >= 2; --l) {
-    int pl = PL_D2B + l - 2;
+    int pl = critic_dgrad_plan(h, l, NBt);
     RdEpi ep = epi_make(RD_EPI_GATE_AUX, nullptr, h->dh[l - 1], use_drop, rd_make_key(seed, RD_STREAM_D1 + l - 2), 0);
     ep.out16 = a16;
     if (l == 2 && d2_slab_on(h)) {      // two samples' output gradient resident in LDS, weights streamed in fragment order

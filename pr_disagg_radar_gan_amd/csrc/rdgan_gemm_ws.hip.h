@@ -121,7 +121,7 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
     mt /= nph;
   } else {
     for (int p = 0; p < plan->nphases; ++p) {
-      int nt = (B * plan->ph[p].L + BM - 1) / BM;
+      int nt = (B * plan->phL[p] + BM - 1) / BM;
       if (mt < nt) { pidx = p; break; }
       mt -= nt;
     }

@@ -8,7 +8,7 @@
 #include <stdint.h>
 
 #define RD_MAX_TAPS 64
-#define RD_MAX_PHASES 8
+#define RD_MAX_PHASES 32
 
 struct RdTap { int mask, delta, w, code; };
 
@@ -51,6 +51,7 @@ struct RdPlan {
   int boxes;                   // phases = border-class boxes of ONE output grid (plan_conv_fwd_boxes): same rows as the one-phase plan
   long src_sample, dst_sample; // floats per sample of the source / destination tensor
   const RdRow* tab;            // device pointer to the row tables of all phases
+  int phL[RD_MAX_PHASES];      // ph[i].L again, contiguous: a workgroup of a plan with unequal phases finds its phase by walking these
   RdPhase ph[RD_MAX_PHASES];
 };
 

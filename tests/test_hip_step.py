@@ -341,9 +341,9 @@ def test_side_stream_is_bit_identical(nd, B, bf16):
 
 @pytest.mark.parametrize("nd,B,bf16", [(16, 5, 0), (16, 70, 0), (16, 70, 1), (8, 9, 0), (32, 3, 0), (64, 1, 1)])
 def test_border_boxes_skip_only_zero_products(nd, B, bf16):
-    """"border_boxes" (default on): the forward and second-sweep GEMMs of critic layers 2-4 (Conv3D 3x3x3, stride 2, 'same',
-    T:291-299) run on plans whose output grid is cut into border-class boxes that list only the taps that can land inside the
-    picture (plan_conv_fwd_boxes) -- 28 % / 38 % / 70 % fewer (row, tap) products at ndomain 16, every one of them a product with a
+    """"border_boxes" (default on): the forward, second-sweep and input-gradient GEMMs of critic layers 2-4 (Conv3D 3x3x3, stride 2,
+    'same', T:291-299) run on plans whose loop spaces are cut into border-class boxes that list only the taps that can land inside
+    the picture (plan_boxes) -- 38 % / 38 % / 70 % fewer (row, tap) products at ndomain 16, every one of them a product with a
     zero row.  The remaining products are the same and come in the same tap order; only where a K split cuts the tap list can the
     fp32 summation order differ.  So: critic value, both gradient slabs (dropout on: the masks are keyed by destination index) equal
     the one-phase plans' to rounding; and the box plans are the default every oracle test of this suite runs on."""
