@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdgan_hip.so")
 SOURCES = ["rdgan_api.hip"]
-HEADERS = ["rdgan_gemm.hip.h", "rdgan_gemm_ws.hip.h", "rdgan_gemm_ws16.hip.h", "rdgan_upconv16.hip.h", "rdgan_upconv16b.hip.h", "rdgan_d2slab16.hip.h", "rdgan_d2fwd16.hip.h", "rdgan_upwgrad16.hip.h", "rdgan_upwgrad16b.hip.h", "rdgan_d2wgrad16.hip.h", "rdgan_d3wgrad16.hip.h", "rdgan_d1fwd16.hip.h", "rdgan_elem.hip.h", "rdgan_edge.hip.h", "rdgan_data.hip.h", "rdgan_plan.h", "rdgan_rng.h",
+HEADERS = ["rdgan_gemm.hip.h", "rdgan_gemm_ws.hip.h", "rdgan_gemm_ws16.hip.h", "rdgan_upconv16.hip.h", "rdgan_upconv16b.hip.h", "rdgan_d2slab16.hip.h", "rdgan_d2fwd16.hip.h", "rdgan_upwgrad16.hip.h", "rdgan_upwgrad16b.hip.h", "rdgan_d2wgrad16.hip.h", "rdgan_d3wgrad16.hip.h", "rdgan_d1fwd16.hip.h", "rdgan_g9bwd16.hip.h", "rdgan_elem.hip.h", "rdgan_edge.hip.h", "rdgan_data.hip.h", "rdgan_plan.h", "rdgan_rng.h",
            "../../include/rdgan.h"]
 
 

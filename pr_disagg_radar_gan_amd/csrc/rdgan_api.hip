@@ -28,6 +28,7 @@
 #include "rdgan_d2wgrad16.hip.h"
 #include "rdgan_d3wgrad16.hip.h"
 #include "rdgan_d1fwd16.hip.h"
+#include "rdgan_g9bwd16.hip.h"
 static_assert(RDGAN_LOSS_SLOTS == 8, "k_critic_losses / k_gen_loss write slots 0..7");
 // k_g9_wgrad_mfma: W a power of two in [8, 128]; dynamic LDS = tile + staged dlogits rows + row descriptors (>= the 32 KB fold)
 static bool g9w_mfma_ok(int nd, long npix) { return nd >= 8 && nd <= 128 && (nd & (nd - 1)) == 0 && npix < 0x7FFFFFFFL; }
@@ -519,6 +520,7 @@ struct rdgan_handle {
   void* bW2F = nullptr;           // weight image of the slab kernel of critic layer 2's forward (rdgan_d2fwd16.hip.h): 448 KB
   int d2_fwd_slab = 0;            // 1: bf16 storage mode, ndomain 16: forward of critic layer 2 by k_d2_fwd_slab16 (measured: no faster than the streaming GEMM, default off)
   unsigned char* g1bits = nullptr; // layer 1's gate in 2 bits per element (written by k_d1_gemm_fwd, read by k_d2_dgrad_slab16): 16 B per row
+  int g9_bwd_mfma = 1;            // 1: bf16 storage mode: input gradient of the last conv + block 3's PixelNorm backward on the fp32 matrix pipe (k_g9_bwd_mfma16)
   int d1_fwd_sample = 1;          // 1: bf16 storage mode, ndomain 16: layer-1 forward / second sweep with a sample resident in LDS (k_d1_fwd_sample16)
   int border_boxes = 1;           // 1: forward / second-sweep GEMMs of critic layers 2-4 skip the taps that leave the picture (plan_conv_fwd_boxes)
   int d2_gate_bits = 1;           // 1: the slab kernel of layer 2's input gradient reads the packed gate instead of layer 1's output
@@ -1459,6 +1461,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "upconv2_slab")) { h->upconv2_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "g9_fused")) { h->g9_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_fwd_sample")) { h->d1_fwd_sample = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "g9_bwd_mfma")) { h->g9_bwd_mfma = value ? 1 : 0; return 0; }
   if (!strcmp(name, "border_boxes")) { h->border_boxes = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }    // 2 = at every size (tests)
   if (!strcmp(name, "d3_wgrad_slab")) { h->d3_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_wgrad_slab")) { h->d2_wgrad_slab = value ? 1 : 0; return 0; }
@@ -2391,6 +2394,14 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
     if (l == 3 && g9_direct) {
       // input gradient of the 64 -> 1 conv + block 3's PixelNorm+LeakyReLU backward (+ plane-pair sums)
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+      if (a16 && !fast && h->g9_bwd_mfma && (nd * nd) % 32 == 0) {
+        // exact fp32 products on the matrix pipe, the row's backward in registers (rdgan_g9bwd16.hip.h)
+        const size_t lds9 = (size_t)4 * (nd + 2) * (nd + 2) * sizeof(float);
+        const int nunits = B * (RDGAN_NHOURS / 2);
+        RD_TRY(ensure_lds(h, (const void*)k_g9_bwd_mfma16, lds9));
+        hipLaunchKernelGGL(k_g9_bwd_mfma16, dim3((unsigned)std::min(nunits, 1536)), dim3(256), lds9, st, h->dl, gp + h->goff[8],
+                           (const rd_bf16_t*)hs[3], rs[3], (rd_bf16_t*)dys[3], nunits, RDGAN_NHOURS, nd, nd);
+      } else
       if (a16) hipLaunchKernelGGL(k_g9_bwd_pairs<rd_bf16_t>, dim3(B * (RDGAN_NHOURS / 2)), dim3(256), g9_lds, st, h->dl, gp + h->goff[8],
                                   (const rd_bf16_t*)hs[3], rs[3], (rd_bf16_t*)dys[3], fast ? (rd_bf16_t*)h->fgS : (rd_bf16_t*)nullptr,
                                   RDGAN_NHOURS, nd, nd);

@@ -422,6 +422,45 @@ def test_d1_sample_kernel_equals_the_tile_kernel(B, seed):
         eng.close()
 
 
+@pytest.mark.parametrize("nd,B", [(16, 1), (16, 7), (16, 130), (64, 1), (8, 3)])
+def test_last_conv_input_gradient_on_the_matrix_pipe(nd, B):
+    """"g9_bwd_mfma" (default on in the bf16 storage mode's collapsed form): the input gradient of the generator's last conv (64 -> 1,
+    T:345) + block 3's PixelNorm / LeakyReLU backward by k_g9_bwd_mfma16 -- the fp32 dlogits against the fp32 kernel on
+    v_mfma_f32_32x32x2_f32, exact fp32 products -- against the VALU kernel k_g9_bwd_pairs: the same products, summed in another
+    order in fp32, then ONE bf16 rounding of the block's pre-activation gradient.  That tensor feeds the whole generator backward:
+    the step's gradient slab agrees to 1e-4 ... 4e-3 of each tensor's largest entry (one-ulp differences of bf16 values, 2^-8, carried
+    through three blocks), inside the mode's 3e-2 against the oracle -- which every bf16 oracle test measures on this kernel, the
+    default, with the same errors as on the VALU kernel."""
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 79)
+        x, cond, z = ot.synthetic_batch(min(B, 16), nd, 65)
+        rep = lambda a: np.concatenate([a] * (B // a.shape[0] + 1))[:B]
+        cond, z = rep(cond), rep(z)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("g9_bwd_mfma", on)
+            gg = eng.gen_grad(ds, gs, dev(z), dev(cond), 21).clone()
+            assert torch.equal(gg, eng.gen_grad(ds, gs, dev(z), dev(cond), 21))
+            res[on] = gg.cpu().numpy()
+        a, b = res[0], res[1]
+        assert np.all(np.isfinite(b))
+        n = eng.n_gen
+        errs = {}
+        off = 0
+        for name, shp in eng.gen_shapes:
+            k = int(np.prod(shp))
+            errs[name] = float(np.abs(a[off:off + k] - b[off:off + k]).max() / max(np.abs(a[off:off + k]).max(), 1e-30))
+            off += k
+        print(f"nd {nd} B {B} g9_bwd_mfma 1 vs 0:", {k: float(f"{v:.1e}") for k, v in errs.items() if k != "conv3d_3/bias:0"})
+        assert max(v for k, v in errs.items() if k != "conv3d_3/bias:0") < 1e-2, errs
+        np.testing.assert_allclose(b[n:n + 1], a[n:n + 1], rtol=1e-5, atol=1e-6)           # the loss does not depend on the backward
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [2, 50])
 def test_d2_fwd_slab_kernel_equals_the_streaming_gemm(B):
     """"d2_fwd_slab" (default off: measured no faster; ndomain 16): the forward of critic layer 2 in the slab kernel k_d2_fwd_slab16
