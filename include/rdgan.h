@@ -155,6 +155,11 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * (kh, kw) and the hour taps inside the work item; k_tapsum_softmax12 adds the source parity classes and the neighbouring items and
  * takes the softmax.  No pass over block 3's output (k_g9_fwd); a critic step does not store that output at all.  Same bf16 products
  * as 0, another fp32 summation order: fractions agree to ~3e-7 of the largest.
+ * "d1_fwd_sample" (default 1; bf16 storage mode, ndomain 16, one condition channel): forward and second sweep of the critic's first
+ * layer with a sample's input volume resident in LDS (k_d1_fwd_sample16); the second sweep then takes its gate from the 2-bit codes
+ * ("d2_gate_bits"; without them it keeps the tile kernel).  One bf16 ulp from 0 in ~4e-5 of the activations.
+ * "g9_bwd_mfma" (default 1; bf16 storage mode, collapsed backward): the input gradient of the generator's last conv + block 3's
+ * PixelNorm backward on the fp32 matrix pipe (k_g9_bwd_mfma16: exact fp32 products); 0 = the VALU kernel k_g9_bwd_pairs.
  * "border_boxes" (default 1; 2 = at every size, 0 = off): the forward, second-sweep and input-gradient GEMMs of critic layers 2-4
  * (stride-2 'same' convs on 6x4x4 / 3x2x2 / 2x1x1 output grids) run on plans whose loop spaces are cut into border-class boxes,
  * each listing only the taps that can land inside the picture: 38 / 38 / 70 % fewer (row, tap) products at ndomain 16, all of them
