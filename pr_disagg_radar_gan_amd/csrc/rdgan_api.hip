@@ -406,6 +406,9 @@ static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
     RdPhase& q = p.ph[pi];
     q.tab = first;
     p.phL[pi] = q.L;
+    p.phT[pi] = q.ntaps;
+    for (int w = 0; w < 32; ++w) p.tapinv[pi][w] = -1;
+    for (int t = 0; t < q.ntaps; ++t) if (q.tap[t].w >= 0 && q.tap[t].w < 32) p.tapinv[pi][q.tap[t].w] = (signed char)t;
     for (int t = 0; t < q.ntaps; ++t) {
       int mask = 0;
       for (int a = 0; a < 3; ++a) {
@@ -522,6 +525,7 @@ struct rdgan_handle {
   unsigned char* g1bits = nullptr; // layer 1's gate in 2 bits per element (written by k_d1_gemm_fwd, read by k_d2_dgrad_slab16): 16 B per row
   int g9_bwd_mfma = 1;            // 1: bf16 storage mode: input gradient of the last conv + block 3's PixelNorm backward on the fp32 matrix pipe (k_g9_bwd_mfma16)
   int d1_fwd_sample = 1;          // 1: bf16 storage mode, ndomain 16: layer-1 forward / second sweep with a sample resident in LDS (k_d1_fwd_sample16)
+  int wgrad_boxes = 1;            // 1: the weight gradients of critic layers 2-4 (streaming kernels) on the border-class boxes too
   int border_boxes = 1;           // 1: forward / second-sweep GEMMs of critic layers 2-4 skip the taps that leave the picture (plan_conv_fwd_boxes)
   int d2_gate_bits = 1;           // 1: the slab kernel of layer 2's input gradient reads the packed gate instead of layer 1's output
   int d2_slab = 1;                // 1: bf16 storage mode, ndomain 16: input gradient of critic layer 2 by k_d2_dgrad_slab16
@@ -947,7 +951,7 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   BN = (p.N % 128 == 0) ? 128 : 64;
   // 64 input channels against >= 128 output channels (critic layer 2): two taps per 128-row tile, so every wave owns a
   // 64x64 tile (4 fragment reads per 4 MFMAs instead of 3 per 2)
-  if (p.SC == 64 && BN == 128 && q.ntaps >= 2 && p.nphases == 1 && !p.s_shift) BR = 128;
+  if (p.SC == 64 && BN == 128 && q.ntaps >= 2 && (p.nphases == 1 || p.boxes) && !p.s_shift) BR = 128;
   if (BN == 64 && p.SC == 128 && q.ntaps % 2 == 0 && (long)B * q.L >= 65536) BR = 256;   // two taps per tile, 4 accumulators per wave
   if (p.SC >= BR) {
     T.tiles_per_tap = (p.SC + BR - 1) / BR; T.cw = BR; T.taps_per_tile = 1; T.RT = q.ntaps * T.tiles_per_tap;
@@ -956,6 +960,25 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
     T.RT = (q.ntaps + T.taps_per_tile - 1) / T.taps_per_tile;
   }
   T.NT = p.N / BN;
+  T.tpt_log2 = T.taps_per_tile >= 4 ? 2 : (T.taps_per_tile >= 2 ? 1 : 0);
+  if (p.boxes) {
+    // border-class boxes: ONE power-of-two row count per split for all phases, the smallest that keeps the launch at about a
+    // thousand workgroups; nsplit = workgroups in all, RT = partial slabs in all (what the callers size and launch with)
+    T.box = 1;
+    for (int lg = 5; lg < 31; ++lg) {
+      long wgs = 0, slabs = 0;
+      for (int i = 0; i < p.nphases; ++i) {
+        const long nsp = ((long)B * p.ph[i].L + (1L << lg) - 1) >> lg;
+        const long rtp = rd_wgrad_phase_rt(T, p.ph[i].ntaps);
+        wgs += rtp * T.NT * nsp; slabs += rtp * nsp;
+      }
+      T.rps_log2 = lg; T.rows_per_split = 1 << lg; T.nsplit = (int)wgs; T.RT = (int)slabs;
+      if (wgs <= wgrad_target_wgs() * 5 / 4) break;
+    }
+    T.nphases = p.nphases;
+    nsplit = T.nsplit;
+    return T;
+  }
   long rows = (long)B * q.L;
   long tiles = (long)T.RT * T.NT * p.nphases;
   long want = std::max(1L, (wgrad_target_wgs() + tiles - 1) / tiles);
@@ -991,7 +1014,7 @@ static int launch_wgrad_ws_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, i
   auto kern = k_wgrad_gemm_ws<BR, BN>;
   RD_KNAME(h, "k_wgrad_gemm_ws<%d,%d>", BR, BN);
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
-  dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
+  dim3 grid((unsigned)(T.box ? T.nsplit : T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dp, B, src, dy, partial, T);
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -1004,13 +1027,18 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   LaunchScope ls(h, plan_index(h, hp), RD_KIND_WGRAD, B, plan_flops(hp, B), st);
   if (h) h->flops_acc += plan_flops(hp, B);
   if (hp.N % 64) return bad_arg(h, "wgrad: N % 64 != 0");
+  if (!hp.boxes)
   for (int i = 1; i < hp.nphases; ++i)
     if (hp.ph[i].ntaps != hp.ph[0].ntaps || hp.ph[i].L != hp.ph[0].L) return bad_arg(h, "wgrad: phases must be congruent");
   int BR, BN, nsplit;
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
-  size_t need = (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
+  size_t need = T.box ? (size_t)T.RT * BR * hp.N : (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
+  if (T.box && !(h && h->wave_spec && (hp.SC & 3) == 0 && !hp.s_shift && !dy16 && BR == 128 && BN == 128))
+    return bad_arg(h, "wgrad: border-class boxes only through k_wgrad_gemm_ws<128,128>");
   if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
-  if ((T.rows_per_split / hp.ph[0].L + 2) * std::max(hp.src_sample, hp.dst_sample) * 4 >= 0x7FFFFFF0L)
+  long minL = hp.ph[0].L;
+  for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
+  if (std::min<long>(B, T.rows_per_split / minL + 2) * std::max(hp.src_sample, hp.dst_sample) * 4 >= 0x7FFFFFF0L)
     return bad_arg(h, "wgrad: split span exceeds 2 GiB");
   const int np = hp.nphases;
   const bool partial = (hp.SC & 3) != 0, shift = hp.s_shift != 0;
@@ -1022,7 +1050,7 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   } while (0)
   float* partial_buf = partial_ws;
   const long wrows = (long)B * hp.ph[0].L;
-  const bool ws = h && h->wave_spec && !partial && !shift && !dy16 && (h->wave_spec == 2 || wrows * hp.nphases >= 1024);
+  const bool ws = h && h->wave_spec && !partial && !shift && !dy16 && (h->wave_spec == 2 || wrows * hp.nphases >= 1024 || T.box);
   if (dy16) {       // bf16 storage mode, first critic layer: fp32 gathered input against the bf16 output gradient
     if (shift || BR != 64 || BN != 64) return bad_arg(h, "wgrad: bf16 output gradient only with the 64x64 tile");
     if (partial) RD_TRY((launch_wgrad_cfg<64, 64, true, false, true>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
@@ -1040,6 +1068,12 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   else if (BN == 128) RD_WG(64, 128);
   else RD_WG(64, 64);
 #undef RD_WG
+  if (T.box) {      // per weight tap: the slabs of every phase that lists it
+    const long nout = 27L * hp.SC * (hp.N / 4);
+    hipLaunchKernelGGL(k_wgrad_reduce_box, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, dp, partial_ws, T, BR, B, 27, dW, hp.N);
+    RD_CHECK(h, hipGetLastError());
+    return 0;
+  }
   long total = (long)T.RT * BR * (hp.N / 4);
   int outs = 256;                       // output float4s per workgroup; the other 256/outs thread slices split the fold
   while (outs > 16 && (total + outs - 1) / outs * np < 512 && 256 / outs < nsplit) outs >>= 1;
@@ -1060,7 +1094,7 @@ static int launch_wgrad16_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, in
   auto kern = k_wgrad_gemm_ws16<BR, BN>;
   RD_KNAME(h, "k_wgrad_gemm_ws16<%d,%d>", BR, BN);
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
-  dim3 grid((unsigned)(T.RT * T.NT * nsplit * nphases));
+  dim3 grid((unsigned)(T.box ? T.nsplit : T.RT * T.NT * nsplit * nphases));
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, dp, B, (const unsigned short*)src16, (const unsigned short*)dy16, partial, T);
   RD_CHECK(h, hipGetLastError());
   return 0;
@@ -1077,18 +1111,28 @@ static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, i
   LaunchScope ls(h, plan_index(h, hp), RD_KIND_WGRAD, B, plan_flops(hp, B), st);
   if (h) h->flops_acc += plan_flops(hp, B);
   if (!wgrad16_ok(hp, B)) return bad_arg(h, "wgrad16: needs SC % 64 == 0, N % 64 == 0, a 128- or 256-row tile, no folded upsample");
+  if (!hp.boxes)
   for (int i = 1; i < hp.nphases; ++i)
     if (hp.ph[i].ntaps != hp.ph[0].ntaps || hp.ph[i].L != hp.ph[0].L) return bad_arg(h, "wgrad: phases must be congruent");
   int BR, BN, nsplit;
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
-  size_t need = (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
+  size_t need = T.box ? (size_t)T.RT * BR * hp.N : (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
+  if (T.box && !(BR == 128 && BN == 128)) return bad_arg(h, "wgrad16: border-class boxes only through the 128x128 tile");
   if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
-  if ((T.rows_per_split / hp.ph[0].L + 2) * std::max(hp.src_sample, hp.dst_sample) * 2 >= 0x7FFFFFF0L)
+  long minL16 = hp.ph[0].L;
+  for (int i = 1; i < hp.nphases; ++i) minL16 = std::min<long>(minL16, hp.ph[i].L);
+  if (std::min<long>(B, T.rows_per_split / minL16 + 2) * std::max(hp.src_sample, hp.dst_sample) * 2 >= 0x7FFFFFF0L)
     return bad_arg(h, "wgrad: split span exceeds 2 GiB");
   const int np = hp.nphases;
   if (BR == 256) RD_TRY((launch_wgrad16_cfg<256, 64>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
   else if (BN == 128) RD_TRY((launch_wgrad16_cfg<128, 128>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
   else RD_TRY((launch_wgrad16_cfg<128, 64>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
+  if (T.box) {      // per weight tap: the slabs of every phase that lists it
+    const long nout = 27L * hp.SC * (hp.N / 4);
+    hipLaunchKernelGGL(k_wgrad_reduce_box, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, dp, partial_ws, T, BR, B, 27, dW, hp.N);
+    RD_CHECK(h, hipGetLastError());
+    return 0;
+  }
   long total = (long)T.RT * BR * (hp.N / 4);
   int outs = 256;
   while (outs > 16 && (total + outs - 1) / outs * np < 512 && 256 / outs < nsplit) outs >>= 1;
@@ -1101,7 +1145,15 @@ static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, i
 static size_t wgrad_partial_need(const RdPlan& hp, int B) {
   int BR, BN, nsplit;
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
+  if (T.box) return (size_t)T.RT * BR * hp.N;
   return (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
+}
+// border-class boxes in a weight gradient: through k_wgrad_gemm_ws<128,128> only (critic layers 2-4: N a multiple of 128)
+static bool wgrad_box_ok(const RdPlan& hp) {
+  if (!hp.boxes || hp.s_shift || (hp.SC & 3) || hp.N % 128) return false;
+  int BR, BN, nsplit;
+  (void)wgrad_tiling(hp, 1, BR, BN, nsplit);
+  return BR == 128 && BN == 128;
 }
 
 // out[c] = sum over rows of src[rows][C]
@@ -1296,7 +1348,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B, PL_G1FC, PL_G2FC, PL_G3FC,
                       PL_F1WA, PL_F2WA, PL_F3WA, PL_F1WS, PL_F2WS, PL_F3WS, PL_F1WD, PL_F2WD, PL_F3WD};
     for (int id : wg) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)MB));
-    const int wd[] = {PL_D1F, PL_D2F, PL_D3F, PL_D4F};
+    const int wd[] = {PL_D1F, PL_D2F, PL_D3F, PL_D4F, PL_D2FX, PL_D3FX, PL_D4FX};
     for (int id : wd) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)NB));
     wneed = std::max(wneed, (size_t)MB * (RDGAN_NHOURS / 2) * 1728);      // k_g9_wgrad_pairs: [27][64] per (sample, plane pair)
     if (g9w_mfma_ok(nd, (long)MB * h->gpix[3]))                            // k_g9_wgrad_mfma: [27][64] per persistent workgroup
@@ -1462,6 +1514,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "g9_fused")) { h->g9_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_fwd_sample")) { h->d1_fwd_sample = value ? 1 : 0; return 0; }
   if (!strcmp(name, "g9_bwd_mfma")) { h->g9_bwd_mfma = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "wgrad_boxes")) { h->wgrad_boxes = value ? 1 : 0; return 0; }
   if (!strcmp(name, "border_boxes")) { h->border_boxes = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }    // 2 = at every size (tests)
   if (!strcmp(name, "d3_wgrad_slab")) { h->d3_wgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_wgrad_slab")) { h->d2_wgrad_slab = value ? 1 : 0; return 0; }
@@ -1640,6 +1693,14 @@ static int critic_box_plan(const rdgan_handle* h, int one, int box, long rows) {
 }
 static int critic_fwd_plan(const rdgan_handle* h, int l, int n) {
   return critic_box_plan(h, PL_D2F + l - 2, PL_D2FX + l - 2, (long)n * h->dL[l]);
+}
+// weight gradient of layer l >= 2 (streaming kernels): every box is its own set of partial slabs and short-K workgroups, so the
+// boxes must drop at least 30 % of the work to pay (ndomain 64, layer 3: 18 % dropped, 0.130 -> 0.142 ms)
+static int critic_wgrad_plan(const rdgan_handle* h, int l, int n) {
+  const int one = PL_D2F + l - 2, box = PL_D2FX + l - 2;
+  if (!h->wgrad_boxes || !wgrad_box_ok(h->plans[box])) return one;
+  if (h->border_boxes < 2 && plan_flops(h->plans[box], 1) > 0.7 * plan_flops(h->plans[one], 1)) return one;
+  return critic_fwd_plan(h, l, n);
 }
 // the same choice for the input gradient of layer l >= 2 (rows = the layer's input positions)
 static int critic_dgrad_plan(const rdgan_handle* h, int l, int n) {
@@ -2253,13 +2314,17 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
                          h->wpartial, NBt, G);
       hipLaunchKernelGGL(k_d3_wgrad_fold, dim3((27 * RD_D3W_TILE / 4 + 255) / 256), dim3(256), 0, st, h->wpartial, G, grad + h->doff[4]);
       RD_CHECK(h, hipGetLastError());
-    } else if (a16 && l >= 2) {      // layers 2-4: bf16 activations against bf16 output gradients
+    } else if (a16 && l >= 2) {      // layers 2-4: bf16 activations against bf16 output gradients (on the border-class boxes)
+      pl = critic_wgrad_plan(h, l, NBt);
       if (!wgrad16_ok(h->plans[pl], NBt)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this critic layer");
       RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], grad + h->doff[2 * (l - 1)], h->wpartial,
                             h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM));
-    } else
+    } else {
+    // fp32 storage, layers 2-4: the border-class boxes of the layer's forward plan (k_wgrad_gemm_ws<128,128> + k_wgrad_reduce_box)
+    if (l >= 2 && !a16 && h->wave_spec) pl = critic_wgrad_plan(h, l, NBt);
     RD_TRY(launch_wgrad(h, h->plans[pl], h->d_plans + pl, NBt, in, h->du[l], padded ? h->dW1P : grad + h->doff[2 * (l - 1)],
                         h->wpartial, h->wpartial_cap, st, RDGAN_TAG_CRITIC_GEMM, a16));
+    }
     if (padded) hipLaunchKernelGGL(k_unpad_w1, dim3(27), dim3(256), 0, st, h->dW1P, grad + h->doff[0], h->Cin, h->CP);
   }
   RD_TRY(side_join(h, st, h->ev_join));                 // the bias-gradient sums issued on the side stream above

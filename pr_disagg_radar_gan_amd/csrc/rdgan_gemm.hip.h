@@ -701,7 +701,37 @@ struct RdWgradTiling {
   int taps_per_tile;     // 1 or BR/cw
   int rows_per_split;    // multiple of 32
   int nsplit, nphases;   // grid = RT*NT * nsplit * nphases workgroups (1-D)
+  // border-class boxes (RdPlan::boxes): phases with their own tap and row counts that share ONE set of weights.  Phase p has
+  // rd_wgrad_phase_rt(T, phT[p]) row tiles and ceil(B * phL[p] / rows_per_split) splits (rows_per_split = 1 << rps_log2); its
+  // workgroups and partial slabs follow those of the phases in front of it; k_wgrad_reduce_box adds up, per WEIGHT tap, the
+  // slabs of every phase that lists the tap.
+  int box, rps_log2, tpt_log2;
 };
+
+__host__ __device__ __forceinline__ int rd_wgrad_phase_rt(const RdWgradTiling& T, int ntaps) {
+  return T.tiles_per_tap > 0 ? ntaps * T.tiles_per_tap : (ntaps + T.taps_per_tile - 1) >> T.tpt_log2;
+}
+// box plans: workgroup wg -> phase bz, split by, row tile rt, n tile; slab = index of the first partial slab of (bz, by)
+__device__ __forceinline__ void rd_wgrad_box_decode(const RdPlan* __restrict__ plan, const RdWgradTiling& T, int B, int wg,
+                                                    int& bz, int& by, int& rt, int& ntile, int& slab) {
+  int prefix = 0;
+  bz = 0; by = 0; rt = 0; ntile = 0; slab = 0;
+  const int np = plan->nphases;
+  for (int p = 0; p < np; ++p) {
+    const int rtp = rd_wgrad_phase_rt(T, plan->phT[p]);
+    const int nsp = (B * plan->phL[p] + (1 << T.rps_log2) - 1) >> T.rps_log2;
+    const int tiles = rtp * T.NT;
+    const int cnt = tiles * nsp;
+    if (wg < cnt) {
+      bz = p; by = wg / tiles;
+      const int bx = wg - by * tiles;
+      rt = bx / T.NT; ntile = bx - rt * T.NT;
+      slab = prefix + by * rtp;
+      return;
+    }
+    wg -= cnt; prefix += rtp * nsp;
+  }
+}
 
 __device__ __forceinline__ void rd_wgrad_tile_row(const RdWgradTiling& T, int BR, int rt, int r, int& tap, int& c) {
   if (T.tiles_per_tap > 0) {
@@ -939,4 +969,37 @@ k_wgrad_reduce(const RdPlan* __restrict__ plan, const float* __restrict__ partia
       for (int j = 1; j < ks; ++j) s += red[j * outs + o];
   }
   if (ok && sl == 0) *(f32x4*)(dW + P.w_off + ((long)P.tap[tap].w * plan->w_rows_per_tap + c) * ldw + n) = s;
+}
+
+// The fold for border-class boxes: one thread per (weight tap w, channel c, four columns) adds, phase by phase and split by split
+// in a fixed order, the partial slabs of every phase that lists tap w; a tap no phase lists (it never lands inside the picture)
+// gets its exact zero.  nw = number of weight taps (27).
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce_box(const RdPlan* __restrict__ plan, const float* __restrict__ partial, RdWgradTiling T, int BR, int B, int nw,
+                   float* __restrict__ dW, int ldw) {
+  const int N = plan->N, n4s = N / 4, SC = plan->SC;
+  const long f = (long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= (long)nw * SC * n4s) return;
+  const int n = (int)(f % n4s) * 4;
+  const int c = (int)((f / n4s) % SC), w = (int)(f / ((long)n4s * SC));
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  int prefix = 0;
+  const int np = plan->nphases;
+  for (int p = 0; p < np; ++p) {
+    const int rtp = rd_wgrad_phase_rt(T, plan->phT[p]);
+    const int nsp = (B * plan->phL[p] + (1 << T.rps_log2) - 1) >> T.rps_log2;
+    const int k = plan->tapinv[p][w];
+    if (k >= 0) {
+      int rt, r;
+      if (T.tiles_per_tap > 0) { const int ct = c / BR; rt = k * T.tiles_per_tap + ct; r = c - ct * BR; }
+      else { rt = k >> T.tpt_log2; r = (k & (T.taps_per_tile - 1)) * T.cw + c; }
+      const float* q = partial + ((long)(prefix + rt) * BR + r) * N + n;
+      const long st = (long)rtp * BR * N;
+      int by = 0;
+      for (; by + 1 < nsp; by += 2) { s0 += *(const f32x4*)(q + by * st); s1 += *(const f32x4*)(q + (by + 1) * st); }
+      if (by < nsp) s0 += *(const f32x4*)(q + by * st);
+    }
+    prefix += rtp * nsp;
+  }
+  *(f32x4*)(dW + ((long)w * plan->w_rows_per_tap + c) * ldw + n) = s0 + s1;
 }

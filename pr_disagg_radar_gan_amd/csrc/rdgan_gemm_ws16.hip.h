@@ -45,12 +45,19 @@ k_wgrad_gemm_ws16(const RdPlan* __restrict__ plan, int B, const unsigned short* 
   const bool is_compute = wave < 4;
   const int l31 = lane & 31, lhalf = lane >> 5;
   const int swz = rd_xcd_swizzle(blockIdx.x, gridDim.x);
-  const int tiles = T.RT * T.NT;
-  const int bx = swz % tiles, by = (swz / tiles) % T.nsplit, bz = swz / (tiles * T.nsplit);
+  int by, bz, rt, ntile, slab;
+  if (T.box) {          // border-class boxes: every phase has its own tile and split counts (k_wgrad_gemm_ws)
+    rd_wgrad_box_decode(plan, T, B, swz, bz, by, rt, ntile, slab);
+  } else {
+    const int tiles = T.RT * T.NT;
+    const int bx = swz % tiles;
+    by = (swz / tiles) % T.nsplit; bz = swz / (tiles * T.nsplit);
+    rt = bx / T.NT; ntile = bx - rt * T.NT;
+    slab = (bz * T.nsplit + by) * T.RT;
+  }
   const RdPhase& P = plan->ph[bz];
   const int L = P.L;
   const int rows = B * L;
-  const int rt = bx / T.NT, ntile = bx - rt * T.NT;
   const int n0 = ntile * BN;
   const int mbeg = by * T.rows_per_split;
   const int mend = min(rows, mbeg + T.rows_per_split);
@@ -203,7 +210,7 @@ k_wgrad_gemm_ws16(const RdPlan* __restrict__ plan, int B, const unsigned short* 
       }
   }
   __syncthreads();
-  float* out = partial + (((long)bz * T.nsplit + by) * T.RT + rt) * BR * N;
+  float* out = partial + ((long)slab + rt) * BR * N;
   constexpr int F4R = BN / 4, RPP = 512 / F4R;
   const int c4 = (tid % F4R) * 4;
   for (int row = tid / F4R; row < BR; row += RPP)

@@ -52,6 +52,8 @@ struct RdPlan {
   long src_sample, dst_sample; // floats per sample of the source / destination tensor
   const RdRow* tab;            // device pointer to the row tables of all phases
   int phL[RD_MAX_PHASES];      // ph[i].L again, contiguous: a workgroup of a plan with unequal phases finds its phase by walking these
+  int phT[RD_MAX_PHASES];      // ph[i].ntaps, the same way (weight gradients over border-class boxes)
+  signed char tapinv[RD_MAX_PHASES][32];   // [phase][weight tap w < 32] -> index of that tap in the phase's list, -1 = not listed
   RdPhase ph[RD_MAX_PHASES];
 };
 
