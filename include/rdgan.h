@@ -155,6 +155,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * (kh, kw) and the hour taps inside the work item; k_tapsum_softmax12 adds the source parity classes and the neighbouring items and
  * takes the softmax.  No pass over block 3's output (k_g9_fwd); a critic step does not store that output at all.  Same bf16 products
  * as 0, another fp32 summation order: fractions agree to ~3e-7 of the largest.
+ * "wgrad_boxes" (default 1; with "border_boxes"): the weight gradients of critic layers 2-4 that run in the streaming kernels (fp32
+ * storage: all three; bf16 storage: the layers without a slab kernel) use the border-class boxes too: per-phase tile and split
+ * counts, one fold per weight tap over every phase that lists it (k_wgrad_reduce_box).  Same products, same results to ~1e-9.
  * "d1_fwd_sample" (default 1; bf16 storage mode, ndomain 16, one condition channel): forward and second sweep of the critic's first
  * layer with a sample's input volume resident in LDS (k_d1_fwd_sample16); the second sweep then takes its gate from the 2-bit codes
  * ("d2_gate_bits"; without them it keeps the tile kernel).  One bf16 ulp from 0 in ~4e-5 of the activations.

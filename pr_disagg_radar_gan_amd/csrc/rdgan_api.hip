@@ -138,6 +138,9 @@ static RdPlan plan_boxes(const RdPlan& src) {
   RdPlan p = src;
   p.nphases = (int)boxes.size();
   p.boxes = 1;
+  p.wmask = 0;
+  for (int pi = 0; pi < src.nphases; ++pi)
+    for (int t = 0; t < src.ph[pi].ntaps; ++t) if (src.ph[pi].tap[t].w >= 0 && src.ph[pi].tap[t].w < 64) p.wmask |= 1ull << src.ph[pi].tap[t].w;
   for (int i = 0; i < p.nphases; ++i) {
     const Box& b = boxes[i];
     const RdPhase& par = src.ph[b.parent];
@@ -407,8 +410,8 @@ static bool plan_build_tables(RdPlan& p, std::vector<RdRow>& out) {
     q.tab = first;
     p.phL[pi] = q.L;
     p.phT[pi] = q.ntaps;
-    for (int w = 0; w < 32; ++w) p.tapinv[pi][w] = -1;
-    for (int t = 0; t < q.ntaps; ++t) if (q.tap[t].w >= 0 && q.tap[t].w < 32) p.tapinv[pi][q.tap[t].w] = (signed char)t;
+    for (int w = 0; w < 64; ++w) p.tapinv[pi][w] = -1;
+    for (int t = 0; t < q.ntaps; ++t) if (q.tap[t].w >= 0 && q.tap[t].w < 64) p.tapinv[pi][q.tap[t].w] = (signed char)t;
     for (int t = 0; t < q.ntaps; ++t) {
       int mask = 0;
       for (int a = 0; a < 3; ++a) {
@@ -462,6 +465,7 @@ enum {
   PL_F1BS, PL_F2BS, PL_F3BS, PL_F1BE, PL_F2BE, PL_F3BE, PL_F1FE, PL_F2FE, PL_F3FE,
   PL_D2FX, PL_D3FX, PL_D4FX,          // critic layers 2-4 forward, output grid cut into border-class boxes (plan_boxes)
   PL_D2BX, PL_D3BX, PL_D4BX,          // their input gradients, every parity phase cut the same way
+  PL_F1WAX, PL_F2WAX, PL_F3WAX, PL_F1WSX, PL_F2WSX, PL_F3WSX, PL_F1WDX, PL_F2WDX, PL_F3WDX,   // shared-centre weight gradients on boxes
   PL_COUNT
 };
 
@@ -1033,8 +1037,8 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   int BR, BN, nsplit;
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
   size_t need = T.box ? (size_t)T.RT * BR * hp.N : (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
-  if (T.box && !(h && h->wave_spec && (hp.SC & 3) == 0 && !hp.s_shift && !dy16 && BR == 128 && BN == 128))
-    return bad_arg(h, "wgrad: border-class boxes only through k_wgrad_gemm_ws<128,128>");
+  if (T.box && !(h && h->wave_spec && (hp.SC & 3) == 0 && !hp.s_shift && !dy16))
+    return bad_arg(h, "wgrad: border-class boxes only through k_wgrad_gemm_ws");
   if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
   long minL = hp.ph[0].L;
   for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
@@ -1069,8 +1073,9 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   else RD_WG(64, 64);
 #undef RD_WG
   if (T.box) {      // per weight tap: the slabs of every phase that lists it
-    const long nout = 27L * hp.SC * (hp.N / 4);
-    hipLaunchKernelGGL(k_wgrad_reduce_box, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, dp, partial_ws, T, BR, B, 27, dW, hp.N);
+    const int nw = 64 - __builtin_clzll(hp.wmask | 1ull);
+    const long nout = (long)nw * hp.SC * (hp.N / 4);
+    hipLaunchKernelGGL(k_wgrad_reduce_box, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, dp, partial_ws, T, BR, B, nw, dW, hp.N);
     RD_CHECK(h, hipGetLastError());
     return 0;
   }
@@ -1117,7 +1122,6 @@ static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, i
   int BR, BN, nsplit;
   RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
   size_t need = T.box ? (size_t)T.RT * BR * hp.N : (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
-  if (T.box && !(BR == 128 && BN == 128)) return bad_arg(h, "wgrad16: border-class boxes only through the 128x128 tile");
   if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
   long minL16 = hp.ph[0].L;
   for (int i = 1; i < hp.nphases; ++i) minL16 = std::min<long>(minL16, hp.ph[i].L);
@@ -1128,8 +1132,9 @@ static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, i
   else if (BN == 128) RD_TRY((launch_wgrad16_cfg<128, 128>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
   else RD_TRY((launch_wgrad16_cfg<128, 64>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
   if (T.box) {      // per weight tap: the slabs of every phase that lists it
-    const long nout = 27L * hp.SC * (hp.N / 4);
-    hipLaunchKernelGGL(k_wgrad_reduce_box, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, dp, partial_ws, T, BR, B, 27, dW, hp.N);
+    const int nw = 64 - __builtin_clzll(hp.wmask | 1ull);
+    const long nout = (long)nw * hp.SC * (hp.N / 4);
+    hipLaunchKernelGGL(k_wgrad_reduce_box, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, dp, partial_ws, T, BR, B, nw, dW, hp.N);
     RD_CHECK(h, hipGetLastError());
     return 0;
   }
@@ -1148,12 +1153,11 @@ static size_t wgrad_partial_need(const RdPlan& hp, int B) {
   if (T.box) return (size_t)T.RT * BR * hp.N;
   return (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
 }
-// border-class boxes in a weight gradient: through k_wgrad_gemm_ws<128,128> only (critic layers 2-4: N a multiple of 128)
+// border-class boxes in a weight gradient: the producer/consumer kernels (k_wgrad_gemm_ws / ws16), clean plans
 static bool wgrad_box_ok(const RdPlan& hp) {
-  if (!hp.boxes || hp.s_shift || (hp.SC & 3) || hp.N % 128) return false;
-  int BR, BN, nsplit;
-  (void)wgrad_tiling(hp, 1, BR, BN, nsplit);
-  return BR == 128 && BN == 128;
+  if (!hp.boxes || hp.s_shift || (hp.SC & 3) || hp.N % 64) return false;
+  for (int i = 1; i < hp.nphases; ++i) if (hp.ph[i].w_off != hp.ph[0].w_off) return false;     // one weight block, taps told apart by tap.w
+  return true;
 }
 
 // out[c] = sum over rows of src[rows][C]
@@ -1305,8 +1309,10 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->plans[PL_G1B + l - 1] = plan_conv_dgrad_s1(od[0], od[1], od[2], gch[l - 1], gch[l]);
     h->plans[PL_G1FC + l - 1] = plan_upconv_fwd_collapsed(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
     h->plans[PL_G1BC + l - 1] = plan_upconv_dgrad_collapsed(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 3; ++g) {
       h->plans[PL_F1WA + 3 * g + l - 1] = plan_fastd_wgrad(sd[0], sd[1], sd[2], gch[l - 1], gch[l], g);
+      h->plans[PL_F1WAX + 3 * g + l - 1] = plan_boxes(h->plans[PL_F1WA + 3 * g + l - 1]);
+    }
     h->plans[PL_F1BS + l - 1] = plan_fastd_dgrad_s(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
     h->plans[PL_F1BE + l - 1] = plan_fastd_dgrad_e(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
     h->plans[PL_F1FE + l - 1] = plan_fastd_fwd_e(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
@@ -1346,7 +1352,8 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
   size_t wneed = 0;
   {
     const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B, PL_G1FC, PL_G2FC, PL_G3FC,
-                      PL_F1WA, PL_F2WA, PL_F3WA, PL_F1WS, PL_F2WS, PL_F3WS, PL_F1WD, PL_F2WD, PL_F3WD};
+                      PL_F1WA, PL_F2WA, PL_F3WA, PL_F1WS, PL_F2WS, PL_F3WS, PL_F1WD, PL_F2WD, PL_F3WD,
+                      PL_F1WAX, PL_F2WAX, PL_F3WAX, PL_F1WSX, PL_F2WSX, PL_F3WSX, PL_F1WDX, PL_F2WDX, PL_F3WDX};
     for (int id : wg) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)MB));
     const int wd[] = {PL_D1F, PL_D2F, PL_D3F, PL_D4F, PL_D2FX, PL_D3FX, PL_D4FX};
     for (int id : wd) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)NB));
@@ -1581,7 +1588,10 @@ static const char* const RD_PLAN_NAMES[PL_COUNT] = {
   "gen block1 dgrad difference part", "gen block2 dgrad difference part", "gen block3 dgrad difference part",
   "gen block1 fwd difference part", "gen block2 fwd difference part", "gen block3 fwd difference part",
   "critic layer2 (border boxes)", "critic layer3 (border boxes)", "critic layer4 (border boxes)",
-  "critic layer2 dgrad (border boxes)", "critic layer3 dgrad (border boxes)", "critic layer4 dgrad (border boxes)"};
+  "critic layer2 dgrad (border boxes)", "critic layer3 dgrad (border boxes)", "critic layer4 dgrad (border boxes)",
+  "gen block1 shared-centre E[s] (boxes)", "gen block2 shared-centre E[s] (boxes)", "gen block3 shared-centre E[s] (boxes)",
+  "gen block1 shared-centre S (boxes)", "gen block2 shared-centre S (boxes)", "gen block3 shared-centre S (boxes)",
+  "gen block1 shared-centre E[s+1] (boxes)", "gen block2 shared-centre E[s+1] (boxes)", "gen block3 shared-centre E[s+1] (boxes)"};
 
 extern "C" int rdgan_profile_launches(rdgan_handle* h, int on) {
   if (!h) return -2;
@@ -2508,7 +2518,13 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       const float* wsrc[3] = {h->fE[l], hs[l - 1], h->fE[l]};
       const float* wdy[3] = {dys[l], h->fgS, dys[l]};
       for (int g = 0; g < 3; ++g) {
-        const int pl = PL_F1WA + 3 * g + l - 1;
+        int pl = PL_F1WA + 3 * g + l - 1;
+        // fp32 storage: the (h, w) border boxes of the block (12 % of its row-tap products are products with a zero row)
+        // -- where they drop at least a fifth of the work (block 2: 23 %, 0.237 -> 0.219 ms per launch; block 3's 12 % do not pay
+        // for the extra partial slabs and short row tiles of its 256 x 64 tiling: 0.43 -> 0.51 ms, measured)
+        if (!a16 && h->wgrad_boxes && h->border_boxes && h->wave_spec && wgrad_box_ok(h->plans[PL_F1WAX + 3 * g + l - 1]) &&
+            (h->border_boxes >= 2 || plan_flops(h->plans[PL_F1WAX + 3 * g + l - 1], 1) < 0.8 * plan_flops(h->plans[pl], 1)))
+          pl = PL_F1WAX + 3 * g + l - 1;
         if (a16) {
           if (!wgrad16_ok(h->plans[pl], B)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this block");
           RD_TRY(launch_wgrad16(h, h->plans[pl], h->d_plans + pl, B, wsrc[g], wdy[g], h->fdU, h->wpartial, h->wpartial_cap, st,

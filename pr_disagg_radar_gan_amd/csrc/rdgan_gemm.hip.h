@@ -973,7 +973,7 @@ k_wgrad_reduce(const RdPlan* __restrict__ plan, const float* __restrict__ partia
 
 // The fold for border-class boxes: one thread per (weight tap w, channel c, four columns) adds, phase by phase and split by split
 // in a fixed order, the partial slabs of every phase that lists tap w; a tap no phase lists (it never lands inside the picture)
-// gets its exact zero.  nw = number of weight taps (27).
+// gets its exact zero.  nw = weight taps to look at (at most 64); RdPlan::wmask says which of them this plan owns.
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce_box(const RdPlan* __restrict__ plan, const float* __restrict__ partial, RdWgradTiling T, int BR, int B, int nw,
                    float* __restrict__ dW, int ldw) {
@@ -982,6 +982,7 @@ k_wgrad_reduce_box(const RdPlan* __restrict__ plan, const float* __restrict__ pa
   if (f >= (long)nw * SC * n4s) return;
   const int n = (int)(f % n4s) * 4;
   const int c = (int)((f / n4s) % SC), w = (int)(f / ((long)n4s * SC));
+  if (!((plan->wmask >> w) & 1ull)) return;          // not a tap of this plan (another launch owns that row block of dW)
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   int prefix = 0;
   const int np = plan->nphases;
@@ -1001,5 +1002,5 @@ k_wgrad_reduce_box(const RdPlan* __restrict__ plan, const float* __restrict__ pa
     }
     prefix += rtp * nsp;
   }
-  *(f32x4*)(dW + ((long)w * plan->w_rows_per_tap + c) * ldw + n) = s0 + s1;
+  *(f32x4*)(dW + plan->ph[0].w_off + ((long)w * plan->w_rows_per_tap + c) * ldw + n) = s0 + s1;
 }

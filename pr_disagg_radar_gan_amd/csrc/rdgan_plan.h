@@ -53,7 +53,8 @@ struct RdPlan {
   const RdRow* tab;            // device pointer to the row tables of all phases
   int phL[RD_MAX_PHASES];      // ph[i].L again, contiguous: a workgroup of a plan with unequal phases finds its phase by walking these
   int phT[RD_MAX_PHASES];      // ph[i].ntaps, the same way (weight gradients over border-class boxes)
-  signed char tapinv[RD_MAX_PHASES][32];   // [phase][weight tap w < 32] -> index of that tap in the phase's list, -1 = not listed
+  signed char tapinv[RD_MAX_PHASES][64];   // [phase][weight tap w < 64] -> index of that tap in the phase's list, -1 = not listed
+  unsigned long long wmask;    // boxes: the weight taps the PARENT plan listed (bit w): the fold writes exactly these
   RdPhase ph[RD_MAX_PHASES];
 };
 
