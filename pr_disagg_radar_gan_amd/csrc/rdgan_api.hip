@@ -466,6 +466,7 @@ enum {
   PL_D2FX, PL_D3FX, PL_D4FX,          // critic layers 2-4 forward, output grid cut into border-class boxes (plan_boxes)
   PL_D2BX, PL_D3BX, PL_D4BX,          // their input gradients, every parity phase cut the same way
   PL_F1WAX, PL_F2WAX, PL_F3WAX, PL_F1WSX, PL_F2WSX, PL_F3WSX, PL_F1WDX, PL_F2WDX, PL_F3WDX,   // shared-centre weight gradients on boxes
+  PL_G1FCX, PL_G2FCX, PL_G3FCX, PL_G1BCX, PL_G2BCX, PL_G3BCX,     // collapsed generator blocks, forward / input gradient, on boxes
   PL_COUNT
 };
 
@@ -704,8 +705,8 @@ static int launch_conv_cfg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   {  // a tile's buffer descriptor is based at its first sample: its span must stay below 2 GiB
     long minL = hp.ph[0].L;
     for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
-    if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
-    if ((BM / minL + 2) * hp.dst_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: destination tile span exceeds 2 GiB");
+    if (std::min<long>(B, BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
+    if (std::min<long>(B, BM / minL + 2) * hp.dst_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: destination tile span exceeds 2 GiB");
   }
   const long blocks = tm * (hp.N / BN);
   // split-K for small-M / large-K layers (critic tail, Dense, first generator block): few workgroups, long K loops
@@ -785,8 +786,8 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
   if (tm <= 0) return 0;
   long minL = hp.ph[0].L;
   for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
-  if ((BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
-  if ((BM / minL + 2) * hp.dst_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: destination tile span exceeds 2 GiB");
+  if (std::min<long>(B, BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
+  if (std::min<long>(B, BM / minL + 2) * hp.dst_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: destination tile span exceeds 2 GiB");
   RdEpi e2 = epi;
   e2.ksplit = 1; e2.kpart = nullptr; e2.kstride = 0;
   const long blocks = tm * (hp.N / BN);
@@ -1309,6 +1310,8 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
     h->plans[PL_G1B + l - 1] = plan_conv_dgrad_s1(od[0], od[1], od[2], gch[l - 1], gch[l]);
     h->plans[PL_G1FC + l - 1] = plan_upconv_fwd_collapsed(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
     h->plans[PL_G1BC + l - 1] = plan_upconv_dgrad_collapsed(sd[0], sd[1], sd[2], gch[l - 1], gch[l]);
+    h->plans[PL_G1FCX + l - 1] = plan_boxes(h->plans[PL_G1FC + l - 1]);
+    h->plans[PL_G1BCX + l - 1] = plan_boxes(h->plans[PL_G1BC + l - 1]);
     for (int g = 0; g < 3; ++g) {
       h->plans[PL_F1WA + 3 * g + l - 1] = plan_fastd_wgrad(sd[0], sd[1], sd[2], gch[l - 1], gch[l], g);
       h->plans[PL_F1WAX + 3 * g + l - 1] = plan_boxes(h->plans[PL_F1WA + 3 * g + l - 1]);
@@ -1351,7 +1354,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
   const long MB = h->MB, NB = h->NB;
   size_t wneed = 0;
   {
-    const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B, PL_G1FC, PL_G2FC, PL_G3FC,
+    const int wg[] = {PL_GDENSE, PL_G1F, PL_G2F, PL_G3F, PL_G9B, PL_G1FC, PL_G2FC, PL_G3FC, PL_G1FCX, PL_G2FCX, PL_G3FCX,
                       PL_F1WA, PL_F2WA, PL_F3WA, PL_F1WS, PL_F2WS, PL_F3WS, PL_F1WD, PL_F2WD, PL_F3WD,
                       PL_F1WAX, PL_F2WAX, PL_F3WAX, PL_F1WSX, PL_F2WSX, PL_F3WSX, PL_F1WDX, PL_F2WDX, PL_F3WDX};
     for (int id : wg) wneed = std::max(wneed, wgrad_partial_need(h->plans[id], (int)MB));
@@ -1591,7 +1594,9 @@ static const char* const RD_PLAN_NAMES[PL_COUNT] = {
   "critic layer2 dgrad (border boxes)", "critic layer3 dgrad (border boxes)", "critic layer4 dgrad (border boxes)",
   "gen block1 shared-centre E[s] (boxes)", "gen block2 shared-centre E[s] (boxes)", "gen block3 shared-centre E[s] (boxes)",
   "gen block1 shared-centre S (boxes)", "gen block2 shared-centre S (boxes)", "gen block3 shared-centre S (boxes)",
-  "gen block1 shared-centre E[s+1] (boxes)", "gen block2 shared-centre E[s+1] (boxes)", "gen block3 shared-centre E[s+1] (boxes)"};
+  "gen block1 shared-centre E[s+1] (boxes)", "gen block2 shared-centre E[s+1] (boxes)", "gen block3 shared-centre E[s+1] (boxes)",
+  "gen block1 (collapsed, boxes)", "gen block2 (collapsed, boxes)", "gen block3 (collapsed, boxes)",
+  "gen block1 dgrad (collapsed, boxes)", "gen block2 dgrad (collapsed, boxes)", "gen block3 dgrad (collapsed, boxes)"};
 
 extern "C" int rdgan_profile_launches(rdgan_handle* h, int on) {
   if (!h) return -2;
@@ -1698,6 +1703,7 @@ static bool upconv2_slab_on(const rdgan_handle* h, int l) {
 // launch keeps the one-phase plan unless the boxes drop more than half of the work (layer 4: 70 %)
 static int critic_box_plan(const rdgan_handle* h, int one, int box, long rows) {
   if (!h->border_boxes || !h->plans[box].boxes) return one;
+  if (std::max(h->plans[box].src_sample, h->plans[box].dst_sample) * 4 * 258 >= 0x7FFFFFF0L) return one;      // (32-bit offsets of a tile)
   if (h->border_boxes >= 2 || rows >= 8192 || 2.0 * plan_flops(h->plans[box], 1) <= plan_flops(h->plans[one], 1)) return box;
   return one;
 }
@@ -1715,6 +1721,21 @@ static int critic_wgrad_plan(const rdgan_handle* h, int l, int n) {
 // the same choice for the input gradient of layer l >= 2 (rows = the layer's input positions)
 static int critic_dgrad_plan(const rdgan_handle* h, int l, int n) {
   return critic_box_plan(h, PL_D2B + l - 2, PL_D2BX + l - 2, (long)n * h->dL[l - 1]);
+}
+
+// collapsed generator block (forward or input gradient): the border-class boxes where the launch runs several rounds of workgroups
+// -- in a single round the interior box's workgroups, which keep every tap, set the time -- and the boxes drop 30 % of the work
+// (block 1, 3 x 2 x 2 source grid: 47 % of its row-tap products are products with a zero row; blocks 2 / 3: 30 % / 16 %)
+static bool box_span_ok(const RdPlan& p, int B) {      // a tile of the smallest box must stay inside the kernels' 32-bit offsets
+  long minL = p.ph[0].L;
+  for (int i = 1; i < p.nphases; ++i) minL = std::min<long>(minL, p.ph[i].L);
+  return std::min<long>(B, 256 / minL + 2) * std::max(p.src_sample, p.dst_sample) * 4 < 0x7FFFFFF0L;
+}
+static int gen_box_plan(const rdgan_handle* h, int one, int box, int B) {
+  if (!h->border_boxes || !h->plans[box].boxes || !box_span_ok(h->plans[box], B)) return one;
+  if (h->border_boxes >= 2) return box;
+  if (plan_flops(h->plans[box], 1) > 0.7 * plan_flops(h->plans[one], 1)) return one;
+  return plan_tiles(h->plans[one], B, 128) * (h->plans[one].N / 128 > 0 ? h->plans[one].N / 128 : 1) >= 1024 ? box : one;
 }
 
 static bool g9_fused_on(const rdgan_handle* h) { return h->g9_fused && h->tapgather && upconv_slab_on(h, 3); }
@@ -1811,6 +1832,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     if (h->collapse) {
       Wl = h->GWC[l];
       pl = PL_G1FC + l - 1;
+      if (!upconv_slab_on(h, l) && !upconv2_slab_on(h, l)) pl = gen_box_plan(h, pl, PL_G1FCX + l - 1, B);
     }
     const bool fuse = a16 ? conv16_rows_owned(h->plans[pl]) : conv_rows_owned(h->plans[pl], B);       // PixelNorm+LeakyReLU in the GEMM epilogue
     RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
@@ -2569,7 +2591,11 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
         else hipLaunchKernelGGL(k_combine_dx<float>, cg, dim3(256), 0, st, gups[l], (const float*)h->fdE, B, D, P);
       }
     } else if (col) {
-      int plf = PL_G1FC + l - 1, plb = PL_G1BC + l - 1;
+      int plf = PL_G1FC + l - 1, plb = gen_box_plan(h, PL_G1BC + l - 1, PL_G1BCX + l - 1, B);
+      // weight gradient through the streaming kernels: on the boxes where they drop a fifth of the work (as the shared-centre ones)
+      const int plfx = PL_G1FCX + l - 1;
+      const bool wbox = h->wgrad_boxes && h->border_boxes && h->wave_spec && wgrad_box_ok(h->plans[plfx]) &&
+                        (h->border_boxes >= 2 || plan_flops(h->plans[plfx], 1) < 0.8 * plan_flops(h->plans[plf], 1));
       bool bias_done = false;         // (the slab kernel delivers the bias gradient too)
       if (a16 && l == 3 && h->upwgrad_slab && h->nd == 16) {
         // each workgroup owns one phase and keeps its eight tap products in registers over its share of the batch
@@ -2602,12 +2628,15 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
         bias_done = true;
         RD_CHECK(h, hipGetLastError());
       } else if (a16) {
+        if (wbox && wgrad16_ok(h->plans[plfx], B)) plf = plfx;
         if (!wgrad16_ok(h->plans[plf], B)) return bad_arg(h, "bf16 storage mode: no bf16 weight-gradient tile for this block");
         RD_TRY(launch_wgrad16(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap, st,
                               RDGAN_TAG_GCONV_WGRAD));
-      } else
+      } else {
+      if (wbox) plf = plfx;
       RD_TRY(launch_wgrad(h, h->plans[plf], h->d_plans + plf, B, hs[l - 1], dys[l], h->dWc, h->wpartial, h->wpartial_cap,
                           st, RDGAN_TAG_GCONV_WGRAD));
+      }
       hipLaunchKernelGGL(k_fold_collapsed_wgrad, dim3(ew_blocks(27L * cc / 4)), dim3(256), 0, st, h->dWc,
                          grad + h->goff[2 * l], (int)cc);
       if (!bias_done)
