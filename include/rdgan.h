@@ -161,6 +161,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "d1_fwd_sample" (default 1; bf16 storage mode, ndomain 16, one condition channel): forward and second sweep of the critic's first
  * layer with a sample's input volume resident in LDS (k_d1_fwd_sample16); the second sweep then takes its gate from the 2-bit codes
  * ("d2_gate_bits"; without them it keeps the tile kernel).  One bf16 ulp from 0 in ~4e-5 of the activations.
+ * "dense16" (default 1; bf16 storage mode): the generator's Dense layer on the bf16 matrix pipe: input rows and kernel rounded to
+ * bf16, K padded to a multiple of 64, three launches of a third of the columns each (the streaming kernel wants N / 128 to be a power
+ * of two).  0 = the fp32-pipe kernel with bf16 output.
  * "g9_bwd_mfma" (default 1; bf16 storage mode, collapsed backward): the input gradient of the generator's last conv + block 3's
  * PixelNorm backward on the fp32 matrix pipe (k_g9_bwd_mfma16: exact fp32 products); 0 = the VALU kernel k_g9_bwd_pairs.
  * "border_boxes" (default 1; 2 = at every size, 0 = off): the forward, second-sweep and input-gradient GEMMs of critic layers 2-4

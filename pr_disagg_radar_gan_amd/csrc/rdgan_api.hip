@@ -467,6 +467,7 @@ enum {
   PL_D2BX, PL_D3BX, PL_D4BX,          // their input gradients, every parity phase cut the same way
   PL_F1WAX, PL_F2WAX, PL_F3WAX, PL_F1WSX, PL_F2WSX, PL_F3WSX, PL_F1WDX, PL_F2WDX, PL_F3WDX,   // shared-centre weight gradients on boxes
   PL_G1FCX, PL_G2FCX, PL_G3FCX, PL_G1BCX, PL_G2BCX, PL_G3BCX,     // collapsed generator blocks, forward / input gradient, on boxes
+  PL_GDENSE16,                        // the Dense layer with its K padded to the bf16 GEMM's chunk of 64
   PL_COUNT
 };
 
@@ -528,6 +529,11 @@ struct rdgan_handle {
   void* bW2F = nullptr;           // weight image of the slab kernel of critic layer 2's forward (rdgan_d2fwd16.hip.h): 448 KB
   int d2_fwd_slab = 0;            // 1: bf16 storage mode, ndomain 16: forward of critic layer 2 by k_d2_fwd_slab16 (measured: no faster than the streaming GEMM, default off)
   unsigned char* g1bits = nullptr; // layer 1's gate in 2 bits per element (written by k_d1_gemm_fwd, read by k_d2_dgrad_slab16): 16 B per row
+  int dense16 = 1;                // 1: bf16 storage mode: the generator's Dense layer on the bf16 matrix pipe (inputs and kernel rounded to bf16, K padded to 64)
+  int KP0 = 0;                    // its padded K
+  bool dense16_ok = false;
+  void* xcat16 = nullptr;         // [MB][KP0] bf16
+  void* bW0 = nullptr;            // [n_nodes][KP0] bf16
   int g9_bwd_mfma = 1;            // 1: bf16 storage mode: input gradient of the last conv + block 3's PixelNorm backward on the fp32 matrix pipe (k_g9_bwd_mfma16)
   int d1_fwd_sample = 1;          // 1: bf16 storage mode, ndomain 16: layer-1 forward / second sweep with a sample resident in LDS (k_d1_fwd_sample16)
   int wgrad_boxes = 1;            // 1: the weight gradients of critic layers 2-4 (streaming kernels) on the border-class boxes too
@@ -1304,6 +1310,14 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
   // plans
   h->plans.resize(PL_COUNT);
   h->plans[PL_GDENSE] = plan_rows(1, 1, 1, h->n_in, h->n_in, h->n_nodes, h->n_nodes);
+  h->KP0 = (h->n_in + 63) / 64 * 64;
+  // (the producer/consumer kernel wants N / 128 to be a power of two; n_nodes = 3 * 2^k * 256 for ndomain 8 / 16 / 32 / 64 / 128:
+  // three launches of a third of the columns each, destination rows n_nodes apart)
+  h->plans[PL_GDENSE16] = plan_rows(1, 1, 1, h->KP0, h->KP0, h->n_nodes / 3, h->n_nodes);
+  {
+    const int n3 = h->n_nodes / 3;
+    h->dense16_ok = h->n_nodes % 3 == 0 && n3 % 128 == 0 && ((n3 / 128) & (n3 / 128 - 1)) == 0;
+  }
   for (int l = 1; l <= 3; ++l) {
     const int* sd = h->gdim[l - 1]; const int* od = h->gdim[l];
     h->plans[PL_G1F + l - 1] = plan_conv_fwd(sd[0], sd[1], sd[2], gch[l - 1], gch[l], od[0], od[1], od[2], 1, 1, 1, 1, 1);
@@ -1437,6 +1451,8 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         h->bU[0] = nullptr;
         for (int l = 1; l <= 3; ++l) { carve(p, 24L * gch[l - 1] * gch[l] + 8); h->bU[l] = p; }
         carve(p, 24L * 256 * 256 + 8); h->bUT = p;
+        carve(p, (long)MB * h->KP0 / 2 + 8); h->xcat16 = p;
+        carve(p, (long)h->n_nodes * h->KP0 / 2 + 8); h->bW0 = p;
         h->bWF[0] = h->bWF[1] = h->bWB[0] = h->bWB[1] = nullptr;
         for (int l = 2; l <= 4; ++l) {
           carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->bWF[l] = p;
@@ -1524,6 +1540,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "g9_fused")) { h->g9_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_fwd_sample")) { h->d1_fwd_sample = value ? 1 : 0; return 0; }
   if (!strcmp(name, "g9_bwd_mfma")) { h->g9_bwd_mfma = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "dense16")) { h->dense16 = value ? 1 : 0; return 0; }
   if (!strcmp(name, "wgrad_boxes")) { h->wgrad_boxes = value ? 1 : 0; return 0; }
   if (!strcmp(name, "border_boxes")) { h->border_boxes = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }    // 2 = at every size (tests)
   if (!strcmp(name, "d3_wgrad_slab")) { h->d3_wgrad_slab = value ? 1 : 0; return 0; }
@@ -1596,7 +1613,8 @@ static const char* const RD_PLAN_NAMES[PL_COUNT] = {
   "gen block1 shared-centre S (boxes)", "gen block2 shared-centre S (boxes)", "gen block3 shared-centre S (boxes)",
   "gen block1 shared-centre E[s+1] (boxes)", "gen block2 shared-centre E[s+1] (boxes)", "gen block3 shared-centre E[s+1] (boxes)",
   "gen block1 (collapsed, boxes)", "gen block2 (collapsed, boxes)", "gen block3 (collapsed, boxes)",
-  "gen block1 dgrad (collapsed, boxes)", "gen block2 dgrad (collapsed, boxes)", "gen block3 dgrad (collapsed, boxes)"};
+  "gen block1 dgrad (collapsed, boxes)", "gen block2 dgrad (collapsed, boxes)", "gen block3 dgrad (collapsed, boxes)",
+  "gen dense (bf16 pipe)"};
 
 extern "C" int rdgan_profile_launches(rdgan_handle* h, int on) {
   if (!h) return -2;
@@ -1750,12 +1768,15 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // ---- weight forms (read only the weights): skipped when the caller vouches that the forms in the workspace were built from
   // these very weights (same slab, same content version, same form options)
   const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0) | (h->upconv_slab ? 8 : 0) | (h->upconv2_slab ? 16 : 0) |
-                   (h->g9_fused && h->tapgather ? 32 : 0);
+                   (h->g9_fused && h->tapgather ? 32 : 0) | (h->dense16 ? 64 : 0);
   const bool forms_cached = h->gver_in != 0 && gp == h->gcache_ptr && h->gver_in == h->gcache_ver && gcfg == h->gcache_cfg;
   if (!forms_cached) {
   h->form_builds[0]++;
   // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
   RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, ws));
+  if (a16 && h->dense16 && h->dense16_ok && h->bW0)
+    hipLaunchKernelGGL(k_dense_w16, dim3((h->n_nodes + 31) / 32, (h->KP0 + 31) / 32), dim3(256), 0, ws, gp + h->goff[0],
+                       (unsigned short*)h->bW0, h->n_in, h->n_nodes, h->KP0);
   if (g9_fused_on(h)) hipLaunchKernelGGL(k_g9_wimg, dim3(1), dim3(256), 0, ws, gp + h->goff[8], (unsigned short*)h->bW9I);
   for (int l = 1; l <= 3; ++l) {
     const float* Wl = gp + h->goff[2 * l];
@@ -1779,10 +1800,31 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // ---- activations
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    const bool d16 = a16 && h->dense16 && h->dense16_ok && h->xcat16;
     hipLaunchKernelGGL(k_concat, dim3(ew_blocks((long)B * h->n_in)), dim3(256), 0, st, z, cond, h->xcat, B,
-                       RDGAN_LATENT_DIM, nd * nd * h->nc, h->d_flag);       // (first kernel of every entry: clears the non-finite flag)
+                       RDGAN_LATENT_DIM, nd * nd * h->nc, h->d_flag,       // (first kernel of every entry: clears the non-finite flag)
+                       d16 ? (unsigned short*)h->xcat16 : (unsigned short*)nullptr, h->KP0);
   }
   // Dense + LeakyReLU (T:326-327); the Reshape (T:328) is a view
+  if (a16 && h->dense16 && h->dense16_ok && h->xcat16) {
+    // the Dense layer on the bf16 matrix pipe: at ndomain 64 its 825 MB fp32 kernel is the launch (HBM-bound); the bf16 image halves it
+    if (ws != st && !forms_cached) RD_CHECK(h, hipStreamWaitEvent(st, h->ev_g[1], 0));      // (the image is built in front of block 1's forms)
+    const int n3 = h->n_nodes / 3;
+    for (int j = 0; j < 3; ++j) {
+      RdEpi ed = epi_make(RD_EPI_BIAS_LRELU, gp + h->goff[1] + (long)j * n3);
+      ed.out16 = 1;
+      const unsigned short* wj = (const unsigned short*)h->bW0 + (long)j * n3 * h->KP0;
+      float* dj = (float*)((rd_bf16_t*)h->h0 + (long)j * n3);
+      if (B <= 128) {       // one row tile: the 64-column tile doubles the workgroups that stream the kernel (ndomain 64: 138 MB per launch)
+        ProfScope ps(h, -1, st);
+        LaunchScope ls(h, PL_GDENSE16, RD_KIND_CONV, B, plan_flops(h->plans[PL_GDENSE16], B), st);
+        h->flops_acc += plan_flops(h->plans[PL_GDENSE16], B);
+        RD_TRY((launch_conv_ws_cfg<128, 64, 2, 2, true>(h, h->plans[PL_GDENSE16], h->d_plans + PL_GDENSE16, B, (const float*)h->xcat16,
+                                                        (const float*)wj, 0, dj, ed, st)));
+      } else
+      RD_TRY(launch_conv16(h, h->plans[PL_GDENSE16], h->d_plans + PL_GDENSE16, B, h->xcat16, wj, dj, ed, st, -1));
+    }
+  } else
   if (a16) RD_TRY(launch_conv_a16(h, h->plans[PL_GDENSE], h->d_plans + PL_GDENSE, B, h->xcat, gp + h->goff[0], h->n_nodes, h->h0,
                                   epi_make(RD_EPI_BIAS_LRELU, gp + h->goff[1]), st, -1, false, true));
   else

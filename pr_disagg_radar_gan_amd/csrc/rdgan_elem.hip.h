@@ -32,13 +32,20 @@ __device__ __forceinline__ float rd_block_sum(float v, float* red) {
 
 // G0 (T:322-323): out[b] = [z[b] (nz) | cond[b].flatten (nc)]
 // (also clears the non-finite flag of the call it opens: a 4-byte hipMemsetAsync is a launch of its own, ~9 us)
+// out16 (optional, bf16 storage mode with the Dense layer on the bf16 matrix pipe): the same rows rounded to bf16, row length KP >= nz + nc
+// (a multiple of 64: the K chunk of the bf16 GEMM), zero padded
 __global__ void k_concat(const float* __restrict__ z, const float* __restrict__ cond, float* __restrict__ out,
-                         int B, int nz, int nc, int* __restrict__ zero_flag) {
+                         int B, int nz, int nc, int* __restrict__ zero_flag, unsigned short* __restrict__ out16 = nullptr, int KP = 0) {
   if (zero_flag && blockIdx.x == 0 && threadIdx.x == 0) *zero_flag = 0;
   const int w = nz + nc;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)B * w; i += (long)gridDim.x * blockDim.x) {
     int b = (int)(i / w), j = (int)(i - (long)b * w);
-    out[i] = j < nz ? z[(long)b * nz + j] : cond[(long)b * nc + (j - nz)];
+    const float v = j < nz ? z[(long)b * nz + j] : cond[(long)b * nc + (j - nz)];
+    out[i] = v;
+    if (out16) {
+      out16[(long)b * KP + j] = __builtin_bit_cast(unsigned short, (__bf16)v);
+      if (j < KP - w) out16[(long)b * KP + w + j] = 0;          // the pad columns (KP - w <= 63 < w)
+    }
   }
 }
 
@@ -1008,6 +1015,22 @@ __global__ void k_weights_to_bf16_t(const float* __restrict__ in, unsigned short
       const __bf16 v = (__bf16)tile[tx][i];
       out[(t * N + n) * K + k] = __builtin_bit_cast(unsigned short, v);
     }
+  }
+}
+// out[n][k] = bf16(in[k][n]) for k < K, 0 for K <= k < KP: the Dense kernel [K][N] as the [N][KP] operand of the bf16 GEMM, K padded
+// to the GEMM's chunk of 64; grid (N/32, KP/32)
+__global__ void k_dense_w16(const float* __restrict__ in, unsigned short* __restrict__ out, int K, int N, int KP) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int k = k0 + i, n = n0 + tx;
+    tile[i][tx] = (k < K && n < N) ? in[(long)k * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, k = k0 + tx;
+    if (n < N && k < KP) out[(long)n * KP + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][i]);
   }
 }
 // The critic's layers 2-4 in one launch: per layer l (blockIdx.z / 27) and tap (blockIdx.z % 27) the transposed bf16 image
