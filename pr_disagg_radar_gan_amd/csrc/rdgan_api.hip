@@ -788,6 +788,8 @@ static int launch_conv_ws_tg(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp
   RD_TRY(ensure_lds(h, (const void*)kern, lds));
   constexpr int KCH = BF ? 64 : 32;                    // K elements per chunk
   if (BF && hp.SC % 64) return bad_arg(h, "conv: bf16 operands need a multiple of 64 channels per tap");
+  // (the kernel decodes its tile with shifts: round 3's first bf16 Dense launch, 24 column tiles, computed 8 of them -- silently)
+  if (hp.N % BN || ((hp.N / BN) & (hp.N / BN - 1))) return bad_arg(h, "conv: the producer/consumer kernel needs N / BN to be a power of two");
   long tm = plan_tiles(hp, B, BM);
   if (tm <= 0) return 0;
   long minL = hp.ph[0].L;
