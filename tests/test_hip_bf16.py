@@ -461,6 +461,42 @@ def test_last_conv_input_gradient_on_the_matrix_pipe(nd, B):
         eng.close()
 
 
+@pytest.mark.parametrize("nd,B", [(16, 5), (16, 200), (64, 1), (8, 3), (24, 2)])
+def test_dense_layer_on_the_bf16_pipe(nd, B):
+    """"dense16" (default on): the generator's Dense layer (T:326) on the bf16 matrix pipe -- inputs (z | condition) and kernel rounded
+    to bf16, K padded to a multiple of 64, three launches of a third of the columns each because the streaming kernel decodes
+    N / 128 as a power of two (3072 = 3 x 1024; a first version computed the first 1024 columns only) -- against the fp32-pipe
+    kernel with bf16 output: every one of the n_nodes columns of h0 within the rounding of the inputs (2^-9 each, 356 ... 4196
+    terms), the generator output follows.  ndomain 24: n_nodes / 3 is not 2^k x 128, the option leaves the fp32-pipe kernel in place.
+    B = 200: two row tiles."""
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 83)
+        x, cond, z = ot.synthetic_batch(min(B, 16), nd, 67)
+        rep = lambda a: np.concatenate([a] * (B // a.shape[0] + 1))[:B]
+        cond, z = rep(cond), rep(z)
+        gs = eng.to_slab(g)
+        n_nodes = 3 * (nd // 8) ** 2 * 256
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("dense16", on)
+            out = eng.gen_forward(gs, dev(z), dev(cond)).clone()
+            assert torch.equal(out, eng.gen_forward(gs, dev(z), dev(cond)))
+            res[on] = (out, eng.debug_activation(0, (B, n_nodes)).clone())
+        (o0, h0), (o1, h1) = res[0], res[1]
+        assert bool(torch.isfinite(h1).all()) and bool(torch.isfinite(o1).all())
+        err = (h1 - h0).abs() / (h0.abs().max())
+        print(f"nd {nd} B {B} dense16 1 vs 0: h0 differs by at most {float(err.max()):.2e} of its largest entry, "
+              f"worst column block {int(err.max(dim=0).values.argmax()) // 128} of {n_nodes // 128}")
+        assert float(err.max()) < 2e-2
+        if nd == 24:
+            assert torch.equal(h0, h1)
+        assert float((o1 - o0).abs().max()) < 2e-2 * float(o0.max())
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("B", [2, 50])
 def test_d2_fwd_slab_kernel_equals_the_streaming_gemm(B):
     """"d2_fwd_slab" (default off: measured no faster; ndomain 16): the forward of critic layer 2 in the slab kernel k_d2_fwd_slab16
