@@ -2537,11 +2537,12 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
       ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
       if (a16 && !fast && h->g9_bwd_mfma && (nd * nd) % 32 == 0) {
         // exact fp32 products on the matrix pipe, the row's backward in registers (rdgan_g9bwd16.hip.h)
-        const size_t lds9 = (size_t)4 * (nd + 2) * (nd + 2) * sizeof(float);
-        const int nunits = B * (RDGAN_NHOURS / 2);
+        const int PP = nd <= 16 ? 4 : 1;        // plane pairs per unit (ten staged planes = 13 KB at ndomain 16; 3 B units deal evenly to 768 workgroups)
+        const size_t lds9 = (size_t)(2 * PP + 2) * (nd + 2) * (nd + 2) * sizeof(float);
+        const int nunits = B * (RDGAN_NHOURS / 2 / PP);
         RD_TRY(ensure_lds(h, (const void*)k_g9_bwd_mfma16, lds9));
-        hipLaunchKernelGGL(k_g9_bwd_mfma16, dim3((unsigned)std::min(nunits, 1536)), dim3(256), lds9, st, h->dl, gp + h->goff[8],
-                           (const rd_bf16_t*)hs[3], rs[3], (rd_bf16_t*)dys[3], nunits, RDGAN_NHOURS, nd, nd);
+        hipLaunchKernelGGL(k_g9_bwd_mfma16, dim3((unsigned)std::min(nunits, PP > 1 ? 768 : 1536)), dim3(256), lds9, st, h->dl, gp + h->goff[8],
+                           (const rd_bf16_t*)hs[3], rs[3], (rd_bf16_t*)dys[3], nunits, RDGAN_NHOURS, nd, nd, PP);
       } else
       if (a16) hipLaunchKernelGGL(k_g9_bwd_pairs<rd_bf16_t>, dim3(B * (RDGAN_NHOURS / 2)), dim3(256), g9_lds, st, h->dl, gp + h->goff[8],
                                   (const rd_bf16_t*)hs[3], rs[3], (rd_bf16_t*)dys[3], fast ? (rd_bf16_t*)h->fgS : (rd_bf16_t*)nullptr,

@@ -9,18 +9,19 @@
 // 2 ks + half from the staged planes (one ds_read_b32 per MFMA pair), and ends up with 32 channels of one grid point (lane ^ 32:
 // the other 32): the row's PixelNorm + LeakyReLU backward (one cross-half exchange for the mean) and the bf16 rounding run in
 // registers, h3 comes in and dy goes out in 16-byte pieces.  No plane-pair sums (the shared-centre backward keeps the VALU kernel).
-// A workgroup walks units (sample, hour-plane pair) and keeps the kernel fragments; H * W % 32 == 0.
+// A workgroup walks units (sample, PP hour-plane pairs: four at ndomain 16 -- one pair per unit meant two barriers per 16 tiles)
+// and keeps the kernel fragments; H * W % 32 == 0, (D / 2) % PP == 0.
 #pragma once
 #include "rdgan_edge.hip.h"
 
 __global__ void __launch_bounds__(256, 3)
 k_g9_bwd_mfma16(const float* __restrict__ dl, const float* __restrict__ w9 /* [27][64] */, const rd_bf16_t* __restrict__ h3,
-                const float* __restrict__ rinv, rd_bf16_t* __restrict__ dy, int nunits, int D, int H, int W) {
-  extern __shared__ __attribute__((aligned(16))) float dls[];     // [4][H + 2][W + 2]: planes 2 s - 1 .. 2 s + 2 with a zero halo
+                const float* __restrict__ rinv, rd_bf16_t* __restrict__ dy, int nunits, int D, int H, int W, int PP) {
+  extern __shared__ __attribute__((aligned(16))) float dls[];     // [2 PP + 2][H + 2][W + 2]: planes 2 s - 1 .. 2 (s + PP) with a zero halo
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhalf = lane >> 5;
-  const int Ds = D / 2, PW = W + 2, PHW = (H + 2) * PW, HW = H * W;
+  const int Ds = D / 2 / PP, PW = W + 2, PHW = (H + 2) * PW, HW = H * W;
 
   // kernel fragments: k-step ks, channel block ct: lane (c = 32 ct + l31, half) holds w9[2 ks + half][c] (tap 27: zero);
   // and this lane's staged-plane offset of tap 2 ks + half relative to its grid point in plane A (pl = 1)
@@ -38,9 +39,9 @@ k_g9_bwd_mfma16(const float* __restrict__ dl, const float* __restrict__ w9 /* [2
 
   for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
     const long b = unit / Ds;
-    const int s = unit - (int)b * Ds;
+    const int s = (unit - (int)b * Ds) * PP;          // first plane pair of the unit
     __syncthreads();                                  // every wave has left the previous unit's planes
-    for (int i = tid; i < 4 * PHW; i += 256) {
+    for (int i = tid; i < (2 * PP + 2) * PHW; i += 256) {
       const int pl = i / PHW, r = i - pl * PHW, hh = r / PW - 1, ww = r % PW - 1, d = 2 * s - 1 + pl;
       float v = 0.f;
       if ((unsigned)d < (unsigned)D && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) v = dl[((b * D + d) * H + hh) * W + ww];
@@ -48,7 +49,7 @@ k_g9_bwd_mfma16(const float* __restrict__ dl, const float* __restrict__ w9 /* [2
     }
     __syncthreads();
 #pragma unroll 1
-    for (int tile = wave; tile < 2 * HW / 32; tile += 4) {
+    for (int tile = wave; tile < 2 * PP * HW / 32; tile += 4) {
       const int pos = tile * 32 + l31;
       const int plane = pos / HW, it = pos - plane * HW;
       const int hh = it / W, ww = it - hh * W;
