@@ -697,6 +697,36 @@ k_d1_gemm_wgrad(const float* __restrict__ cin, const TG* __restrict__ u1, float*
 // fp32 sums, bit for bit.  LDS: [544 rows][33] floats (row stride 33: the 32 taps of a row and the rows of a register quad fall
 // into different banks).  grid: min(B, 2 per CU) persistent workgroups.
 #define RD_D1DG_LDS (544 * 33 * 4)
+// the outputs of ONE parity class (d, h, w) = (2 d' + PD, 2 h' + PH, 2 w' + PW): an axis of parity 1 takes tap 1 at o = its half
+// coordinate, an axis of parity 0 taps 0 (o = half coordinate, < the layer's extent) and 2 (o = half coordinate - 1, >= 0) -- the
+// same terms in the same order (td, th, tw ascending) as the scalar loop this replaces, without its divergent branches
+template <int PD, int PH, int PW>
+__device__ __forceinline__ void rd_d1dg_class(const float* __restrict__ Dl, float* __restrict__ gb, int tid) {
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int i = tid + it * 256;                     // 12 x 8 x 8 half coordinates
+    const int dq = i >> 6, hq = (i >> 3) & 7, wq = i & 7;
+    float sum = 0.f;
+#pragma unroll
+    for (int jd = 0; jd < (PD ? 1 : 2); ++jd) {
+      const int td = PD ? 1 : 2 * jd, od = PD ? dq : dq - jd;
+      const bool vd = od >= 0 && od < 11;
+#pragma unroll
+      for (int jh = 0; jh < (PH ? 1 : 2); ++jh) {
+        const int th = PH ? 1 : 2 * jh, oh = PH ? hq : hq - jh;
+        const bool vh = vd && oh >= 0 && oh < 7;
+#pragma unroll
+        for (int jw = 0; jw < (PW ? 1 : 2); ++jw) {
+          const int tw = PW ? 1 : 2 * jw, ow = PW ? wq : wq - jw;
+          const bool ok = vh && ow >= 0 && ow < 7;
+          const float v = Dl[(ok ? (od * 7 + oh) * 7 + ow : 0) * 33 + (td * 3 + th) * 3 + tw];
+          if (ok) sum += v;
+        }
+      }
+    }
+    gb[((2 * dq + PD) * 16 + 2 * hq + PH) * 16 + 2 * wq + PW] = sum;
+  }
+}
 __global__ void __launch_bounds__(256, 2)
 k_d1_dgrad_sample16(const rd_bf16_t* __restrict__ u1, const float* __restrict__ w1, float* __restrict__ g0, int B) {
   extern __shared__ __attribute__((aligned(16))) float Dl[];
@@ -715,47 +745,40 @@ k_d1_dgrad_sample16(const rd_bf16_t* __restrict__ u1, const float* __restrict__ 
   }
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const rd_bf16_t* ub = u1 + (long)b * (539 * 64);
-    // ---- products: 17 blocks of 32 rows dealt to the four waves (5, 4, 4, 4); rows past 538 are zeros
-    for (int blk = wave; blk < 17; blk += 4) {
-      const int row = blk * 32 + l31;
-      const bool ok = row < 539;
-      const rd_bf16_t* rp = ub + (long)(ok ? row : 0) * 64 + lhalf * 8;
-      u32x4_t a[4];
+    // ---- products: 17 blocks of 32 rows dealt to the four waves (5, 4, 4, 4); rows past 538 are zeros.  All of a wave's rows are
+    // requested before the first product (one memory round trip per sample instead of one per block: a first version loaded block
+    // by block, 0.10 ms per launch at 2048 samples of which most was load latency)
+    u32x4_t a[5][4];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) a[kk] = *(const u32x4_t*)(rp + kk * 16);
-      f32x16 acc;
+    for (int i = 0; i < 5; ++i) {
+      const int row = (wave + 4 * i) * 32 + l31;
+      const rd_bf16_t* rp = ub + (long)(row < 539 ? row : 0) * 64 + lhalf * 8;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int kk = 0; kk < 4; ++kk) a[i][kk] = *(const u32x4_t*)(rp + kk * 16);
+    }
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const u32x4_t z = {0u, 0u, 0u, 0u};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, ok ? a[kk] : z), wf[kk], acc, 0, 0, 0);
+    for (int i = 0; i < 5; ++i) {
+      const int blk = wave + 4 * i;
+      if (blk < 17) {
+        const bool ok = blk * 32 + l31 < 539;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const u32x4_t z = {0u, 0u, 0u, 0u};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, ok ? a[i][kk] : z), wf[kk], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Dl[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 33 + l31] = acc[r];
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Dl[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 33 + l31] = acc[r];
     }
     __syncthreads();
-    // ---- outputs: voxel f = (d, h, w), <= 8 terms, in the order of k_d1_col2im
+    // ---- outputs: voxel (d, h, w), <= 8 terms, in the order of k_d1_col2im; one parity class at a time
     float* gb = g0 + (long)b * 6144;
-#pragma unroll 4
-    for (int f = tid; f < 6144; f += 256) {
-      const int d = f >> 8, h = (f >> 4) & 15, w = f & 15;
-      float sum = 0.f;
-      for (int td = (d & 1); td < 3; td += 2) {
-        const int od = (d - td) >> 1;
-        if (d - td < 0 || od >= 11) continue;
-        for (int th = (h & 1); th < 3; th += 2) {
-          const int oh = (h - th) >> 1;
-          if (h - th < 0 || oh >= 7) continue;
-          for (int tw = (w & 1); tw < 3; tw += 2) {
-            const int ow = (w - tw) >> 1;
-            if (w - tw < 0 || ow >= 7) continue;
-            sum += Dl[((od * 7 + oh) * 7 + ow) * 33 + (td * 3 + th) * 3 + tw];
-          }
-        }
-      }
-      gb[f] = sum;
-    }
+    rd_d1dg_class<0, 0, 0>(Dl, gb, tid); rd_d1dg_class<0, 0, 1>(Dl, gb, tid); rd_d1dg_class<0, 1, 0>(Dl, gb, tid);
+    rd_d1dg_class<0, 1, 1>(Dl, gb, tid); rd_d1dg_class<1, 0, 0>(Dl, gb, tid); rd_d1dg_class<1, 0, 1>(Dl, gb, tid);
+    rd_d1dg_class<1, 1, 0>(Dl, gb, tid); rd_d1dg_class<1, 1, 1>(Dl, gb, tid);
     __syncthreads();                                  // the products are read: the next sample may overwrite them
   }
 }
