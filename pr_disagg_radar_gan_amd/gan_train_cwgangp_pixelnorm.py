@@ -40,6 +40,7 @@ n_epoch_and_batch_size_list = ((50, 32),)
 plot_format = 'png'
 name = 'wgancp_pixelnorm'
 nhours = 24 // tres
+exchange = None           # gradient exchange of the data-parallel trainer: None / "auto", "allreduce", "sharded" (trainer.WGANGPTrainer)
 n_channel = 1             # 2: + longitude index (revision1/additional_inputs/…_lon.py:126,136), 3: + sin/cos day of year (…_doy.py:135)
 
 plotdir = f'plots_{name}/'
@@ -283,7 +284,8 @@ def _get_trainer(per_rank_batch):
     eng = models.get_engine(ndomain, per_rank_batch, n_channel)
     if _trainer is None or _trainer.eng is not eng:
         _trainer = WGANGPTrainer(eng, generator.get_weights(), critic.get_weights(), n_disc=n_disc,
-                                 world_size=world, rank=rank, process_group=dist.group.WORLD if world > 1 else None)
+                                 world_size=world, rank=rank, process_group=dist.group.WORLD if world > 1 else None,
+                                 exchange=exchange)
         generator.adopt_slab(_trainer.gparams)
         critic.adopt_slab(_trainer.dparams)
         if resume_from:
@@ -350,6 +352,9 @@ def train(n_epochs, _batch_size, start_epoch=0, make_plots=False, max_batches_pe
                 raise ValueError('encountered nan in g_loss and/or d_loss')          # reference :487-488
             hist['d_loss'].append(d_loss)
             hist['g_loss'].append(g_loss)
+        # every rank: the sharded exchange keeps the Adam second moments current only where they are owned, and gathering
+        # them for the checkpoint is a collective -- it has to run in front of the rank gate, not behind it
+        trainer.sync_state()
         if rank == 0:
             _end_of_epoch(epoch, make_plots, save_models)
     return hist
@@ -372,7 +377,7 @@ def _end_of_epoch(epoch, make_plots, save_models):
         generator.save(f'{outdir}/gen_{params}_{epoch:04d}.{ext}')                   # reference :520-521
         critic.save(f'{outdir}/disc_{params}_{epoch:04d}.{ext}')
         if _trainer is not None:
-            _trainer.save_checkpoint(f'{outdir}/checkpoint_{params}.npz', extra={'epoch': epoch})
+            _trainer.save_checkpoint(f'{outdir}/checkpoint_{params}.npz', extra={'epoch': epoch}, synced=True)
 
 
 def _plot_epoch(epoch, n_plot=30):

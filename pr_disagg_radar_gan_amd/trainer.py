@@ -282,12 +282,20 @@ class WGANGPTrainer:
 
 
     # ---- resume checkpoint (the reference saves weights only, T:520-521, and cannot resume)
-    def save_checkpoint(self, path, extra=None):
+    def save_checkpoint(self, path, extra=None, synced=False, write=True):
         """Everything a bit-identical continuation needs: both weight slabs, both Adam second-moment slabs, the
         shared Adam iteration counter, the step-RNG position (base_seed, calls) and numpy's global RNG state (the
-        reference draws batches and latents from it, T:150,179).  One .npz; rank 0 writes (replicas are identical)."""
+        reference draws batches and latents from it, T:150,179).  One .npz.
+
+        With the sharded exchange the second-moment slabs have to be gathered first, and that is a COLLECTIVE: either every
+        rank calls save_checkpoint (write=(rank == 0) on all but one keeps the file single), or every rank calls
+        sync_state() and the writer passes synced=True (what train() does).  Never call it under `if rank == 0` with
+        synced=False: rank 0 would wait in the all-gather alone."""
         st = np.random.get_state()
-        self.sync_state()                   # (sharded exchange: gather the second-moment slabs; a collective)
+        if not synced:
+            self.sync_state()               # (sharded exchange: gather the second-moment slabs; a collective)
+        if not write:
+            return
         np.savez(path, format=np.array("rdgan-checkpoint-1"), ndomain=self.eng.ndomain,
                  n_cond_channels=getattr(self.eng, "n_cond_channels", 1),
                  gparams=self.gparams.cpu().numpy(), dparams=self.dparams.cpu().numpy(),

@@ -125,6 +125,58 @@ def test_sharded_exchange_equals_the_allreduce_exchange(tmp_path):
     assert float(a["dl"][:4].abs().max()) > 0
 
 
+def _worker_train_script(rank, world, port, out_dir):
+    """train() exactly as the training script runs it (end-of-epoch save under `if rank == 0`), sharded exchange"""
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    # a lone rank inside a collective fails after 60 s instead of hanging the suite
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    torch.set_num_threads(3)
+    from pr_disagg_radar_gan_amd import gan_train_cwgangp_pixelnorm as T
+    from pr_disagg_radar_gan_amd import models
+    from tests.fake_engine import FakeEngine
+    engines = {}
+    models.get_engine = lambda nd, b, nc=1: engines.setdefault(nd, FakeEngine(nd))
+    os.chdir(out_dir)
+    T.configure(ndomain=8, n_disc=1, exchange="sharded", outdir=os.path.join(out_dir, f"models{rank}/"),
+                plotdir=os.path.join(out_dir, f"plots{rank}/"))
+    rng = np.random.default_rng(3)
+    data = rng.gamma(2.0, 1.0, size=(3, 24, 8, 16)).astype(np.float32)
+    T.use_arrays(data, [(t, 0, x) for t in range(3) for x in (0, 8)])
+    T.build_networks(seed=5)
+    np.random.seed(100)                                    # same batch draws on every rank (each takes its shard of them)
+    T.train(2, 4, max_batches_per_epoch=1)                 # two epochs: the second save follows a second sharded update
+    tr = T._trainer
+    assert tr.exchange == {"g": "sharded", "d": "sharded"} and tr.t == 4
+    torch.save({"gparams": tr.gparams.clone(), "dparams": tr.dparams.clone(), "gv": tr.gv.clone(), "dv": tr.dv.clone()},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_end_of_epoch_with_sharded_exchange(tmp_path):
+    """save_checkpoint gathers the Adam second moments of a sharded slab -- a collective -- and train()
+    called it under `if rank == 0`.  train() now runs trainer.sync_state() on every rank in front of the gate; this is the
+    script's own loop at world 2 (gloo, 60 s collective timeout): it must finish, rank 0 alone writes the files, and the
+    checkpoint holds the GATHERED second moments (equal to what each rank holds after the gather, non-zero in both halves)."""
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_worker_train_script, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+    assert (tmp_path / "models0").exists() and not (tmp_path / "models1").exists()
+    cks = [f for f in os.listdir(tmp_path / "models0") if f.startswith("checkpoint_")]
+    assert len(cks) == 1
+    with np.load(tmp_path / "models0" / cks[0]) as f:
+        assert int(f["t"]) == 4
+        for k in ("gparams", "dparams", "gv", "dv"):
+            assert np.array_equal(f[k], r0[k].numpy()), k
+        half = f["gv"].size // 2
+        assert np.abs(f["gv"][:half]).max() > 0 and np.abs(f["gv"][half:]).max() > 0      # both owners' shards arrived
+
+
 def test_exchange_defaults_by_slab_size():
     """None / "auto": only a slab of at least SHARD_THRESHOLD_BYTES is sharded (the generator of ndomain 64), and never at
     world 1; padded shards are whole float4s and cover the 8 loss slots"""
