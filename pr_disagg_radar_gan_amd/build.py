@@ -14,8 +14,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdgan_hip.so")
 SOURCES = ["rdgan_api.hip"]
-HEADERS = ["rdgan_gemm.hip.h", "rdgan_gemm_ws.hip.h", "rdgan_gemm_ws16.hip.h", "rdgan_upconv16.hip.h", "rdgan_upconv16b.hip.h", "rdgan_d2slab16.hip.h", "rdgan_d2fwd16.hip.h", "rdgan_upwgrad16.hip.h", "rdgan_upwgrad16b.hip.h", "rdgan_d2wgrad16.hip.h", "rdgan_d3wgrad16.hip.h", "rdgan_d1fwd16.hip.h", "rdgan_g9bwd16.hip.h", "rdgan_elem.hip.h", "rdgan_edge.hip.h", "rdgan_data.hip.h", "rdgan_plan.h", "rdgan_rng.h",
-           "../../include/rdgan.h"]
+
+
+def headers():
+    """Every header the translation unit can include: a glob, so a new header can never be missing from the staleness check
+    (round 3: four "fixes" were tested on a stale binary because a new header was not listed here)."""
+    import glob
+    hs = sorted(glob.glob(os.path.join(CSRC, "*.h")))
+    return hs + [os.path.normpath(os.path.join(HERE, "..", "include", "rdgan.h"))]
 
 
 def hipcc_path():
@@ -29,7 +35,7 @@ def is_stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, x) for x in SOURCES] + headers())
 
 
 def build(force=False, verbose=False):

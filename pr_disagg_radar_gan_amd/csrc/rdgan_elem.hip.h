@@ -932,7 +932,7 @@ __global__ void k_unpad_w1(const float* __restrict__ wp, float* __restrict__ w, 
 // source position on that axis (48 instead of 64 per position overall; the other two axes keep the collapsed form).
 // U[u] = sum_k c[u][k] W[k] with u = (group A',S,D) x (ph,th) x (pw,tw) and c in {-1,0,1}.
 // ------------------------------------------------------------------------------------
-struct RdWeightMap { int8_t c[48][27]; };
+// (struct RdWeightMap: rdgan_plan.h)
 
 __global__ void k_weight_transform(const float* __restrict__ W, float* __restrict__ U, int CC, int nu, RdWeightMap T) {
   const int c4s = CC / 4;

@@ -694,23 +694,6 @@ __global__ void k_splitk_finish(float* dst, long total, int N, RdEpi epi) {
 // grid.x = r_tile * NT + n_tile, grid.y = split over rows m, grid.z = plan phase; partial sums go to
 // `partial[phase][split][RT*BR][N]` and are folded by k_wgrad_reduce (deterministic, no atomics).
 // ------------------------------------------------------------------------------------
-struct RdWgradTiling {
-  int RT, NT;            // tiles over (tap,c) rows and over N
-  int tiles_per_tap;     // SC >= BR: ceil(SC/BR); else 0
-  int cw;                // c extent per tap inside a tile (BR, or padded SC < BR)
-  int taps_per_tile;     // 1 or BR/cw
-  int rows_per_split;    // multiple of 32
-  int nsplit, nphases;   // grid = RT*NT * nsplit * nphases workgroups (1-D)
-  // border-class boxes (RdPlan::boxes): phases with their own tap and row counts that share ONE set of weights.  Phase p has
-  // rd_wgrad_phase_rt(T, phT[p]) row tiles and ceil(B * phL[p] / rows_per_split) splits (rows_per_split = 1 << rps_log2); its
-  // workgroups and partial slabs follow those of the phases in front of it; k_wgrad_reduce_box adds up, per WEIGHT tap, the
-  // slabs of every phase that lists the tap.
-  int box, rps_log2, tpt_log2;
-};
-
-__host__ __device__ __forceinline__ int rd_wgrad_phase_rt(const RdWgradTiling& T, int ntaps) {
-  return T.tiles_per_tap > 0 ? ntaps * T.tiles_per_tap : (ntaps + T.taps_per_tile - 1) >> T.tpt_log2;
-}
 // box plans: workgroup wg -> phase bz, split by, row tile rt, n tile; slab = index of the first partial slab of (bz, by)
 __device__ __forceinline__ void rd_wgrad_box_decode(const RdPlan* __restrict__ plan, const RdWgradTiling& T, int B, int wg,
                                                     int& bz, int& by, int& rt, int& ntile, int& slab) {

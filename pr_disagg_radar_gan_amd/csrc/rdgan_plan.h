@@ -7,6 +7,12 @@
 #pragma once
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+#define RD_PLAN_HD __host__ __device__ __forceinline__
+#else
+#define RD_PLAN_HD inline
+#endif
+
 #define RD_MAX_TAPS 64
 #define RD_MAX_PHASES 32
 
@@ -88,3 +94,27 @@ struct RdEpi {
   int addt_plane;              // floats per output hour plane (2H * 2W * Cout)
   int out16;                   // bf16-operand kernels: 1 = the destination, aux and addt tensors are bf16 (storage mode)
 };
+
+// weight-gradient tiling (rdgan_gemm.hip.h: k_wgrad_gemm*): dW[tap_w*wrpt + c][n] = sum_m A_gather[m][tap][c] * dY[m][n];
+// partial sums go to `partial[phase][split][RT*BR][N]` and are folded by k_wgrad_reduce (deterministic, no atomics).
+// Chosen on the host (rdgan_hostplan.h: wgrad_tiling), passed to the kernels by value.
+struct RdWgradTiling {
+  int RT, NT;            // tiles over (tap,c) rows and over N
+  int tiles_per_tap;     // SC >= BR: ceil(SC/BR); else 0
+  int cw;                // c extent per tap inside a tile (BR, or padded SC < BR)
+  int taps_per_tile;     // 1 or BR/cw
+  int rows_per_split;    // multiple of 32
+  int nsplit, nphases;   // grid = RT*NT * nsplit * nphases workgroups (1-D)
+  // border-class boxes (RdPlan::boxes): phases with their own tap and row counts that share ONE set of weights.  Phase p has
+  // rd_wgrad_phase_rt(T, phT[p]) row tiles and ceil(B * phL[p] / rows_per_split) splits (rows_per_split = 1 << rps_log2); its
+  // workgroups and partial slabs follow those of the phases in front of it; k_wgrad_reduce_box adds up, per WEIGHT tap, the
+  // slabs of every phase that lists the tap.
+  int box, rps_log2, tpt_log2;
+};
+
+RD_PLAN_HD int rd_wgrad_phase_rt(const RdWgradTiling& T, int ntaps) {
+  return T.tiles_per_tap > 0 ? ntaps * T.tiles_per_tap : (ntaps + T.taps_per_tile - 1) >> T.tpt_log2;
+}
+
+// shared-centre form (rdgan_elem.hip.h: k_weight_transform): U[u] = sum_k c[u][k] W[k], c in {-1, 0, 1}
+struct RdWeightMap { int8_t c[48][27]; };
