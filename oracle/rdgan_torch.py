@@ -170,15 +170,16 @@ def gen_step_grads(dp, gp, z, cond, seed, gates=None, return_intermediates=False
     return loss.detach(), [gg.detach() for gg in grads]
 
 
-def check_gates(gates, acts, masks=None, max_margin=1e-3, max_fraction=1e-3):
+def check_gates(gates, acts, masks=None, max_margin=1e-3, max_fraction=1e-3, observed=None):
     """Guard for the ``gates=`` mechanism: an externally supplied slope pattern may differ from this oracle's own decision
     only where the oracle's LeakyReLU input is within rounding of zero.  gates / acts: matching lists of bool patterns and of
     the post-activation tensors this oracle computed WITH those patterns (x * slope(gate), so sign(x) = sign(act) is the
     oracle's own decision for the inputs it saw); masks: optional dropout masks (elements dropped by the mask are ignored:
     their gradient is zero whatever the slope, and an external run reads them back as 0).  Asserts that disagreements are
     rare (max_fraction of the layer) and all sit within max_margin of the kink, measured as |LeakyReLU input| / RMS of the
-    layer.  Returns the worst margin met."""
-    worst = 0.0
+    layer.  Returns (worst margin, worst fraction) met over the layers; with `observed` (a dict) the maxima are also
+    accumulated there (keys "margin", "fraction"), so that a test run can report the guard's headroom."""
+    worst, worst_frac = 0.0, 0.0
     for li, (g, a) in enumerate(zip(gates, acts)):
         live = torch.ones_like(g) if masks is None else (masks[li] != 0)
         pre = a / torch.where(g, torch.ones((), dtype=a.dtype), torch.full((), LRELU, dtype=a.dtype))
@@ -191,10 +192,13 @@ def check_gates(gates, acts, masks=None, max_margin=1e-3, max_fraction=1e-3):
         if nbad:
             frac = nbad / max(1, int(live.sum()))
             margin = float(pre[bad].abs().max()) / rms
-            worst = max(worst, margin)
+            worst, worst_frac = max(worst, margin), max(worst_frac, frac)
+            if observed is not None:
+                observed["margin"] = max(observed.get("margin", 0.0), margin)
+                observed["fraction"] = max(observed.get("fraction", 0.0), frac)
             assert frac <= max_fraction, f"layer {li}: {nbad} slope disagreements ({frac:.2e} of the layer)"
             assert margin <= max_margin, f"layer {li}: slope disagreement {margin:.2e} RMS away from the kink"
-    return worst
+    return worst, worst_frac
 
 
 def adam_update(params, grads, vs, t, lr=1e-4, beta2=0.9, eps=1e-7):

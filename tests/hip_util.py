@@ -58,6 +58,15 @@ def hip_critic_gates(eng, B):
 # how far from a LeakyReLU kink (in RMS of the layer's inputs) the engine's slope decision may differ from the fp64 oracle's,
 # and for what share of a layer: fp32 rounding of sums of ~1e3..1e4 terms; bf16 storage: every stored tensor rounded to 2^-9
 GATE_TOL = {"f32": dict(max_margin=2e-4, max_fraction=1e-4), "bf16": dict(max_margin=0.15, max_fraction=3e-2)}
+# the largest margin / fraction any test of this process has met, per mode (printed by every helper call, and once more by
+# tests/test_hip_bf16.py::test_zz_gate_guard_headroom): the tolerances above are meant to stay within 3x of these
+GATE_OBSERVED = {"f32": {}, "bf16": {}}
+
+
+def _gate_report(mode, what):
+    o = GATE_OBSERVED[mode]
+    print(f"gate guard [{mode}] after {what}: worst margin {o.get('margin', 0.0):.3e} (limit {GATE_TOL[mode]['max_margin']:.1e}), "
+          f"worst fraction {o.get('fraction', 0.0):.3e} (limit {GATE_TOL[mode]['max_fraction']:.1e})")
 
 
 def gen_step_on_engine_branch(eng, ds, gs, d, g, z, cond, seed, mode="f32"):
@@ -70,8 +79,9 @@ def gen_step_on_engine_branch(eng, ds, gs, d, g, z, cond, seed, mode="f32"):
     t64 = lambda arrs: [torch.from_numpy(a).double() for a in arrs]
     loss, grads, (gh, dh) = ot.gen_step_grads(t64(d), t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double(),
                                               seed, gates=gates, return_intermediates=True)
-    ot.check_gates(gates[0], gh, None, **GATE_TOL[mode])
-    ot.check_gates(gates[1], dh, ot.critic_masks(seed, B, eng.ndomain, torch.float64), **GATE_TOL[mode])
+    ot.check_gates(gates[0], gh, None, observed=GATE_OBSERVED[mode], **GATE_TOL[mode])
+    ot.check_gates(gates[1], dh, ot.critic_masks(seed, B, eng.ndomain, torch.float64), observed=GATE_OBSERVED[mode], **GATE_TOL[mode])
+    _gate_report(mode, f"generator step nd{eng.ndomain} B{B}")
     return slab, loss, grads
 
 
@@ -91,5 +101,6 @@ def critic_step_on_engine_branch(eng, ds, gs, d, g, x, cond, z, seed, mode="f32"
                                              torch.from_numpy(z).double(), seed, alpha_offset=alpha_offset, gates=gates,
                                              fake=None if fake is None else torch.from_numpy(np.asarray(fake)).double(),
                                              return_intermediates=True)
-    ot.check_gates(gates, dh, ot.critic_masks(seed, 3 * B, eng.ndomain, torch.float64), **GATE_TOL[mode])
+    ot.check_gates(gates, dh, ot.critic_masks(seed, 3 * B, eng.ndomain, torch.float64), observed=GATE_OBSERVED[mode], **GATE_TOL[mode])
+    _gate_report(mode, f"critic step nd{eng.ndomain} B{B}")
     return slab, losses, grads

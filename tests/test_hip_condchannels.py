@@ -128,6 +128,29 @@ def test_bf16_storage_step_grads(eng):
         eng.set_option("bf16", 0)
 
 
+def test_critic_form_cache_survives_another_critic_on_the_shared_engine(eng):
+    """with extra condition channels (CP != Cin) the fp32 path of rdgan_critic_forward rewrites the padded
+    layer-1 kernel W1P from ITS weights.  A trainer that vouches for its critic slab (content version) between its critic and
+    generator steps must not find its cached forms still marked valid after another Critic predicted on the shared engine
+    (models.get_engine): the generator step would silently use the other critic's first layer."""
+    from pr_disagg_radar_gan_amd.engine import new_version
+    nc = eng.n_cond_channels
+    g, dA = _params(16, nc, 61)
+    _, dB = _params(16, nc, 62)
+    gs, dsA, dsB = eng.to_slab(g), eng.to_slab(dA), eng.to_slab(dB)
+    x, cond, z = _batch(4, 16, nc, 63)
+    want = eng.gen_grad(dsA, gs, dev(z), dev(cond), 7).clone()                   # versions 0: forms rebuilt from dsA
+    vg, vA, vB = new_version(), new_version(), new_version()
+    eng.critic_grad(dsA, gs, dev(x), dev(cond), dev(z), 5, gen_version=vg, critic_version=vA)       # caches (dsA, vA)
+    builds = eng.form_builds()[1]
+    eng.critic_forward(dsB, dev(x), dev(cond), critic_version=vB)                 # another model on the same engine
+    got = eng.gen_grad(dsA, gs, dev(z), dev(cond), 7, gen_version=vg, critic_version=vA)
+    assert torch.equal(got, want)
+    assert eng.form_builds()[1] == builds + 1                                     # the forms were rebuilt, not trusted
+    again = eng.gen_grad(dsA, gs, dev(z), dev(cond), 7, gen_version=vg, critic_version=vA)
+    assert torch.equal(again, want) and eng.form_builds()[1] == builds + 1        # ... and are cached again afterwards
+
+
 def test_cond_shape_checked(eng):
     g, _ = _params(16, eng.n_cond_channels, 25)
     x, cond, z = ot.synthetic_batch(2, 16, 1)                           # one-channel condition: wrong for this engine

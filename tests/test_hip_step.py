@@ -149,25 +149,24 @@ def test_adam_parity(eng16):
 
 
 def test_nd64_forward_and_grads():
-    """largedomain variant (L:59,325,335): ndomain=64, single sample."""
+    """largedomain variant (L:59,325,335): ndomain=64, single sample.  Forward at the north-star tolerance; the critic step
+    (gradient penalty double backward included) against the fp64 oracle on the run's own LeakyReLU branch at TIGHT -- round 3
+    compared it with the fp32 oracle at 1e-3 without the branch hook."""
     eng = Engine(ndomain=64, max_batch=1)
     try:
         g, d = _params(64, 15)
         x, cond, z = ot.synthetic_batch(1, 64, 8)
-        ref = ot.generator_forward([torch.from_numpy(a) for a in g], torch.from_numpy(z), torch.from_numpy(cond)).numpy()
+        ref = ot.generator_forward(_t64(g), torch.from_numpy(z).double(), torch.from_numpy(cond).double()).numpy()
         gs, ds = eng.to_slab(g), eng.to_slab(d)
         out = eng.gen_forward(gs, dev(z), dev(cond)).cpu().numpy()
-        assert rel_err(out, ref) < 5e-5
-        losses, grads = ot.critic_step_grads([torch.from_numpy(a) for a in d], [torch.from_numpy(a) for a in g],
-                                             torch.from_numpy(x), torch.from_numpy(cond), torch.from_numpy(z), 5)
-        slab = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 5).cpu().numpy()
+        np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-7)
+        assert rel_err(out, ref) < 2e-5
+        slab, losses, grads = critic_step_on_engine_branch(eng, ds, gs, d, g, x, cond, z, 5)
         n = eng.n_critic
-        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=1e-3, atol=1e-5)
-        off = 0
-        for (name, s), r in zip(eng.critic_shapes, grads):
-            k = int(np.prod(s))
-            assert rel_err(slab[off:off + k].reshape(s), r.numpy()) < 1e-3, name
-            off += k
+        np.testing.assert_allclose(slab[n:n + 4], losses.numpy(), rtol=2e-4, atol=1e-6)
+        errs = _grad_errors(slab[:n], grads, eng.critic_shapes)
+        print("nd64 critic-step grad rel errors:", {k: float(f"{v:.2e}") for k, v in errs.items()})
+        assert max(errs.values()) < TIGHT, errs
     finally:
         eng.close()
 
@@ -198,6 +197,18 @@ def test_full_size_properties():
         np.testing.assert_allclose(ga[n], gb[n], rtol=1e-5)
         sl = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 31337).cpu().numpy()
         assert np.all(np.isfinite(sl)) and sl[eng.n_critic + 4] == 0
+        # batches BELOW max_batch: the border-class box plans pick their split per call, so the partial-slab
+        # need is not monotone in B -- at ndomain 16 layer 4 needs 12.6 M floats at 768 samples and 21.0 M at 639 (B = 213).
+        # The workspace is sized for the worst case over all B (rdgan_hostplan.h: wgrad_partial_bound; every B is swept on
+        # the CPU by tests/test_host_plan.py); here the launches themselves, in both storage modes.
+        for bf16 in (0, 1):
+            eng.set_option("bf16", bf16)
+            for B in (213, 131):
+                sl = eng.critic_grad(ds, gs, dev(x[:B]), dev(cond[:B]), dev(z[:B]), 99).cpu().numpy()
+                assert np.all(np.isfinite(sl)) and sl[eng.n_critic + 4] == 0 and np.abs(sl[:eng.n_critic]).max() > 0, (bf16, B)
+                sg = eng.gen_grad(ds, gs, dev(z[:B]), dev(cond[:B]), 98).cpu().numpy()
+                assert np.all(np.isfinite(sg)) and sg[eng.n_gen + 4] == 0 and np.abs(sg[:eng.n_gen]).max() > 0, (bf16, B)
+        eng.set_option("bf16", 0)
     finally:
         eng.close()
 
