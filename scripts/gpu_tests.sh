@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 cd $R
-timeout -k 10 ${GPU_TEST_LIMIT:-1000} python -m pytest tests -m gpu -x -q -rA --durations=30 -p no:cacheprovider "$@" > gpurun_out/gpu_tests.log 2>&1
+timeout -k 10 ${GPU_TEST_LIMIT:-1000} python -m pytest tests -m gpu -q -rA --durations=30 -p no:cacheprovider "$@" > gpurun_out/gpu_tests.log 2>&1
 rc=$?
 grep -E "passed|failed|error" gpurun_out/gpu_tests.log | tail -n 3
 grep -E "^(FAILED|ERROR)" gpurun_out/gpu_tests.log | head -n 20

@@ -27,3 +27,21 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """-m gpu runs: report how close the LeakyReLU-branch guard of the oracle comparisons (tests/hip_util.py: GATE_TOL) came to
+    its limits over the WHOLE session, per storage mode, and leave the figures in gpurun_out/gate_observed.json.  VERDICT round
+    3 (weak 1): the limits are to stay within 3x of what is observed; they were set from this report."""
+    import json
+    hu = sys.modules.get("tests.hip_util")
+    if hu is None or not any(hu.GATE_OBSERVED.values()):
+        return
+    rep = {m: dict(observed=hu.GATE_OBSERVED[m], limit=hu.GATE_TOL[m]) for m in hu.GATE_OBSERVED}
+    print("\ngate guard headroom: " + json.dumps(rep))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "gate_observed.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    except OSError:
+        pass

@@ -146,9 +146,12 @@ def test_critic_form_cache_survives_another_critic_on_the_shared_engine(eng):
     eng.critic_forward(dsB, dev(x), dev(cond), critic_version=vB)                 # another model on the same engine
     got = eng.gen_grad(dsA, gs, dev(z), dev(cond), 7, gen_version=vg, critic_version=vA)
     assert torch.equal(got, want)
-    assert eng.form_builds()[1] == builds + 1                                     # the forms were rebuilt, not trusted
+    # 2 condition channels: C_in 3 is padded to CP 4, the forward rewrote W1P, so the forms were rebuilt, not trusted;
+    # 3 channels: C_in = CP = 4, no padded copy exists, the fp32 forward touches no form and the cache rightly stays valid
+    rebuilt = 1 if nc == 2 else 0
+    assert eng.form_builds()[1] == builds + rebuilt
     again = eng.gen_grad(dsA, gs, dev(z), dev(cond), 7, gen_version=vg, critic_version=vA)
-    assert torch.equal(again, want) and eng.form_builds()[1] == builds + 1        # ... and are cached again afterwards
+    assert torch.equal(again, want) and eng.form_builds()[1] == builds + rebuilt  # ... and are cached (again) afterwards
 
 
 def test_cond_shape_checked(eng):
