@@ -1,0 +1,78 @@
+"""The machine code of librdgan_hip.so against scripts/check_isa.py (CPU only: hipcc cross-compiles gfx950 without a GPU).
+
+VERDICT round 3, item 4: the hand-counted `s_waitcnt vmcnt(n)` / inline-asm loads of the slab kernels and the LDS-DMA + barrier
+protocols were guarded by parity tests alone, and four silent bugs of that class were met in one round.  The lint checks the
+disassembly; its self test re-introduces each historical bug into HEAD's own machine code and expects the matching rule."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = os.path.join(ROOT, "scripts", "check_isa.py")
+LLVM = os.environ.get("RDGAN_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+needs_toolchain = pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")) or shutil.which("hipcc") is None
+                                     and not os.path.exists("/opt/rocm/bin/hipcc"), reason="ROCm LLVM tools not available")
+
+
+def _lib():
+    sys.path.insert(0, ROOT)
+    from pr_disagg_radar_gan_amd import build as b
+    return b.build()          # (re)builds only when a source is newer than the library
+
+
+@needs_toolchain
+def test_library_is_clean():
+    res = subprocess.run([sys.executable, SCRIPT, _lib()], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-2000:]
+    assert " 0 issue(s)" in res.stdout
+
+
+@needs_toolchain
+def test_each_historical_bug_is_flagged_when_reintroduced():
+    res = subprocess.run([sys.executable, SCRIPT, "--selftest", _lib()], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-2000:]
+    for label, rule in (("(1)", "I"), ("(2)", "I"), ("(3)", "II"), ("(4)", "III"), ("(IV)", "IV")):
+        assert any(line.startswith(f"selftest: {label}") and f"rule {rule}" in line for line in res.stdout.splitlines()), res.stdout
+
+
+def test_parser_on_a_hand_written_snippet():
+    """the dataflow itself, on four lines: a load, an instruction that reads its destination, the wait -- in the wrong order"""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import check_isa as C
+    text = """
+0000000000001000 <_Z6k_demoPf>:
+	s_load_dwordx2 s[0:1], s[4:5], 0x0                         // 000000001000: C0060002 00000000
+	s_waitcnt lgkmcnt(0)                                       // 000000001008: BF8CC07F
+	global_load_dwordx4 v[4:7], v1, s[0:1]                     // 00000000100C: DC5C8000 04000001
+	v_add_f32_e32 v8, v4, v4                                   // 000000001014: 02100904
+	s_waitcnt vmcnt(0)                                         // 000000001018: BF8C0F70
+	s_endpgm                                                   // 00000000101C: BF810000
+"""
+    k = C.parse_disassembly(text)
+    (sym, insns), = k.items()
+    issues = C.check_kernel(sym, insns)
+    assert [r for r, _, _ in issues] == ["I"] and "reads ['v4']" in issues[0][2]
+    good = text.replace("\tv_add_f32_e32 v8, v4, v4                                   // 000000001014: 02100904\n\ts_waitcnt vmcnt(0)                                         // 000000001018: BF8C0F70",
+                        "\ts_waitcnt vmcnt(0)                                         // 000000001014: BF8C0F70\n\tv_add_f32_e32 v8, v4, v4                                   // 000000001018: 02100904")
+    (sym, insns), = C.parse_disassembly(good).items()
+    assert C.check_kernel(sym, insns) == []
+    # a loop that carries a load across its back edge: the counted wait must cover it on the SECOND trip too
+    loop = """
+0000000000002000 <_Z6k_loopPf>:
+	global_load_dword v2, v1, s[0:1]                           // 000000002000: DC508000 02000001
+	global_load_dword v3, v1, s[0:1] offset:4                  // 000000002008: DC508004 03000001
+	s_waitcnt vmcnt(1)                                         // 000000002010: BF8C0F71
+	v_add_f32_e32 v9, v2, v9                                   // 000000002014: 02121302
+	global_load_dword v2, v1, s[0:1] offset:8                  // 000000002018: DC508008 02000001
+	v_add_f32_e32 v9, v3, v9                                   // 000000002020: 02121303
+	s_cbranch_scc1 65530                                       // 000000002024: BF85FFFA <_Z6k_loopPf+0x10>
+	s_waitcnt vmcnt(0)                                         // 000000002028: BF8C0F70
+	s_endpgm                                                   // 00000000202C: BF810000
+"""
+    (sym, insns), = C.parse_disassembly(loop).items()
+    issues = C.check_kernel(sym, insns)
+    assert issues and all(r == "I" for r, _, _ in issues)        # v3 is read with one load younger than it and vmcnt(1): in flight
