@@ -143,6 +143,10 @@ def launch_children(args, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL maps its peers' buffers through hipIpcGetMemHandle, and this image's host driver only
+    # supports the dmabuf flavour of IPC -- with the legacy mode the first collective fails with `hipIpcGetMemHandle: invalid
+    # argument`.  The image exports the variable already; it is repeated here so that a caller with a scrubbed environment gets
+    # the same ranks (an explicit setting of the caller wins).
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -239,6 +243,8 @@ def main():
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                          # every rank really takes part in the collective
         ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: the first all-reduce saw {ranks_seen} of {world} ranks")
 
     cfg = dict(CONFIGS[args.config])
     ND = args.ndomain or cfg["nd"]
@@ -278,9 +284,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def check_replicas(dl_, gl_, when):
+        """Data parallel keeps the replicas bit-identical: every rank must hold the same loss tails (they come out of the
+        exchange) and the same weights after an update.  Cheap (two all-reduces of 12 doubles), loud: a mis-exchange -- a
+        collective that silently mixed up shards, a rank that missed an update -- ends the run instead of producing a number."""
+        if world == 1:
+            return
+        trainer.join()
+        v = torch.cat([dl_[:5].double(), gl_[:5].double(), trainer.gparams.double().sum().reshape(1),
+                       trainer.dparams.double().sum().reshape(1)])
+        lo, hi = v.clone(), v.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f"bench.py: replicas differ {when} (rank {rank}): loss tails / weight checksums min {lo.tolist()} max {hi.tolist()}")
+
     for k in range(args.warmup):
         crit, gen = data[k % nbuf]
-        trainer.iteration_raw(crit, gen)
+        dl_w, gl_w = trainer.iteration_raw(crit, gen)
+        if k == 0:
+            check_replicas(dl_w, gl_w, "after the first iteration")
     sync()
     eng.profile(1 << _lib.TAG_GCONV3_FWD)            # HIP events around the dominant kernel, on the launch stream
     eng.flop_count(reset=True)
@@ -302,6 +325,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    check_replicas(dl, gl, "after the timed iterations")
     # (a non-finite value anywhere poisons the weights for good, so the last iteration's flags and losses tell)
     dl, gl = dl.cpu().numpy(), gl.cpu().numpy()
     nonfinite = float(max(dl[4], gl[4]))

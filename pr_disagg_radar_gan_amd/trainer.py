@@ -85,6 +85,7 @@ class WGANGPTrainer:
         self.d_ready = None             # events recorded on the communication stream behind the last critic / generator update
         self.g_ready = None
         self._native_collectives = None
+        self._native_verified = set()   # slabs whose first native sharded exchange has been checked against an all-reduce
 
     def weights_changed(self, which="gd"):
         """Call after writing a weight slab from outside (set_weights, a checkpoint load): its forms are rebuilt on next use."""
@@ -109,6 +110,10 @@ class WGANGPTrainer:
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(slab, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _allreduce_plain(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
     # ---- collectives of the sharded exchange.  RCCL (backend "nccl") has both natively; gloo -- only used to rehearse the
     # data-parallel path on CPU or on one GPU -- has neither for device tensors, so there the same data movement is spelled
@@ -159,7 +164,23 @@ class WGANGPTrainer:
             return tail if self.world == 1 else tail / self.world      # (a view at world 1: no extra kernel on the step path)
         pbuf, vbuf = getattr(self, which + "_pbuf"), getattr(self, which + "_vbuf")
         gsh, psh = getattr(self, which + "_gshard"), getattr(self, which + "_pshard")
+        first_native = self._native() and which not in self._native_verified
+        if first_native:
+            # RCCL's reduce_scatter_tensor / all_gather_into_tensor (in place on views of the padded buffers) had never run
+            # on hardware when this was written: the FIRST native sharded exchange of a slab is checked against a plain
+            # all-reduce of a copy (one extra collective, once) and fails loudly instead of training on a mixed-up shard
+            check = grad[:P].clone()
+            self._allreduce_plain(check)
         self._reduce_scatter(gsh, grad[:P])                # this rank's 1/world of the summed slab (loss tail included)
+        if first_native:
+            want = check[self.rank * per:(self.rank + 1) * per]
+            tol = 1e-5 * float(want.abs().max()) + 1e-30       # (ring order of the two collectives may differ: not bitwise)
+            bad = (~((gsh - want).abs() <= tol).all()).float().reshape(1)
+            self._allreduce_plain(bad)                         # every rank learns of it: nobody is left alone in the all-gather
+            if float(bad) != 0:
+                raise RuntimeError(f"sharded exchange: reduce_scatter_tensor of slab '{which}' disagrees with all_reduce on rank "
+                                   f"{self.rank} (max diff {float((gsh - want).abs().max()):.3e}); use exchange='allreduce'")
+            del check, want
         self.t += 1
         lo = self.rank * per
         hi = min(lo + per, n)
@@ -170,6 +191,19 @@ class WGANGPTrainer:
             pbuf[a:b].copy_(gsh[a - lo:b - lo])            # ... rides behind the weights in the all-gather
         psh.copy_(pbuf[lo:lo + per])
         self._all_gather(pbuf[:P], psh)                    # every rank: the updated weights + the loss sums
+        if first_native:
+            import torch.distributed as dist
+            misplaced = 0.0 if torch.equal(pbuf[lo:lo + per], psh) else 1.0
+            cs = torch.stack([pbuf[:P].double().sum(), torch.tensor(misplaced, dtype=torch.float64, device=pbuf.device)])
+            lo_, hi_ = cs.clone(), cs.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN, group=self.pg)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX, group=self.pg)
+            if float(hi_[1]) != 0:
+                raise RuntimeError("sharded exchange: all_gather_into_tensor put another shard where a rank's own belongs; "
+                                   "use exchange='allreduce'")
+            if not torch.equal(lo_[:1], hi_[:1]):
+                raise RuntimeError("sharded exchange: replicas differ after all_gather_into_tensor; use exchange='allreduce'")
+            self._native_verified.add(which)
         self.weights_changed(which)
         return pbuf[n:n + 5] / self.world
 
