@@ -330,6 +330,11 @@ int rdgan_op_g9_wgrad(const float* dl, const float* h3, float* dW, int B, int nd
  * back as fp32 (the bf16 output widened), rinv [B,24,16,16] = 1/l2 per grid point; dbg: NULL, or [B*24*16*16][4] floats (test
  * hook: row sum of squares and 1/l2 as the two lane halves of a row computed them). */
 int rdgan_op_upconv_slab16(const float* x, const float* w, const float* bias, float* y, float* rinv, float* dbg, int B, void* stream);
+/* The same block of the large-domain variant (L:355-358; source planes of H x W positions, multiples of 8: 32 x 32 at ndomain 64)
+ * through the tiled slab kernel alone (k_upconv_slab_t16: 8 x 8 tiles with their halo resident, K in two halves):
+ * x [B,12,H,W,128], y [B,24,2H,2W,64], rinv [B,24,2H,2W], dbg NULL or [B*24*2H*2W][4]. */
+int rdgan_op_upconv_slab_t16(const float* x, const float* w, const float* bias, float* y, float* rinv, float* dbg, int B, int H, int W,
+                             void* stream);
 /* Generator block 2 forward of the bf16 storage mode (T:335-338 on the 6 x 4 x 4 x 256 input of ndomain 16) through the slab kernel
  * alone (k_upconv2_slab16): x and w [3,3,3,256,128] are rounded to bf16 on the device, y [B,12,8,8,128] = LeakyReLU(PixelNorm(
  * upconv(x) + bias)) comes back as fp32 (the bf16 output widened), rinv [B,12,8,8] = 1/l2 per grid point. */

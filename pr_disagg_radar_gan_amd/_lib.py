@@ -65,6 +65,7 @@ SIGNATURES = {
     "rdgan_op_fastd_wgrad": (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 8 + [c_stream]),
     "rdgan_op_g9_wgrad": (ctypes.c_int, [c_f32p, c_f32p, c_f32p] + [ctypes.c_int] * 4 + [c_stream]),
     "rdgan_op_upconv_slab16": (ctypes.c_int, [c_f32p] * 6 + [ctypes.c_int, c_stream]),
+    "rdgan_op_upconv_slab_t16": (ctypes.c_int, [c_f32p] * 6 + [ctypes.c_int] * 3 + [c_stream]),
     "rdgan_op_upconv2_slab16": (ctypes.c_int, [c_f32p] * 5 + [ctypes.c_int, c_stream]),
     "rdgan_op_upconv_wgrad_slab16": (ctypes.c_int, [c_f32p] * 3 + [ctypes.c_int, c_stream]),
     "rdgan_op_d2_fwd_slab16": (ctypes.c_int, [c_f32p] * 4 + [ctypes.c_int, ctypes.c_uint64, c_stream]),

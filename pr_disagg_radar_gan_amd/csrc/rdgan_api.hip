@@ -19,6 +19,7 @@
 #include "rdgan_gemm_ws16.hip.h"
 #include "rdgan_upconv16.hip.h"
 #include "rdgan_upconv16b.hip.h"
+#include "rdgan_upconv16t.hip.h"
 #include "rdgan_elem.hip.h"
 #include "rdgan_data.hip.h"
 #include "rdgan_edge.hip.h"
@@ -70,6 +71,8 @@ struct rdgan_handle : RdGeom {     // geometry + parameter layout: rdgan_hostpla
   void *bG1F[4], *bG1B, *bW1B;
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
+  void* bW3T = nullptr;           // weight image of the TILED slab kernel of generator block 3 (rdgan_upconv16t.hip.h): 1 MB, [phase][half][tap][j]
+  int upconv_slab_t = 1;          // 1: bf16 storage mode, source planes larger than 8 x 8 (ndomain 32, 64, ...: multiples of 16): block 3 forward by k_upconv_slab_t16
   void* bW2I = nullptr;           // weight image of the slab kernel of generator block 2 (rdgan_upconv16b.hip.h): 4 MB
   int upconv2_slab = 1;           // 1: the same for block 2 (k_upconv2_slab16)
   int g9_fused = 1;               // 1: with the block-3 slab kernel, the last conv's tap products come out of that kernel's epilogue
@@ -650,7 +653,9 @@ static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, fl
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
   const bool any = C != 64 && C != 128 && C != 256;
   if (src16 && any) return bad_arg(h, "colsum: bf16 input only for 64 / 128 / 256 columns");
-  long nblk = std::min<long>(1024, std::max<long>(1, rows / (any ? 8 : 32)));
+  // at most 256 partial rows (one workgroup per CU, four loads in flight per thread): their fold is then one round trip of
+  // k_reduce_partials' 64 row groups instead of four
+  long nblk = std::min<long>(any ? 1024 : 256, std::max<long>(1, rows / (any ? 8 : 32)));
   if ((size_t)nblk * C > h->cpartial_cap) nblk = std::max<long>(1, (long)(h->cpartial_cap / C));
   long rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
@@ -854,6 +859,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
         carve(p, 32L * h->ldp1 + 8); h->bW1B = p;
         carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3I = p;
+        carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3T = p;
         carve(p, 4L * 64 * 4 + 8); h->bW9I = p;
         carve(p, (long)RD_UP2_KSTEPS * 4 * 64 * 4 + 8); h->bW2I = p;
         carve(p, (long)RD_D2S_KSTEPS * 2 * 64 * 4 + 8); h->bW2S = p;
@@ -927,6 +933,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "tapgather")) { h->tapgather = value ? 1 : 0; return 0; }
   if (!strcmp(name, "resident")) { h->resident = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv_slab")) { h->upconv_slab = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "upconv_slab_t")) { h->upconv_slab_t = value ? 1 : 0; return 0; }
   if (!strcmp(name, "upconv2_slab")) { h->upconv2_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "g9_fused")) { h->g9_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_fwd_sample")) { h->d1_fwd_sample = value ? 1 : 0; return 0; }
@@ -1101,6 +1108,11 @@ static bool gen_block_fast(const rdgan_handle* h, int l, int enabled) {
 static bool upconv_slab_on(const rdgan_handle* h, int l) {
   return h->upconv_slab && h->a16 && h->collapse && l == 3 && h->nd == 16 && !gen_block_fast(h, 3, fast_fwd_on(h));
 }
+// the same block on (h, w) tiles of 8 x 8 source positions with their halo (rdgan_upconv16t.hip.h): source planes of 16 x 16, 32 x 32, ...
+static bool upconv_slab_t_on(const rdgan_handle* h, int l) {
+  return h->upconv_slab_t && h->a16 && h->collapse && l == 3 && h->nd > 16 && h->gdim[2][1] % 8 == 0 && h->gdim[2][2] % 8 == 0 &&
+         h->bW3T && !gen_block_fast(h, 3, fast_fwd_on(h));
+}
 static bool upconv2_slab_on(const rdgan_handle* h, int l) {
   return h->upconv2_slab && h->a16 && h->collapse && l == 2 && h->nd == 16 && !gen_block_fast(h, 2, fast_fwd_on(h));
 }
@@ -1159,7 +1171,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // ---- weight forms (read only the weights): skipped when the caller vouches that the forms in the workspace were built from
   // these very weights (same slab, same content version, same form options)
   const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0) | (h->upconv_slab ? 8 : 0) | (h->upconv2_slab ? 16 : 0) |
-                   (h->g9_fused && h->tapgather ? 32 : 0) | (h->dense16 ? 64 : 0);
+                   (h->g9_fused && h->tapgather ? 32 : 0) | (h->dense16 ? 64 : 0) | (h->upconv_slab_t ? 128 : 0);
   const bool forms_cached = h->gver_in != 0 && gp == h->gcache_ptr && h->gver_in == h->gcache_ver && gcfg == h->gcache_cfg;
   if (!forms_cached) {
   h->form_builds[0]++;
@@ -1182,6 +1194,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     } else if (h->collapse) {
       hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * cc)), dim3(256), 0, ws, Wl, h->GWC[l], (int)cc);
       if (upconv_slab_on(h, l)) hipLaunchKernelGGL(k_upconv_wimg, dim3(256), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW3I);
+      else if (upconv_slab_t_on(h, l)) hipLaunchKernelGGL(k_upconv_wimg_t, dim3(256), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW3T);
       else if (upconv2_slab_on(h, l)) hipLaunchKernelGGL(k_upconv2_wimg, dim3(RD_UP2_KSTEPS), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW2I);
       else if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
     }
@@ -1267,7 +1280,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     if (h->collapse) {
       Wl = h->GWC[l];
       pl = PL_G1FC + l - 1;
-      if (!upconv_slab_on(h, l) && !upconv2_slab_on(h, l)) pl = gen_box_plan(h, pl, PL_G1FCX + l - 1, B);
+      if (!upconv_slab_on(h, l) && !upconv2_slab_on(h, l) && !upconv_slab_t_on(h, l)) pl = gen_box_plan(h, pl, PL_G1FCX + l - 1, B);
     }
     const bool fuse = a16 ? conv16_rows_owned(h->plans[pl]) : conv_rows_owned(h->plans[pl], B);       // PixelNorm+LeakyReLU in the GEMM epilogue
     RdEpi ep = epi_make(fuse ? RD_EPI_BIAS_PN_LRELU : RD_EPI_BIAS, gp + h->goff[2 * l + 1]);
@@ -1301,6 +1314,19 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       RD_TRY(ensure_lds(h, (const void*)k_upconv_slab16<1>, RD_UPC_LDS));
       hipLaunchKernelGGL(k_upconv_slab16<1>, ug, dim3(256), RD_UPC_LDS, st, (const rd_bf16_t*)hs[l - 1],
                          (const rd_bf16_t*)h->bW3I, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B);
+      RD_CHECK(h, hipGetLastError());
+      continue;
+    }
+    if (upconv_slab_t_on(h, l)) {   // block 3, bf16 storage, planes larger than 8 x 8: (h, w) tiles with their halo resident, K in two halves
+      ProfScope ps(h, RDGAN_TAG_GCONV3_FWD, st);
+      LaunchScope ls(h, pl, RD_KIND_CONV, B, plan_flops(h->plans[pl], B), st);
+      RD_KNAME(h, "k_upconv_slab_t16<bf16>");
+      h->flops_acc += plan_flops(h->plans[pl], B);
+      const int Hs = h->gdim[2][1], Ws = h->gdim[2][2];
+      const long items = (long)B * 6 * (Hs / 8) * (Ws / 8);
+      RD_TRY(ensure_lds(h, (const void*)k_upconv_slab_t16, RD_UPT_LDS));
+      hipLaunchKernelGGL(k_upconv_slab_t16, dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_UPT_LDS, st, (const rd_bf16_t*)hs[l - 1],
+                         (const rd_bf16_t*)h->bW3T, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B, Hs, Ws, (float*)nullptr);
       RD_CHECK(h, hipGetLastError());
       continue;
     }
@@ -2401,6 +2427,37 @@ extern "C" int rdgan_op_upconv_slab16(const float* x, const float* w, const floa
   if (rc == 0) {
     hipLaunchKernelGGL(k_upconv_slab16<0>, dim3((unsigned)std::min(6 * B, 512)), dim3(256), RD_UPC_LDS, st, (const rd_bf16_t*)xb,
                        (const rd_bf16_t*)wi, bias, (rd_bf16_t*)yb, rinv, B, dbg);
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(ny)), dim3(256), 0, st, (const rd_bf16_t*)yb, y, ny);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {xb, yb, wi, (void*)wc}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// The same block on source planes of H x W positions (multiples of 8) through the TILED slab kernel alone (rdgan_upconv16t.hip.h):
+// x [B,12,H,W,128] -> y [B,24,2H,2W,64], rinv [B,24,2H,2W]; dbg (optional, [B*24*2H*2W][4]) as above.
+extern "C" int rdgan_op_upconv_slab_t16(const float* x, const float* w, const float* bias, float* y, float* rinv, float* dbg, int B,
+                                        int H, int W, void* stream) {
+  if (!x || !w || !bias || !y || !rinv || B < 1 || H < 8 || W < 8 || (H & 7) || (W & 7)) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long nx = (long)B * 12 * H * W * 128, ny = (long)B * 24 * 4 * H * W * 64;
+  if (12L * H * W * 256 >= 0x7FFFFFF0L) return -2;
+  void *xb = nullptr, *yb = nullptr, *wi = nullptr; float* wc = nullptr;
+  int rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc(&wi, 64L * 8 * 2 * 64 * 16);
+  if (rc == 0) rc = (int)hipMalloc((void**)&wc, 64L * 128 * 64 * sizeof(float));
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * 128 * 64)), dim3(256), 0, st, w, wc, 128 * 64);
+    hipLaunchKernelGGL(k_upconv_wimg_t, dim3(256), dim3(256), 0, st, wc, (unsigned short*)wi);
+    rc = ensure_lds(nullptr, (const void*)k_upconv_slab_t16, RD_UPT_LDS);
+  }
+  if (rc == 0) {
+    const long items = (long)B * 6 * (H / 8) * (W / 8);
+    hipLaunchKernelGGL(k_upconv_slab_t16, dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_UPT_LDS, st, (const rd_bf16_t*)xb,
+                       (const rd_bf16_t*)wi, bias, (rd_bf16_t*)yb, rinv, B, H, W, dbg);
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(ny)), dim3(256), 0, st, (const rd_bf16_t*)yb, y, ny);
     rc = (int)hipGetLastError();
   }

@@ -619,13 +619,18 @@ k_colsum_partial(const T* __restrict__ src, long rows, float* __restrict__ parti
   __shared__ f32x4 red[256];
   const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
   const long r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   long r = r0 + rg;
-  for (; r + RG < r1; r += 2 * RG) {            // two independent chains to keep loads in flight
-    s0 += rd_ld4(src + r * C + cg * 4);
-    s1 += rd_ld4(src + (r + RG) * C + cg * 4);
+  // four independent chains: four 16-byte loads in flight per thread (round 4: at most 256 workgroups, so that the fold of the
+  // partial rows is ONE round trip -- with 1024 workgroups and two chains the fold kernel was 24 us on 4-16 workgroups)
+  for (; r + 3 * RG < r1; r += 4 * RG) {
+    const f32x4 a0 = rd_ld4(src + r * C + cg * 4), a1 = rd_ld4(src + (r + RG) * C + cg * 4);
+    const f32x4 a2 = rd_ld4(src + (r + 2 * RG) * C + cg * 4), a3 = rd_ld4(src + (r + 3 * RG) * C + cg * 4);
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
   }
-  if (r < r1) s0 += rd_ld4(src + r * C + cg * 4);
+  for (; r < r1; r += RG) s0 += rd_ld4(src + r * C + cg * 4);
+  s0 = (s0 + s1) + (s2 + s3);
+  s1 = f32x4{0.f, 0.f, 0.f, 0.f};
   red[threadIdx.x] = s0 + s1;
   __syncthreads();
   if (rg == 0) {

@@ -1,0 +1,217 @@
+// bf16 storage mode, generator block 3 forward (T:340-343 / L:355-358: UpSampling3D(2) + Conv3D(128 -> 64, 3x3x3, 'same') + PixelNorm +
+// LeakyReLU) in the collapsed form, as a slab kernel for source planes LARGER than 8 x 8: the large-domain variant
+// (alternative_domains/...largedomain.py, ndomain 64: 12 x 32 x 32 x 128 -> 24 x 64 x 64 x 64; ndomain 32: 16 x 16 planes).  Round 4.
+//
+// k_upconv_slab16 (rdgan_upconv16.hip.h) keeps two whole 8 x 8 source planes + two halo planes resident (64 KB)
+// and assumes the plane IS the tile.  Here a work item is an (h, w) TILE of 8 x 8 positions of two source hour planes:
+//   * the tile is resident WITH ITS HALO: 10 x 10 positions x 4 planes (d0 - 1 .. d0 + 2), so every one of the 8 phases x 8 taps is
+//     a plain shifted read -- no border test in the K loop; positions outside the picture are DMA'd as zeros (out-of-range offset);
+//   * with all 128 channels that image would be 100 KB -- one workgroup per CU, and round 3 measured what a lone workgroup costs
+//     (all waves of a CU in lock-step: epilogue beside epilogue, 1.75x the matrix time).  The image therefore holds HALF of the
+//     channels (4 x 100 rows x 128 B = 50 KB, two workgroups per CU as in 4.6) and a tile's K loop runs in two halves that add into
+//     the same accumulators: pd = 0: channels 0-63 then 64-127; pd = 1: 64-127 (already resident) then 0-63 -- three image loads
+//     per item, 150 KB against 4 MB for the same rows x taps as a streaming GEMM;
+//   * everything else is 4.6: weights global -> VGPR in MFMA-fragment order through a queue of four k-steps (inline-asm loads,
+//     hand-counted vmcnt, checked by scripts/check_isa.py), operands swapped (a lane ends up with 32 channels of one output row),
+//     bias + PixelNorm + LeakyReLU + bf16 rounding in registers, 16-byte stores, two 256-thread workgroups per CU.
+//
+// LDS image: row R = hh * 10 + ww (hh, ww = 0..9: tile position + 1) of plane slot s at s * 12800 + R * 128; 16-byte chunk c
+// (8 channels) of a row at position c ^ (((hh & 1) << 2) | ((ww >> 1) & 3)): the 16 lanes of a fragment-read group take two tile
+// rows x eight columns, whose (ww & 1, position) pairs are then all different -- 16 different 16-byte bank groups.  The DMA
+// writes lane-linearly (8 rows per instruction), so the swizzle is applied to the SOURCE address.
+#pragma once
+#include "rdgan_upconv16.hip.h"
+
+#define RD_UPT_ROWS 100                         // (8 + 2) x (8 + 2) positions
+#define RD_UPT_SLOT (RD_UPT_ROWS * 128)         // bytes per plane slot: 64 channels of every position
+#define RD_UPT_IMG (4 * RD_UPT_SLOT)            // 51,200 B = 50 DMA instructions of 1 KB
+#define RD_UPT_BIAS RD_UPT_IMG                  // 64 floats
+#define RD_UPT_LDS (RD_UPT_BIAS + 256)
+
+// Weight image for the tiled kernel from the collapsed forms Wc [64 = phase*8 + tap][128 ci][64 co] (fp32, k_collapse_weights):
+// k-steps in the order the kernel consumes them, [phase][half][tap][j] (j = 16-channel step inside the half): for k-step
+// g = ((phase*2 + half)*8 + tap)*4 + j and column block nb, lane l holds the 8 bf16
+// Wc[phase*8 + tap][64 half + 16 j + 8 (l >> 5) + e][32 nb + (l & 31)], e = 0..7 (the A fragment of v_mfma_f32_32x32x16_bf16):
+// 1 KB per (g, nb), 64 KB contiguous per (phase, half), 1 MB in all.
+__global__ void k_upconv_wimg_t(const float* __restrict__ Wc, unsigned short* __restrict__ wimg) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;                 // (g, nb, lane)
+  if (idx >= 512 * 2 * 64) return;
+  const int lane = idx & 63, nb = (idx >> 6) & 1, g = idx >> 7;
+  const int j = g & 3, tap = (g >> 2) & 7, half = (g >> 5) & 1, phase = g >> 6;
+  const int n = nb * 32 + (lane & 31), k0 = half * 64 + j * 16 + (lane >> 5) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = Wc[((long)(phase * 8 + tap) * 128 + k0 + e) * 64 + n];
+  u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
+  *(u32x4_t*)(wimg + (long)idx * 8) = o;
+}
+
+// x [B][12][H][W][128] bf16 -> out [B][24][2H][2W][64] bf16 = LeakyReLU(PixelNorm(upconv(x) + bias)), rinv [B][24][2H][2W] = 1/l2.
+// H, W multiples of 8.  Work item = (sample, source plane pair d0 = 2 dp, tile (th, tw)); wave q computes the 128 rows (2 planes x
+// 8 x 8 positions) x 64 channels of phase (pd, q >> 1, q & 1), pd = 0 then 1.  grid: persistent workgroups of 256 threads (two per
+// CU); consecutive items -- neighbouring tiles, which share their halo columns -- go to workgroups of the same XCD (same L2).
+// dynamic LDS RD_UPT_LDS.
+__global__ void __launch_bounds__(256, 2)
+k_upconv_slab_t16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__ wimg, const float* __restrict__ bias,
+                  rd_bf16_t* __restrict__ out, float* __restrict__ rinv, int B, int H, int W, float* __restrict__ dbg = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  const int ph = wave >> 1, pw = wave & 1;
+  if (tid < 64) *(float*)(lds + RD_UPT_BIAS + tid * 4) = bias[tid];
+  const unsigned wvoff = (unsigned)lane * 16u;
+  const int TH = H >> 3, TW = W >> 3;
+  const int nitem = B * 6 * TH * TW;
+  // workgroups of one XCD (blockIdx % 8 under round-robin placement: speed only) take consecutive items
+  const int G = gridDim.x;
+  const int vid = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const long plane_b = (long)H * W * 256;                    // bytes per source plane
+
+  for (int item = vid; item < nitem; item += G) {
+    const int tw = item % TW, th = (item / TW) % TH, dp = (item / (TW * TH)) % 6, b = item / (6 * TH * TW);
+    const int d0 = 2 * dp, h0 = 8 * th, w0 = 8 * tw;
+    const __amdgpu_buffer_rsrc_t rs = rd_make_rsrc((const float*)(x + (long)b * 12 * H * W * 128));
+    f32x16 acc[4][2];
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      // s = 0: (pd 0, channels 0-63)   1: (pd 0, 64-127) + epilogue   2: (pd 1, 64-127: resident)   3: (pd 1, 0-63) + epilogue
+      const int pd = s >> 1, hf = (s ^ (s >> 1)) & 1;
+      if (s != 2) {
+        __syncthreads();                                  // every wave has left the image (and the bias row is in)
+        // the four planes d0 - 1 .. d0 + 2, positions (h0 - 1 .. h0 + 8) x (w0 - 1 .. w0 + 8), channels 64 hf ..: 50 instructions
+        // (the lane index passes through an asm statement: the per-lane image geometry below is the same for every item, and
+        // hipcc otherwise keeps all of it -- ~50 registers -- alive across the K loops, beside 128 accumulators: 41 spilled
+        // registers in the first build, flagged by scripts/check_isa.py)
+        int lq = lane;
+        asm volatile("" : "+v"(lq));
+#pragma unroll 1
+        for (int k = 0; k < 13; ++k) {
+          const int i = wave + 4 * k;                     // wave-uniform
+          if (i < 50) {
+            const int rg = i * 8 + (lq >> 3);             // row of the image, 0..399
+            const int slot = rg / RD_UPT_ROWS, R = rg - slot * RD_UPT_ROWS;
+            const int hh = R / 10, ww = R - hh * 10;
+            const int c_log = (lq & 7) ^ (((hh & 1) << 2) | ((ww >> 1) & 3));
+            const int d = d0 - 1 + slot, hs = h0 + hh - 1, ws = w0 + ww - 1;
+            const bool ok = (unsigned)d < 12u && (unsigned)hs < (unsigned)H && (unsigned)ws < (unsigned)W;
+            unsigned voff = ok ? (unsigned)(d * plane_b + ((long)(hs * W + ws) * 256) + hf * 128 + c_log * 16) : RD_OOB;
+            asm volatile("" : "+v"(voff));
+            rd_lds_dma16(rs, (float*)(lds + i * 1024), (int)voff, 0);
+          }
+        }
+        rd_dma_landed();
+        __syncthreads();
+      }
+      if ((s & 1) == 0) {
+        // accumulators start at the bias of their channel: register r of block nb = channel 32 nb + 8 (r >> 2) + 4 lhalf + (r & 3)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *(const f32x4*)(lds + RD_UPT_BIAS + (nb * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+              acc[mb][nb][4 * g + 0] = b4.x; acc[mb][nb][4 * g + 1] = b4.y;
+              acc[mb][nb][4 * g + 2] = b4.z; acc[mb][nb][4 * g + 3] = b4.w;
+            }
+          }
+      }
+      // ---- half a K loop: 8 taps x 4 k-steps of 16 channels.  Weight fragments: a queue of four k-steps (8 loads in flight)
+      const char* wph = (const char*)wimg + (long)(((pd * 4 + ph * 2 + pw) * 2 + hf) * 32) * 2048;      // wave-uniform
+      u32x4_t bq[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rd_upc_wload(bq[q][0], bq[q][1], wph + q * 2048, wvoff);
+      int abase[4], aswz[4];
+      auto tap_rows = [&](int t) {
+        // tap t = (td, th, tw): source offsets (pd - 1 + td, ph - 1 + th, pw - 1 + tw); the halo is in the image: always valid
+        const int od = pd - 1 + (t >> 2), oh = ph - 1 + ((t >> 1) & 1), ow = pw - 1 + (t & 1);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const int r = 32 * (mb & 1) + l31;
+          const int hh = (r >> 3) + 1 + oh, ww = (r & 7) + 1 + ow;
+          abase[mb] = ((mb >> 1) + 1 + od) * RD_UPT_SLOT + (hh * 10 + ww) * 128;
+          aswz[mb] = (((hh & 1) << 2) | ((ww >> 1) & 3)) ^ lhalf;
+        }
+      };
+      u32x4_t afr[2][4];
+      tap_rows(0);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) afr[0][mb] = *(const u32x4_t*)(lds + abase[mb] + (aswz[mb] << 4));
+#pragma unroll 1
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < 3) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+              afr[(j + 1) & 1][mb] = *(const u32x4_t*)(lds + abase[mb] + (((2 * (j + 1)) ^ aswz[mb]) << 4));
+          } else {
+            // the next tap's first fragments behind this tap's last k-step (tap 7: tap 7 again, never used)
+            tap_rows(t < 7 ? t + 1 : 7);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) afr[0][mb] = *(const u32x4_t*)(lds + abase[mb] + (aswz[mb] << 4));
+          }
+          rd_upc_wait<6>(bq[j][0], bq[j][1]);               // the two oldest of the eight loads in flight
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, bq[j][0]),
+                                                                 __builtin_bit_cast(rd_bf16x8, afr[j & 1][mb]), acc[mb][0], 0, 0, 0);
+            acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, bq[j][1]),
+                                                                 __builtin_bit_cast(rd_bf16x8, afr[j & 1][mb]), acc[mb][1], 0, 0, 0);
+          }
+          {
+            // refill the slot with k-step t*4 + j + 4 of this half (past its end: the last k-step again, never used)
+            const int gn = t * 4 + j + 4;
+            rd_upc_wload(bq[j][0], bq[j][1], wph + (long)(gn < 31 ? gn : 31) * 2048, wvoff);
+          }
+        }
+      }
+      // the clamped refills of the last four k-steps are still in flight and nobody reads them: waited for HERE, naming their
+      // registers (rdgan_upconv16.hip.h: to the compiler they are dead behind the loop)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]), "+v"(bq[3][0]),
+                     "+v"(bq[3][1]));
+      if ((s & 1) == 0) continue;
+
+      // ---- epilogue, in registers (as in k_upconv_slab16): lane (l31, lhalf) of block mb holds 32 channels of output row
+      // m = 32 mb + l31 of the wave's 128 rows (channels 32 nb + 8 g + 4 lhalf + 0..3), lane ^ 32 the other 32
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        float ss = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ss = fmaf(acc[mb][nb][r], acc[mb][nb][r], ss);
+        ss += __shfl_xor(ss, 32, 64);                       // + the other half's 32 channels of the same row
+        const float ri = __builtin_amdgcn_rsqf(ss * (1.0f / 64.0f) + 1.0e-8f);       // PixelNormalization (T:255-266)
+        const int r = 32 * (mb & 1) + l31;
+        const int dsrc = d0 + (mb >> 1);
+        const long pix = (((long)b * 24 + 2 * dsrc + pd) * (2 * H) + 2 * (h0 + (r >> 3)) + ph) * (2 * W) + 2 * (w0 + (r & 7)) + pw;
+        if (lhalf == 0) rinv[pix] = ri;
+        if (dbg) { dbg[pix * 4 + lhalf] = ss; dbg[pix * 4 + 2 + lhalf] = ri; }      // (op-level test hook: both halves' row sums)
+        char* orow = (char*)out + pix * 128 + lhalf * 16;
+#pragma unroll
+        for (int Gc = 0; Gc < 8; Gc += 2) {             // channel groups 8 Gc .. and 8 (Gc + 1) ..: one 16-byte store per lane
+          unsigned lo[2], hi[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int nb = (Gc + u) >> 2, g = (Gc + u) & 3;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y = acc[mb][nb][4 * g + e] * ri;
+              v[e] = fmaxf(y, RD_LRELU_ALPHA * y);
+            }
+            lo[u] = rd_pack_bf16(v[0], v[1]); hi[u] = rd_pack_bf16(v[2], v[3]);
+          }
+          // lanes 0-31 keep their group Gc and take the upper half's group Gc; lanes 32-63 take the lower half's group Gc + 1
+          const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(hi[0], hi[1], false, false);
+          const u32x4_t o = {sx[0], sy[0], sx[1], sy[1]};
+          *(u32x4_t*)(orow + Gc * 16) = o;
+        }
+      }
+    }
+  }
+}

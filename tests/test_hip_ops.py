@@ -284,6 +284,45 @@ def test_upconv_slab_kernel_vs_oracle(B):
         np.testing.assert_allclose(np.sqrt(got[..., 0]), want, rtol=0, atol=1e-3), tap
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (1, 8, 24), (3, 24, 8)])
+def test_upconv_slab_tiled_kernel_vs_oracle(B, H, W):
+    """k_upconv_slab_t16 alone (rdgan_op_upconv_slab_t16): generator block 3 of the bf16 storage mode on source planes larger than
+    8 x 8 (the large-domain variant, L:355-358: 32 x 32 at ndomain 64; here 16 x 16 and two rectangular grids that would expose a
+    swapped axis) -- (h, w) tiles of 8 x 8 positions with their halo resident, the K loop in two channel halves -- against the fp64
+    oracle on the bf16-rounded input: 2e-2 of the largest output as for the one-tile kernel (observed 6e-3), 1/l2 at 1e-2.  One-hot
+    probes: a single kernel tap and channel pair must move exactly the source voxel the definition names, at EVERY position --
+    tile borders (halo columns fetched from the neighbouring tile's positions) and picture borders (zeros) included."""
+    g = torch.Generator(); g.manual_seed(300 + B + H)
+    x = torch.randn((B, 12, H, W, 128), generator=g)
+    w = 0.02 * torch.randn((3, 3, 3, 128, 64), generator=g)
+    bias = 0.05 * torch.randn((64,), generator=g)
+    u = ot.upsample3d(x.to(torch.bfloat16).double())
+    pre = ot._conv3d_tf(u, w.double(), bias.double(), 1, (1, 1, 1), u.shape[1:4])
+    ref = ot._lrelu(ot.pixel_norm(pre)).numpy()
+    rinv_ref = (1.0 / torch.sqrt((pre * pre).mean(-1) + 1e-8)).numpy()
+    xd, wd, bd = dev(x.numpy()), dev(w.numpy()), dev(bias.numpy())
+    y = torch.full((B, 24, 2 * H, 2 * W, 64), float("nan"), device="cuda")
+    rinv = torch.full((B, 24, 2 * H, 2 * W), float("nan"), device="cuda")
+    rc = lib().rdgan_op_upconv_slab_t16(ptr(xd), ptr(wd), ptr(bd), ptr(y), ptr(rinv), ptr(None), B, H, W, stream())
+    assert rc == 0
+    assert rel_err(y.cpu().numpy(), ref) < 2e-2
+    assert rel_err(rinv.cpu().numpy(), rinv_ref) < 1e-2
+    x1 = torch.zeros((1, 12, H, W, 128)); x1[..., 77] = (torch.arange(12 * H * W, dtype=torch.float32).reshape(1, 12, H, W) % 251) + 1
+    for tap, ch in ((0, 77), (13, 77), (26, 77), (5, 77), (21, 3), (9, 120)):      # (channels of both K halves)
+        xs = torch.zeros_like(x1); xs[..., ch] = x1[..., 77]
+        w1 = torch.zeros((3, 3, 3, 128, 64)); w1[tap // 9, (tap // 3) % 3, tap % 3, ch, 5] = 1.0
+        u1 = ot.upsample3d(xs.double())
+        want = ot._conv3d_tf(u1, w1.double(), torch.zeros(64).double(), 1, (1, 1, 1), u1.shape[1:4])[..., 5].numpy()
+        xd, wd, bd = dev(xs.numpy()), dev(w1.numpy()), dev(np.zeros(64, np.float32))
+        dbg = torch.zeros((24 * 4 * H * W, 4), device="cuda")
+        y1 = torch.empty((1, 24, 2 * H, 2 * W, 64), device="cuda"); r1 = torch.empty((1, 24, 2 * H, 2 * W), device="cuda")
+        assert lib().rdgan_op_upconv_slab_t16(ptr(xd), ptr(wd), ptr(bd), ptr(y1), ptr(r1), ptr(dbg), 1, H, W, stream()) == 0
+        got = dbg.cpu().numpy().reshape(1, 24, 2 * H, 2 * W, 4)
+        np.testing.assert_array_equal(got[..., 0], got[..., 1])                  # both lane halves of a row hold the same sum
+        np.testing.assert_allclose(np.sqrt(got[..., 0]), want, rtol=0, atol=1e-3), (tap, ch)
+    assert lib().rdgan_op_upconv_slab_t16(ptr(xd), ptr(wd), ptr(bd), ptr(y1), ptr(r1), ptr(None), 1, 12, 8, stream()) == -2    # H % 8
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 7, 130, 1100])
 def test_d2_dgrad_slab_kernel_vs_oracle(B):
     """k_d2_dgrad_slab16 alone (rdgan_op_d2_dgrad_slab16): input gradient of the critic's second layer (backward of T:291,
