@@ -555,6 +555,10 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   float* partial_buf = partial_ws;
   const long wrows = (long)B * hp.ph[0].L;
   const bool ws = h && h->wave_spec && !partial && !shift && !dy16 && (h->wave_spec == 2 || wrows * hp.nphases >= 1024 || T.box);
+  // one phase in one split through k_wgrad_gemm: the tiles go straight to dW, no partial slab, no fold (the Dense layer's 64-row K
+  // loop at ndomain 64: the slab was 825 MB written, read and written again)
+  const bool direct = !ws && !T.box && !dy16 && !partial && np == 1 && nsplit == 1 && h != nullptr && hp.ph[0].w_off == 0;
+  if (direct) { T.direct = 1; T.ldw = hp.N; partial_buf = dW; }
   if (dy16) {       // bf16 storage mode, first critic layer: fp32 gathered input against the bf16 output gradient
     if (shift || BR != 64 || BN != 64) return bad_arg(h, "wgrad: bf16 output gradient only with the 64x64 tile");
     if (partial) RD_TRY((launch_wgrad_cfg<64, 64, true, false, true>(h, dp, np, B, src, dy, partial_buf, T, nsplit, st)));
@@ -572,6 +576,7 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
   else if (BN == 128) RD_WG(64, 128);
   else RD_WG(64, 64);
 #undef RD_WG
+  if (direct) { RD_CHECK(h, hipGetLastError()); return 0; }
   if (T.box) {      // per weight tap: the slabs of every phase that lists it
     const int nw = 64 - __builtin_clzll(hp.wmask | 1ull);
     const long nout = (long)nw * hp.SC * (hp.N / 4);
@@ -661,12 +666,19 @@ static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, fl
   nblk = (rows + rpb - 1) / rpb;
   dim3 grid((unsigned)nblk);
   const rd_bf16_t* s16 = (const rd_bf16_t*)src;
-  if (src16 && C == 64) hipLaunchKernelGGL((k_colsum_partial<16, rd_bf16_t>), grid, dim3(256), 0, st, s16, rows, h->cpartial, rpb);
-  else if (src16 && C == 128) hipLaunchKernelGGL((k_colsum_partial<32, rd_bf16_t>), grid, dim3(256), 0, st, s16, rows, h->cpartial, rpb);
-  else if (src16) hipLaunchKernelGGL((k_colsum_partial<64, rd_bf16_t>), grid, dim3(256), 0, st, s16, rows, h->cpartial, rpb);
-  else if (C == 64) hipLaunchKernelGGL(k_colsum_partial<16>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
-  else if (C == 128) hipLaunchKernelGGL(k_colsum_partial<32>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
-  else if (C == 256) hipLaunchKernelGGL(k_colsum_partial<64>, grid, dim3(256), 0, st, src, rows, h->cpartial, rpb);
+  const bool big = !any && rpb >= 1024;              // long inputs: 1024 threads per workgroup
+#define RD_COLSUM(CG_, T_, P_)                                                                                                    \
+  do {                                                                                                                            \
+    if (big) hipLaunchKernelGGL((k_colsum_partial<CG_, T_, 1024>), grid, dim3(1024), 0, st, P_, rows, h->cpartial, rpb);          \
+    else hipLaunchKernelGGL((k_colsum_partial<CG_, T_, 256>), grid, dim3(256), 0, st, P_, rows, h->cpartial, rpb);                \
+  } while (0)
+  if (src16 && C == 64) RD_COLSUM(16, rd_bf16_t, s16);
+  else if (src16 && C == 128) RD_COLSUM(32, rd_bf16_t, s16);
+  else if (src16) RD_COLSUM(64, rd_bf16_t, s16);
+  else if (C == 64) RD_COLSUM(16, float, src);
+  else if (C == 128) RD_COLSUM(32, float, src);
+  else if (C == 256) RD_COLSUM(64, float, src);
+#undef RD_COLSUM
   else {
     const int bt = std::max(64, std::min(256, (C + 63) / 64 * 64));
     hipLaunchKernelGGL(k_colsum_partial_any, dim3((unsigned)nblk, (C + bt - 1) / bt), dim3(bt), 0, st, src, rows, C, h->cpartial, rpb);

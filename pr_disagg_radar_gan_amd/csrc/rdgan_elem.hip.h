@@ -612,11 +612,14 @@ k_critic_dense_wgrad(const T* __restrict__ buf, float* __restrict__ out, int NB,
 // column sums of rows [0,rows) of a [rows][C] matrix, two deterministic stages.
 // stage 1: CG = C/4 float4 column groups x RG = 256/CG row groups per block; each thread streams float4s
 // down its rows, the row groups are folded through LDS, and partial[blk][C] is written.
-template <int CG, typename T = float>
-__global__ void __launch_bounds__(256)
+// NT = threads per workgroup: 256, or 1024 for long inputs -- at most 256 partial rows keep the fold a single round trip, and a
+// tensor of hundreds of MB then needs the bytes in flight of 1024 threads per CU (256 workgroups x 256 threads x four 8-byte
+// loads read the 805 MB bf16 gradient of ndomain 64's block 3 at 1.9 TB/s)
+template <int CG, typename T = float, int NT = 256>
+__global__ void __launch_bounds__(NT)
 k_colsum_partial(const T* __restrict__ src, long rows, float* __restrict__ partial, long rows_per_blk) {
-  constexpr int RG = 256 / CG, C = CG * 4;
-  __shared__ f32x4 red[256];
+  constexpr int RG = NT / CG, C = CG * 4;
+  __shared__ f32x4 red[NT];
   const int cg = threadIdx.x % CG, rg = threadIdx.x / CG;
   const long r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;

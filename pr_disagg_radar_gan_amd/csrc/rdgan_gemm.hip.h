@@ -905,6 +905,23 @@ k_wgrad_gemm(const RdPlan* __restrict__ plan, int B, const float* __restrict__ s
   }
 
   const int N = plan->N;
+  if (T.direct) {
+    // one phase, one split: the (tap, c) rows of the tile straight to dW (rows past the tap's channels do not exist there)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        int tap, c;
+        rd_wgrad_tile_row(T, BR, rt, row, tap, c);
+        if (tap < P.ntaps && c < SC) {
+          float* o = partial + ((long)P.tap[tap].w * plan->w_rows_per_tap + c) * T.ldw + n0 + wn * WTN + l31;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) o[j * 32] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   float* out = partial + (((long)bz * T.nsplit + by) * T.RT + rt) * BR * N;
 #pragma unroll
   for (int i = 0; i < TM; ++i)

@@ -14,6 +14,13 @@
 #pragma once
 #include "rdgan_gemm.hip.h"
 
+#ifndef RD_WGRAD_SCHED
+#define RD_WGRAD_SCHED 0
+#endif
+#ifndef RD_CONV_SCHED
+#define RD_CONV_SCHED 0
+#endif
+
 #ifdef RD_STAMP
 __device__ unsigned long long rd_stamp_ws[8];   // diagnostic build only: cumulative s_memtime marks of k_conv_gemm_ws (scratch/stamp_ws.py)
 #endif
@@ -465,6 +472,9 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
       for (int j8 = 0; j8 < NJ; ++j8) {
         const int cur = j8 & 1;
         if (j8 + 1 < NJ) load_frag(cur ^ 1, j8 + 1);
+#if RD_CONV_SCHED == 1     // (round 4 experiment, see k_wgrad_gemm_ws: default off)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -472,6 +482,9 @@ k_conv_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict__
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][s][j], acc[i][j], 0, 0, 0);
+#if RD_CONV_SCHED == 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       __syncthreads();
     }
@@ -814,6 +827,15 @@ k_wgrad_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict_
       for (int g = 0; g < NG; ++g) {
         const int cur = g & 1;
         if (g + 1 < NG) load_frag(cur ^ 1, g + 1);
+        // Round 4, measured and NOT kept (default RD_WGRAD_SCHED 0).  hipcc sinks every fragment read of group g + 1 down to its
+        // first use: the ISA is `ds_read2_b32; s_waitcnt lgkmcnt(0); v_mfma; v_mfma` all the way through, two fragment registers in
+        // all -- an LDS latency exposed in front of every pair of MFMAs, covered only by the SIMD's other compute wave.  Pinning the
+        // reads of the next eight positions in front of this group's sixteen MFMAs (RD_WGRAD_SCHED 1: sched_barrier; 0 of 64 MFMAs
+        // then wait for a read, 112 VGPRs) made the <256,64> launches 5-7 % SLOWER (0.419-0.427 -> 0.446-0.453 ms); RD_WGRAD_SCHED 2
+        // spreads the same prefetch one read per MFMA (sched_group_barrier).  See DESIGN.md section 6, round 4.
+#if RD_WGRAD_SCHED == 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -821,6 +843,19 @@ k_wgrad_gemm_ws(const RdPlan* __restrict__ plan, int B, const float* __restrict_
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s][i], fb[cur][s][j], acc[i][j], 0, 0, 0);
+#if RD_WGRAD_SCHED == 1
+        __builtin_amdgcn_sched_barrier(0);
+#elif RD_WGRAD_SCHED == 2
+        {
+          constexpr int NDS = 2 * (TM + TN), NMF = 4 * TM * TN, PER = NMF / NDS > 0 ? NMF / NDS : 1;
+#pragma unroll
+          for (int k = 0; k < NDS; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one LDS read of the next group
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NDS > 0 ? NMF - PER * NDS : 0, 0);
+        }
+#endif
       }
       __syncthreads();
     }

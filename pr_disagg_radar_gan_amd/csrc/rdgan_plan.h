@@ -110,6 +110,10 @@ struct RdWgradTiling {
   // workgroups and partial slabs follow those of the phases in front of it; k_wgrad_reduce_box adds up, per WEIGHT tap, the
   // slabs of every phase that lists the tap.
   int box, rps_log2, tpt_log2;
+  // direct (k_wgrad_gemm only; one phase, one split): the tile goes straight to its place in the weight gradient -- `partial` is
+  // then dW + w_off, ldw its leading dimension -- instead of a partial slab that k_wgrad_reduce would read and write again (the
+  // Dense layer of ndomain 64: 825 MB of gradient, a 64-sample K loop)
+  int direct, ldw;
 };
 
 RD_PLAN_HD int rd_wgrad_phase_rt(const RdWgradTiling& T, int ntaps) {
