@@ -88,6 +88,7 @@ struct rdgan_handle : RdGeom {     // geometry + parameter layout: rdgan_hostpla
   int d2_fwd_slab = 0;            // 1: bf16 storage mode, ndomain 16: forward of critic layer 2 by k_d2_fwd_slab16 (measured: no faster than the streaming GEMM, default off)
   unsigned char* g1bits = nullptr; // layer 1's gate in 2 bits per element (written by k_d1_gemm_fwd, read by k_d2_dgrad_slab16): 16 B per row
   int dense16 = 1;                // 1: bf16 storage mode: the generator's Dense layer on the bf16 matrix pipe (inputs and kernel rounded to bf16, K padded to 64)
+  int dense_skinny = 1;           // 1: ... and, on a handle of max_batch <= 128, by k_dense16_skinny (weights and inputs streamed in fragment order, no LDS)
   void* xcat16 = nullptr;         // [MB][KP0] bf16
   void* bW0 = nullptr;            // [n_nodes][KP0] bf16
   int g9_bwd_mfma = 1;            // 1: bf16 storage mode: input gradient of the last conv + block 3's PixelNorm backward on the fp32 matrix pipe (k_g9_bwd_mfma16)
@@ -859,7 +860,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         h->bU[0] = nullptr;
         for (int l = 1; l <= 3; ++l) { carve(p, 24L * gch[l - 1] * gch[l] + 8); h->bU[l] = p; }
         carve(p, 24L * 256 * 256 + 8); h->bUT = p;
-        carve(p, (long)MB * h->KP0 / 2 + 8); h->xcat16 = p;
+        carve(p, (long)((MB + 31) / 32 * 32) * h->KP0 / 2 + 8); h->xcat16 = p;       // (whole 32-row blocks: the skinny kernel's input image)
         carve(p, (long)h->n_nodes * h->KP0 / 2 + 8); h->bW0 = p;
         h->bWF[0] = h->bWF[1] = h->bWB[0] = h->bWB[1] = nullptr;
         for (int l = 2; l <= 4; ++l) {
@@ -951,6 +952,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "d1_fwd_sample")) { h->d1_fwd_sample = value ? 1 : 0; return 0; }
   if (!strcmp(name, "g9_bwd_mfma")) { h->g9_bwd_mfma = value ? 1 : 0; return 0; }
   if (!strcmp(name, "dense16")) { h->dense16 = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "dense_skinny")) { h->dense_skinny = value ? 1 : 0; return 0; }
   if (!strcmp(name, "wgrad_boxes")) { h->wgrad_boxes = value ? 1 : 0; return 0; }
   if (!strcmp(name, "border_boxes")) { h->border_boxes = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }    // 2 = at every size (tests)
   if (!strcmp(name, "d3_wgrad_slab")) { h->d3_wgrad_slab = value ? 1 : 0; return 0; }
@@ -1171,6 +1173,11 @@ static int gen_box_plan(const rdgan_handle* h, int one, int box, int B) {
   return plan_tiles(h->plans[one], B, 128) * (h->plans[one].N / 128 > 0 ? h->plans[one].N / 128 : 1) >= 1024 ? box : one;
 }
 
+// the Dense layer by k_dense16_skinny (rdgan_edge.hip.h): the weight image is then in fragment order, so the choice is made per
+// HANDLE (every call has B <= max_batch <= 128), not per call
+static bool dense_skinny_on(const rdgan_handle* h) {
+  return h->a16 && h->dense16 && h->dense_skinny && h->MB <= 128 && h->bW0 && h->xcat16 && h->n_nodes % 32 == 0 && h->KP0 % 64 == 0;
+}
 static bool g9_fused_on(const rdgan_handle* h) { return h->g9_fused && h->tapgather && upconv_slab_on(h, 3); }
 
 // keep_h3: block 3's output and 1/l2 are needed afterwards (generator step: its backward; rdgan_gen_forward: the test hook) --
@@ -1183,13 +1190,18 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // ---- weight forms (read only the weights): skipped when the caller vouches that the forms in the workspace were built from
   // these very weights (same slab, same content version, same form options)
   const int gcfg = (h->collapse ? 1 : 0) | (fast_fwd_on(h) ? 2 : 0) | (a16 ? 4 : 0) | (h->upconv_slab ? 8 : 0) | (h->upconv2_slab ? 16 : 0) |
-                   (h->g9_fused && h->tapgather ? 32 : 0) | (h->dense16 ? 64 : 0) | (h->upconv_slab_t ? 128 : 0);
+                   (h->g9_fused && h->tapgather ? 32 : 0) | (h->dense16 ? 64 : 0) | (h->upconv_slab_t ? 128 : 0) | (h->dense_skinny ? 256 : 0);
   const bool forms_cached = h->gver_in != 0 && gp == h->gcache_ptr && h->gver_in == h->gcache_ver && gcfg == h->gcache_cfg;
   if (!forms_cached) {
   h->form_builds[0]++;
   h->gcache_ptr = nullptr; h->gcache_ver = 0; h->gcache_cfg = -1;     // (valid again only once every form kernel has been issued)
   // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
   RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, ws));
+  if (dense_skinny_on(h)) {
+    const long nimg = (long)(h->n_nodes / 32) * (h->KP0 / 16) * 64;
+    hipLaunchKernelGGL(k_dense_wimg, dim3((unsigned)((nimg + 255) / 256)), dim3(256), 0, ws, gp + h->goff[0], (unsigned short*)h->bW0,
+                       h->n_in, h->n_nodes, h->KP0 / 16);
+  } else
   if (a16 && h->dense16 && h->dense16_ok && h->bW0)
     hipLaunchKernelGGL(k_dense_w16, dim3((h->n_nodes + 31) / 32, (h->KP0 + 31) / 32), dim3(256), 0, ws, gp + h->goff[0],
                        (unsigned short*)h->bW0, h->n_in, h->n_nodes, h->KP0);
@@ -1218,12 +1230,31 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // ---- activations
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    const bool d16 = a16 && h->dense16 && h->dense16_ok && h->xcat16;
+    const bool d16 = a16 && h->dense16 && h->dense16_ok && h->xcat16 && !dense_skinny_on(h);
     hipLaunchKernelGGL(k_concat, dim3(ew_blocks((long)B * h->n_in)), dim3(256), 0, st, z, cond, h->xcat, B,
                        RDGAN_LATENT_DIM, nd * nd * h->nc, h->d_flag,       // (first kernel of every entry: clears the non-finite flag)
                        d16 ? (unsigned short*)h->xcat16 : (unsigned short*)nullptr, h->KP0);
   }
   // Dense + LeakyReLU (T:326-327); the Reshape (T:328) is a view
+  if (dense_skinny_on(h)) {
+    // small batch: the kernel is the launch (415 MB of bf16 weights at ndomain 64) -- weights and input rows streamed in fragment order
+    if (ws != st && !forms_cached) RD_CHECK(h, hipStreamWaitEvent(st, h->ev_g[1], 0));      // (the image is built in front of block 1's forms)
+    const int RB = (B + 31) / 32, KS = h->KP0 / 16;
+    ProfScope ps(h, -1, st);
+    LaunchScope ls(h, PL_GDENSE16, RD_KIND_CONV, B, 3.0 * plan_flops(h->plans[PL_GDENSE16], B), st);
+    RD_KNAME(h, "k_dense16_skinny<bf16>");
+    h->flops_acc += 3.0 * plan_flops(h->plans[PL_GDENSE16], B);         // (the plan is a third of the columns)
+    hipLaunchKernelGGL(k_concat16f, dim3((unsigned)(((long)KS * RB * 64 + 255) / 256)), dim3(256), 0, st, z, cond, (unsigned short*)h->xcat16, B,
+                       RDGAN_LATENT_DIM, nd * nd * h->nc, KS, RB);
+    const dim3 dg((unsigned)(h->n_nodes / 32));
+    const unsigned short* xi = (const unsigned short*)h->xcat16; const unsigned short* wi = (const unsigned short*)h->bW0;
+    const float* bs = gp + h->goff[1];
+    if (RB == 1) hipLaunchKernelGGL(k_dense16_skinny<1>, dg, dim3(64), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
+    else if (RB == 2) hipLaunchKernelGGL(k_dense16_skinny<2>, dg, dim3(64), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
+    else if (RB == 3) hipLaunchKernelGGL(k_dense16_skinny<3>, dg, dim3(64), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
+    else hipLaunchKernelGGL(k_dense16_skinny<4>, dg, dim3(64), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
+    RD_CHECK(h, hipGetLastError());
+  } else
   if (a16 && h->dense16 && h->dense16_ok && h->xcat16) {
     // the Dense layer on the bf16 matrix pipe: at ndomain 64 its 825 MB fp32 kernel is the launch (HBM-bound); the bf16 image halves it
     if (ws != st && !forms_cached) RD_CHECK(h, hipStreamWaitEvent(st, h->ev_g[1], 0));      // (the image is built in front of block 1's forms)

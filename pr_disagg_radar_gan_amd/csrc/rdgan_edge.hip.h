@@ -930,3 +930,107 @@ k_d1_wgrad_fold(const float* __restrict__ partial, int G, float* __restrict__ dw
     if (i < 54 * 64) dw[i] = t; else db[i - 54 * 64] = t;
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The generator's Dense layer (T:326-327 / L:333-334: Dense(256 * s * s * 3) + LeakyReLU) for SMALL batches in the bf16 storage
+// mode (round 4).  At ndomain 64 the layer is a 64-row GEMM against a 4224 x 49152 kernel: 26 GFLOP behind 415 MB of bf16
+// weights, read six times per iteration (five critic steps + the generator step) -- HBM-bound, and as three launches of the
+// tiled producer/consumer GEMM (one 128 x 64 tile per workgroup, 256 workgroups per launch) it streamed them at 2.0 TB/s.
+// k_dense16_skinny: no LDS, no barriers; a WAVE owns 32 output columns, keeps all rows' accumulators (RB blocks of 32 samples) and
+// streams its weights and the input rows through registers in MFMA-fragment order -- both images are stored so that one wave
+// instruction reads 1 KB contiguous (k_dense_wimg, k_concat16f) -- two sets of four k-steps in flight.  Operands swapped as in the
+// slab kernels (weights = A): a lane ends up with 16 channels of one sample, bias + LeakyReLU + bf16 rounding in registers.
+// Weight image: [n-block = N / 32][k-step = KP / 16][lane][8 bf16] = W[16 ks + 8 (lane >> 5) + e][32 nb + (lane & 31)] (zero for
+// k >= K); input image: [k-step][row block][lane][8 bf16] = x[32 rb + (lane & 31)][16 ks + 8 (lane >> 5) + e] (zero rows / columns).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void k_dense_wimg(const float* __restrict__ W /* [K][N] */, unsigned short* __restrict__ img, int K, int N, int KS) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;       // (nb, ks, lane)
+  if (idx >= (long)(N / 32) * KS * 64) return;
+  const int lane = (int)(idx & 63);
+  const long t = idx >> 6;
+  const int ks = (int)(t % KS), nb = (int)(t / KS);
+  const int n = nb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = k0 + e < K ? W[(long)(k0 + e) * N + n] : 0.f;
+  u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
+  *(u32x4_t*)(img + idx * 8) = o;
+}
+// the rows [z | cond] of k_concat as that input image, RB row blocks (rows >= B and columns >= nz + nc are zero)
+__global__ void k_concat16f(const float* __restrict__ z, const float* __restrict__ cond, unsigned short* __restrict__ img, int B, int nz,
+                            int nc, int KS, int RB) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;       // (ks, rb, lane)
+  if (idx >= (long)KS * RB * 64) return;
+  const int lane = (int)(idx & 63);
+  const int rb = (int)((idx >> 6) % RB), ks = (int)((idx >> 6) / RB);
+  const int b = rb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    v[e] = b < B ? (k < nz ? z[(long)b * nz + k] : (k < nz + nc ? cond[(long)b * nc + (k - nz)] : 0.f)) : 0.f;
+  }
+  u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
+  *(u32x4_t*)(img + idx * 8) = o;
+}
+
+// out [B][N] bf16 = LeakyReLU(x W + bias); B <= 32 RB, KS = k-steps (a multiple of 4), N a multiple of 32; grid = N / 32
+// workgroups of ONE wave (32 columns each): 1536 of them at ndomain 64 deal evenly to 256 CUs (as 384 four-wave workgroups half
+// of the CUs had two and the launch took as long as those: 0.128 ms, 3.2 TB/s).
+template <int RB>
+__global__ void __launch_bounds__(64)
+k_dense16_skinny(const unsigned short* __restrict__ ximg, const unsigned short* __restrict__ wimg, const float* __restrict__ bias,
+                 rd_bf16_t* __restrict__ out, int B, int KS, int N) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhalf = lane >> 5;
+  const int nb = blockIdx.x;
+  if (nb * 32 >= N) return;
+  const u32x4_t* wp = (const u32x4_t*)wimg + (long)nb * KS * 64 + lane;      // + 64 per k-step
+  const u32x4_t* xp = (const u32x4_t*)ximg + lane;                           // + 64 RB per k-step
+  f32x16 acc[RB];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    // register r of a block = channel 32 nb + 8 (r >> 2) + 4 lhalf + (r & 3): accumulators start at the bias
+    const f32x4 b4 = *(const f32x4*)(bias + nb * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { acc[rb][4 * g] = b4.x; acc[rb][4 * g + 1] = b4.y; acc[rb][4 * g + 2] = b4.z; acc[rb][4 * g + 3] = b4.w; }
+  }
+  u32x4_t wq[2][4], xq[2][4][RB];
+  auto fetch = [&](int set, int ks0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wq[set][u] = __builtin_nontemporal_load(wp + (long)(ks0 + u) * 64);       // read once: keep the L2 for the input rows
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) xq[set][u][rb] = xp[((long)(ks0 + u) * RB + rb) * 64];
+    }
+  };
+  auto mul = [&](int set) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, wq[set][u]),
+                                                          __builtin_bit_cast(rd_bf16x8, xq[set][u][rb]), acc[rb], 0, 0, 0);
+  };
+  fetch(0, 0);
+  for (int ks = 0; ks < KS; ks += 8) {
+    if (ks + 4 < KS) fetch(1, ks + 4);
+    mul(0);
+    if (ks + 4 >= KS) break;
+    if (ks + 8 < KS) fetch(0, ks + 8);
+    mul(1);
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int b = rb * 32 + l31;
+    if (b >= B) continue;
+    rd_bf16_t* o = out + (long)b * N + nb * 32 + 4 * lhalf;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rd_lrelu(acc[rb][4 * g + e]);
+      const u32x2_t pk = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3])};
+      *(u32x2_t*)(o + 8 * g) = pk;
+    }
+  }
+}

@@ -502,7 +502,7 @@ def test_last_conv_input_gradient_on_the_matrix_pipe(nd, B):
         eng.close()
 
 
-@pytest.mark.parametrize("nd,B", [(16, 5), (16, 200), (64, 1), (8, 3), (24, 2)])
+@pytest.mark.parametrize("nd,B", [(16, 5), (16, 200), (64, 1), (8, 3), (24, 2), (16, 70), (32, 33)])
 def test_dense_layer_on_the_bf16_pipe(nd, B):
     """"dense16" (default on): the generator's Dense layer (T:326) on the bf16 matrix pipe -- inputs (z | condition) and kernel rounded
     to bf16, K padded to a multiple of 64, three launches of a third of the columns each because the streaming kernel decodes
@@ -531,9 +531,24 @@ def test_dense_layer_on_the_bf16_pipe(nd, B):
         print(f"nd {nd} B {B} dense16 1 vs 0: h0 differs by at most {float(err.max()):.2e} of its largest entry, "
               f"worst column block {int(err.max(dim=0).values.argmax()) // 128} of {n_nodes // 128}")
         assert float(err.max()) < 2e-2
-        if nd == 24:
-            assert torch.equal(h0, h1)
         assert float((o1 - o0).abs().max()) < 2e-2 * float(o0.max())
+        # "dense_skinny" (round 4, handles of max_batch <= 128): k_dense16_skinny -- weights and input rows streamed in fragment
+        # order, a wave per 32 columns -- against the three tiled launches: the same bf16 products in another fp32 order, so h0
+        # agrees to one bf16 ulp (ndomain 24, whose column count the tiled kernel cannot decode, only has the skinny kernel;
+        # B = 200 only has the tiled one)
+        eng.set_option("dense_skinny", 0)
+        o2 = eng.gen_forward(gs, dev(z), dev(cond)).clone()
+        h2 = eng.debug_activation(0, (B, n_nodes)).clone()
+        eng.set_option("dense_skinny", 1)
+        if B > 128:
+            assert torch.equal(h2, h1)
+        elif nd == 24:
+            assert torch.equal(h2, h0) and not torch.equal(h1, h0)
+        else:
+            rel = (h2 - h1).abs() / h1.abs().clamp_min(1e-3)
+            assert float(rel.max()) <= 2.0 ** -7 + 1e-6, float(rel.max())
+            assert float((h2 != h1).float().mean()) < 2e-2
+            assert float((o2 - o1).abs().max()) < 5e-3 * float(o1.max())        # (ulp differences of h0 carried through three blocks)
     finally:
         eng.close()
 
