@@ -659,15 +659,16 @@ static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, fl
   ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
   const bool any = C != 64 && C != 128 && C != 256;
   if (src16 && any) return bad_arg(h, "colsum: bf16 input only for 64 / 128 / 256 columns");
-  // at most 256 partial rows (one workgroup per CU, four loads in flight per thread): their fold is then one round trip of
-  // k_reduce_partials' 64 row groups instead of four
-  long nblk = std::min<long>(any ? 1024 : 256, std::max<long>(1, rows / (any ? 8 : 32)));
+  // (round 4 tried at most 256 partial rows with 1024-thread workgroups so that the fold is one round trip: beside the GEMMs of the
+  // main stream such a workgroup waits for sixteen free wave slots on one CU -- block 3's sums went 62 -> 120-250 us; the fold got
+  // small workgroups instead: k_reduce_partials4)
+  long nblk = std::min<long>(1024, std::max<long>(1, rows / (any ? 8 : 32)));
   if ((size_t)nblk * C > h->cpartial_cap) nblk = std::max<long>(1, (long)(h->cpartial_cap / C));
   long rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
   dim3 grid((unsigned)nblk);
   const rd_bf16_t* s16 = (const rd_bf16_t*)src;
-  const bool big = !any && rpb >= 1024;              // long inputs: 1024 threads per workgroup
+  const bool big = false;
 #define RD_COLSUM(CG_, T_, P_)                                                                                                    \
   do {                                                                                                                            \
     if (big) hipLaunchKernelGGL((k_colsum_partial<CG_, T_, 1024>), grid, dim3(1024), 0, st, P_, rows, h->cpartial, rpb);          \
@@ -684,6 +685,9 @@ static int launch_colsum(rdgan_handle* h, const float* src, long rows, int C, fl
     const int bt = std::max(64, std::min(256, (C + 63) / 64 * 64));
     hipLaunchKernelGGL(k_colsum_partial_any, dim3((unsigned)nblk, (C + bt - 1) / bt), dim3(bt), 0, st, src, rows, C, h->cpartial, rpb);
   }
+  if (!any && nblk <= 1024)
+    hipLaunchKernelGGL(k_reduce_partials4, dim3(C / 4), dim3(256), 0, st, h->cpartial, (int)nblk, C, out);
+  else
   hipLaunchKernelGGL(k_reduce_partials, dim3((C + 15) / 16), dim3(rd_reduce_threads((int)nblk)), 0, st, h->cpartial, (int)nblk, C, out);
   RD_CHECK(h, hipGetLastError());
   return 0;

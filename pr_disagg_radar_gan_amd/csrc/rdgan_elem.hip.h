@@ -685,6 +685,30 @@ k_reduce_partials(const float* __restrict__ partial, int nsplit, int n, float* _
 }
 static inline int rd_reduce_threads(int nsplit) { return nsplit >= 192 ? 1024 : 256; }
 
+// The same fold for the column sums (n % 4 == 0, nsplit <= 1024), shaped for the gaps beside a running GEMM: n / 4 workgroups of
+// 256 threads (k_reduce_partials folds 1024 x 64 partials on FOUR workgroups of 1024 threads, each of which needs sixteen free
+// wave slots on one CU while the GEMMs own the CUs: 20-24 us on the side stream).  Thread g adds rows g, g + 256, g + 512, g + 768
+// of its workgroup's four columns -- four independent 16-byte loads, one round trip -- then a fixed-order tree over the 256
+// threads: ((p[g] + p[g+256]) + (p[g+512] + p[g+768])), then strides 128 ... 1.  Deterministic, no atomics.
+__global__ void __launch_bounds__(256)
+k_reduce_partials4(const float* __restrict__ partial, int nsplit, int n, float* __restrict__ out) {
+  __shared__ f32x4 red[256];
+  const int c = blockIdx.x * 4, g = threadIdx.x;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 a0 = g < nsplit ? *(const f32x4*)(partial + (long)g * n + c) : z;
+  const f32x4 a1 = g + 256 < nsplit ? *(const f32x4*)(partial + (long)(g + 256) * n + c) : z;
+  const f32x4 a2 = g + 512 < nsplit ? *(const f32x4*)(partial + (long)(g + 512) * n + c) : z;
+  const f32x4 a3 = g + 768 < nsplit ? *(const f32x4*)(partial + (long)(g + 768) * n + c) : z;
+  red[g] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+#pragma unroll
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (g < st) red[g] = red[g] + red[g + st];
+    __syncthreads();
+  }
+  if (g == 0) *(f32x4*)(out + c) = red[0];
+}
+
 // col2im of the D1 input gradient restricted to the sample channel (channel 0):
 // g0[b][pos] = sum over taps t with (pos - t) even and o = (pos - t)/2 inside D1's output of
 // P[b][o][(t, ci=0)], where P[row][tap*2+ci] = u1[row][:] . W1[tap][ci][:]   (D1: stride 2, 'valid', T:286)
