@@ -864,8 +864,9 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         h->bU[0] = nullptr;
         for (int l = 1; l <= 3; ++l) { carve(p, 24L * gch[l - 1] * gch[l] + 8); h->bU[l] = p; }
         carve(p, 24L * 256 * 256 + 8); h->bUT = p;
-        carve(p, (long)((MB + 31) / 32 * 32) * h->KP0 / 2 + 8); h->xcat16 = p;       // (whole 32-row blocks: the skinny kernel's input image)
-        carve(p, (long)h->n_nodes * h->KP0 / 2 + 8); h->bW0 = p;
+        const long KP128 = (h->n_in + 127) / 128 * 128;                               // (the skinny Dense kernel's images: K in whole 128s)
+        carve(p, (long)((MB + 31) / 32 * 32) * KP128 / 2 + 8); h->xcat16 = p;         // (whole 32-row blocks)
+        carve(p, (long)h->n_nodes * KP128 / 2 + 8); h->bW0 = p;
         h->bWF[0] = h->bWF[1] = h->bWB[0] = h->bWB[1] = nullptr;
         for (int l = 2; l <= 4; ++l) {
           carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->bWF[l] = p;
@@ -1179,6 +1180,7 @@ static int gen_box_plan(const rdgan_handle* h, int one, int box, int B) {
 
 // the Dense layer by k_dense16_skinny (rdgan_edge.hip.h): the weight image is then in fragment order, so the choice is made per
 // HANDLE (every call has B <= max_batch <= 128), not per call
+static int dense_skinny_ks(const rdgan_handle* h) { return (h->n_in + 127) / 128 * 8; }      // k-steps of 16, a multiple of 8 (two waves x sets of four)
 static bool dense_skinny_on(const rdgan_handle* h) {
   return h->a16 && h->dense16 && h->dense_skinny && h->MB <= 128 && h->bW0 && h->xcat16 && h->n_nodes % 32 == 0 && h->KP0 % 64 == 0;
 }
@@ -1202,9 +1204,9 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
   RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, ws));
   if (dense_skinny_on(h)) {
-    const long nimg = (long)(h->n_nodes / 32) * (h->KP0 / 16) * 64;
+    const long nimg = (long)(h->n_nodes / 32) * dense_skinny_ks(h) * 64;
     hipLaunchKernelGGL(k_dense_wimg, dim3((unsigned)((nimg + 255) / 256)), dim3(256), 0, ws, gp + h->goff[0], (unsigned short*)h->bW0,
-                       h->n_in, h->n_nodes, h->KP0 / 16);
+                       h->n_in, h->n_nodes, dense_skinny_ks(h));
   } else
   if (a16 && h->dense16 && h->dense16_ok && h->bW0)
     hipLaunchKernelGGL(k_dense_w16, dim3((h->n_nodes + 31) / 32, (h->KP0 + 31) / 32), dim3(256), 0, ws, gp + h->goff[0],
@@ -1243,7 +1245,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   if (dense_skinny_on(h)) {
     // small batch: the kernel is the launch (415 MB of bf16 weights at ndomain 64) -- weights and input rows streamed in fragment order
     if (ws != st && !forms_cached) RD_CHECK(h, hipStreamWaitEvent(st, h->ev_g[1], 0));      // (the image is built in front of block 1's forms)
-    const int RB = (B + 31) / 32, KS = h->KP0 / 16;
+    const int RB = (B + 31) / 32, KS = dense_skinny_ks(h);
     ProfScope ps(h, -1, st);
     LaunchScope ls(h, PL_GDENSE16, RD_KIND_CONV, B, 3.0 * plan_flops(h->plans[PL_GDENSE16], B), st);
     RD_KNAME(h, "k_dense16_skinny<bf16>");
@@ -1253,10 +1255,10 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     const dim3 dg((unsigned)(h->n_nodes / 32));
     const unsigned short* xi = (const unsigned short*)h->xcat16; const unsigned short* wi = (const unsigned short*)h->bW0;
     const float* bs = gp + h->goff[1];
-    if (RB == 1) hipLaunchKernelGGL(k_dense16_skinny<1>, dg, dim3(64), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
-    else if (RB == 2) hipLaunchKernelGGL(k_dense16_skinny<2>, dg, dim3(64), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
-    else if (RB == 3) hipLaunchKernelGGL(k_dense16_skinny<3>, dg, dim3(64), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
-    else hipLaunchKernelGGL(k_dense16_skinny<4>, dg, dim3(64), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
+    if (RB == 1) hipLaunchKernelGGL(k_dense16_skinny<1>, dg, dim3(128), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
+    else if (RB == 2) hipLaunchKernelGGL(k_dense16_skinny<2>, dg, dim3(128), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
+    else if (RB == 3) hipLaunchKernelGGL(k_dense16_skinny<3>, dg, dim3(128), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
+    else hipLaunchKernelGGL(k_dense16_skinny<4>, dg, dim3(128), 0, st, xi, wi, bs, (rd_bf16_t*)h->h0, B, KS, h->n_nodes);
     RD_CHECK(h, hipGetLastError());
   } else
   if (a16 && h->dense16 && h->dense16_ok && h->xcat16) {
@@ -1706,6 +1708,18 @@ static int critic_input_grad(rdgan_handle* h, const float* dp, const float* u1, 
     RD_TRY(ensure_lds(h, (const void*)k_d1_dgrad_sample16, RD_D1DG_LDS));
     hipLaunchKernelGGL(k_d1_dgrad_sample16, dim3((unsigned)std::min(B, 512)), dim3(256), RD_D1DG_LDS, st, (const rd_bf16_t*)u1,
                        dp + h->doff[0], h->g0, B);
+    RD_CHECK(h, hipGetLastError());
+    return 0;
+  }
+  if (h->a16 && h->d1_dgrad_fused && h->nd > 16 && h->nd % 16 == 0 && d1_gemm_ok(h)) {      // the same on 24 x 16 x 8 input tiles (k_d1_dgrad_tile16)
+    ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+    LaunchScope ls(h, PL_D1B, RD_KIND_CONV, B, 2.0 * B * h->dL[1] * 27 * 64, st);
+    RD_KNAME(h, "k_d1_dgrad_tile16<bf16>");
+    h->flops_acc += 2.0 * B * h->dL[1] * 27 * 64;
+    RD_TRY(ensure_lds(h, (const void*)k_d1_dgrad_tile16, RD_D1DT_LDS));
+    const long items = (long)B * (h->nd / 16) * (h->nd / 8);
+    hipLaunchKernelGGL(k_d1_dgrad_tile16, dim3((unsigned)std::min<long>(items, 1024)), dim3(256), RD_D1DT_LDS, st, (const rd_bf16_t*)u1,
+                       dp + h->doff[0], h->g0, B, h->nd);
     RD_CHECK(h, hipGetLastError());
     return 0;
   }

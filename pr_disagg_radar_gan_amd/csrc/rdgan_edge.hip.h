@@ -783,6 +783,104 @@ k_d1_dgrad_sample16(const rd_bf16_t* __restrict__ u1, const float* __restrict__ 
   }
 }
 
+// The same for domains larger than 16 x 16 (round 4; the large-domain variant L:286: ndomain 64 -> layer-1 grid 11 x 31 x 31): a work
+// item is a TILE of 24 x 16 x 8 input voxels of one sample.  Its outputs need the layer-1 rows o = (i - tap) / 2, i.e. the 11 x 9 x 5
+// rows (oh0 .. oh0 + 8) x (ow0 .. ow0 + 4) with oh0 = 8 ti - 1, ow0 = 4 tj - 1 (495 rows, those outside the grid are zeros): their
+// products with the 27 sample-channel taps stay in LDS ([512][33] floats, 66 KB: two workgroups per CU) and the tile's 3072 outputs
+// gather their <= 8 terms from there in the order of k_d1_col2im.  Against the column GEMM + k_d1_col2im (ndomain 64, 64 samples:
+// 346 MB of fp32 column matrix written and read again, 0.071 + 0.095 ms per call, six calls per iteration) a call reads u1 1.4 times
+// (the overlap of the tiles' row sets) and writes the 1.6 MB result.
+#define RD_D1DT_LDS (512 * 33 * 4)
+template <int PD, int PH, int PW>
+__device__ __forceinline__ void rd_d1dt_class(const float* __restrict__ Dl, float* __restrict__ gb, int tid, int nd, int O, int oh0, int ow0,
+                                              int h0, int w0) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = tid + it * 256;                     // 12 x 8 x 4 half coordinates of the tile
+    if (i >= 384) break;
+    const int dq = i >> 5, hq = (i >> 2) & 7, wq = i & 3;
+    float sum = 0.f;
+#pragma unroll
+    for (int jd = 0; jd < (PD ? 1 : 2); ++jd) {
+      const int td = PD ? 1 : 2 * jd, od = PD ? dq : dq - jd;
+      const bool vd = od >= 0 && od < 11;
+#pragma unroll
+      for (int jh = 0; jh < (PH ? 1 : 2); ++jh) {
+        const int th = PH ? 1 : 2 * jh, loh = PH ? hq + 1 : hq + 1 - jh;           // local row: o_h - oh0, always in [0, 8]
+        const bool vh = vd && (unsigned)(oh0 + loh) < (unsigned)O;
+#pragma unroll
+        for (int jw = 0; jw < (PW ? 1 : 2); ++jw) {
+          const int tw = PW ? 1 : 2 * jw, low = PW ? wq + 1 : wq + 1 - jw;
+          const bool ok = vh && (unsigned)(ow0 + low) < (unsigned)O;
+          const float v = Dl[(ok ? (od * 9 + loh) * 5 + low : 0) * 33 + (td * 3 + th) * 3 + tw];
+          if (ok) sum += v;
+        }
+      }
+    }
+    gb[((long)(2 * dq + PD) * nd + h0 + 2 * hq + PH) * nd + w0 + 2 * wq + PW] = sum;
+  }
+}
+// u1 [B][11][O][O][64] bf16 (O = nd / 2 - 1), w1 [27][2][64] fp32 (channel 0 used), g0 [B][24][nd][nd]; nd % 16 == 0.
+// grid: persistent workgroups of 256 threads over B * (nd / 16) * (nd / 8) tiles; dynamic LDS RD_D1DT_LDS.
+__global__ void __launch_bounds__(256, 2)
+k_d1_dgrad_tile16(const rd_bf16_t* __restrict__ u1, const float* __restrict__ w1, float* __restrict__ g0, int B, int nd) {
+  extern __shared__ __attribute__((aligned(16))) float Dl[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  const int O = nd / 2 - 1, TI = nd / 16, TJ = nd / 8;
+  rd_bf16x8 wf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = l31 < 27 ? w1[(l31 * 2) * 64 + kk * 16 + lhalf * 8 + e] : 0.f;
+    const u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
+    wf[kk] = __builtin_bit_cast(rd_bf16x8, o);
+  }
+  const int nitem = B * TI * TJ;
+  for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
+    const int tj = item % TJ, ti = (item / TJ) % TI, b = item / (TJ * TI);
+    const int oh0 = 8 * ti - 1, ow0 = 4 * tj - 1;
+    const rd_bf16_t* ub = u1 + (long)b * 11 * O * O * 64;
+    // ---- products: 16 blocks of 32 rows, four per wave, all requested before the first product (one memory round trip per tile)
+    u32x4_t a[4][4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave + 4 * i) * 32 + l31;                  // (od * 9 + loh) * 5 + low
+      const int od = row / 45, rr = row - od * 45, loh = rr / 5, low = rr - loh * 5;
+      const int oh = oh0 + loh, ow = ow0 + low;
+      ok[i] = row < 495 && (unsigned)oh < (unsigned)O && (unsigned)ow < (unsigned)O;
+      const rd_bf16_t* rp = ub + (ok[i] ? ((long)(od * O + oh) * O + ow) * 64 : 0) + lhalf * 8;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) a[i][kk] = *(const u32x4_t*)(rp + kk * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int blk = wave + 4 * i;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const u32x4_t z = {0u, 0u, 0u, 0u};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, ok[i] ? a[i][kk] : z), wf[kk], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Dl[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 33 + l31] = acc[r];
+    }
+    __syncthreads();
+    float* gb = g0 + (long)b * 24 * nd * nd;
+    const int h0 = 16 * ti, w0 = 8 * tj;
+    rd_d1dt_class<0, 0, 0>(Dl, gb, tid, nd, O, oh0, ow0, h0, w0); rd_d1dt_class<0, 0, 1>(Dl, gb, tid, nd, O, oh0, ow0, h0, w0);
+    rd_d1dt_class<0, 1, 0>(Dl, gb, tid, nd, O, oh0, ow0, h0, w0); rd_d1dt_class<0, 1, 1>(Dl, gb, tid, nd, O, oh0, ow0, h0, w0);
+    rd_d1dt_class<1, 0, 0>(Dl, gb, tid, nd, O, oh0, ow0, h0, w0); rd_d1dt_class<1, 0, 1>(Dl, gb, tid, nd, O, oh0, ow0, h0, w0);
+    rd_d1dt_class<1, 1, 0>(Dl, gb, tid, nd, O, oh0, ow0, h0, w0); rd_d1dt_class<1, 1, 1>(Dl, gb, tid, nd, O, oh0, ow0, h0, w0);
+    __syncthreads();                                  // the products are read: the next tile may overwrite them
+  }
+}
+
 // The same weight gradient in the bf16 storage mode, on the bf16 matrix pipe (round 3).  k_d1_gemm_wgrad<bf16> multiplies on the
 // fp32 pipe (v_mfma_f32_32x32x2f32: 64 cycles per TWO rows of the contraction) and is bound by it -- 0.38 ms at 6144 samples, 0.46
 // of the fp32 MFMA roof, for a launch whose bytes (u1 424 MB bf16 + the 2-channel input 302 MB) would pass in 0.15 ms.  Here both
@@ -974,23 +1072,27 @@ __global__ void k_concat16f(const float* __restrict__ z, const float* __restrict
   *(u32x4_t*)(img + idx * 8) = o;
 }
 
-// out [B][N] bf16 = LeakyReLU(x W + bias); B <= 32 RB, KS = k-steps (a multiple of 4), N a multiple of 32; grid = N / 32
-// workgroups of ONE wave (32 columns each): 1536 of them at ndomain 64 deal evenly to 256 CUs (as 384 four-wave workgroups half
-// of the CUs had two and the launch took as long as those: 0.128 ms, 3.2 TB/s).
+// out [B][N] bf16 = LeakyReLU(x W + bias); B <= 32 RB, KS = k-steps (a multiple of 8), N a multiple of 32; grid = N / 32
+// workgroups of TWO waves that split the k-steps of their 32 columns in halves (the upper half's accumulators cross through LDS at
+// the end): 1536 workgroups at ndomain 64 deal evenly to 256 CUs, and twelve waves per CU keep 48 KB of weight loads in flight
+// per CU (one wave per 32 columns: 24 KB, 3.3 TB/s -- the launch was latency-bound, not bandwidth-bound).
 template <int RB>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 k_dense16_skinny(const unsigned short* __restrict__ ximg, const unsigned short* __restrict__ wimg, const float* __restrict__ bias,
                  rd_bf16_t* __restrict__ out, int B, int KS, int N) {
   const int lane = threadIdx.x & 63, l31 = lane & 31, lhalf = lane >> 5;
+  __shared__ f32x16 xch[RB][64];
   const int nb = blockIdx.x;
-  if (nb * 32 >= N) return;
-  const u32x4_t* wp = (const u32x4_t*)wimg + (long)nb * KS * 64 + lane;      // + 64 per k-step
-  const u32x4_t* xp = (const u32x4_t*)ximg + lane;                           // + 64 RB per k-step
+  const int kw = threadIdx.x >> 6;                                           // which half of the k-steps
+  const int KH = KS >> 1, kbeg = kw * KH;
+  const u32x4_t* wp = (const u32x4_t*)wimg + ((long)nb * KS + kbeg) * 64 + lane;      // + 64 per k-step
+  const u32x4_t* xp = (const u32x4_t*)ximg + (long)kbeg * RB * 64 + lane;             // + 64 RB per k-step
   f32x16 acc[RB];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    // register r of a block = channel 32 nb + 8 (r >> 2) + 4 lhalf + (r & 3): accumulators start at the bias
-    const f32x4 b4 = *(const f32x4*)(bias + nb * 32 + 8 * g + 4 * lhalf);
+    // register r of a block = channel 32 nb + 8 (r >> 2) + 4 lhalf + (r & 3): the lower half's accumulators start at the bias
+    f32x4 b4 = *(const f32x4*)(bias + nb * 32 + 8 * g + 4 * lhalf);
+    if (kw) b4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) { acc[rb][4 * g] = b4.x; acc[rb][4 * g + 1] = b4.y; acc[rb][4 * g + 2] = b4.z; acc[rb][4 * g + 3] = b4.w; }
   }
@@ -1012,13 +1114,21 @@ k_dense16_skinny(const unsigned short* __restrict__ ximg, const unsigned short* 
                                                           __builtin_bit_cast(rd_bf16x8, xq[set][u][rb]), acc[rb], 0, 0, 0);
   };
   fetch(0, 0);
-  for (int ks = 0; ks < KS; ks += 8) {
-    if (ks + 4 < KS) fetch(1, ks + 4);
+  for (int ks = 0; ks < KH; ks += 8) {
+    if (ks + 4 < KH) fetch(1, ks + 4);
     mul(0);
-    if (ks + 4 >= KS) break;
-    if (ks + 8 < KS) fetch(0, ks + 8);
+    if (ks + 4 >= KH) break;
+    if (ks + 8 < KH) fetch(0, ks + 8);
     mul(1);
   }
+  if (kw) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) xch[rb][lane] = acc[rb];
+  }
+  __syncthreads();
+  if (kw) return;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] += xch[rb][lane];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int b = rb * 32 + l31;

@@ -77,6 +77,13 @@ k_upconv_slab_t16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__
     for (int s = 0; s < 4; ++s) {
       // s = 0: (pd 0, channels 0-63)   1: (pd 0, 64-127) + epilogue   2: (pd 1, 64-127: resident)   3: (pd 1, 0-63) + epilogue
       const int pd = s >> 1, hf = (s ^ (s >> 1)) & 1;
+      // weight fragments: a queue of four k-steps (8 loads in flight), STARTED HERE, in front of the image load: they do not depend on
+      // the image, and their round trip then hides behind the DMA's (scripts/check_isa.py watches the queue registers across the
+      // branch below: nothing may touch them before the counted waits of the K loop)
+      const char* wph = (const char*)wimg + (long)(((pd * 4 + ph * 2 + pw) * 2 + hf) * 32) * 2048;      // wave-uniform
+      u32x4_t bq[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rd_upc_wload(bq[q][0], bq[q][1], wph + q * 2048, wvoff);
       if (s != 2) {
         __syncthreads();                                  // every wave has left the image (and the bias row is in)
         // the four planes d0 - 1 .. d0 + 2, positions (h0 - 1 .. h0 + 8) x (w0 - 1 .. w0 + 8), channels 64 hf ..: 50 instructions
@@ -117,11 +124,7 @@ k_upconv_slab_t16(const rd_bf16_t* __restrict__ x, const rd_bf16_t* __restrict__
             }
           }
       }
-      // ---- half a K loop: 8 taps x 4 k-steps of 16 channels.  Weight fragments: a queue of four k-steps (8 loads in flight)
-      const char* wph = (const char*)wimg + (long)(((pd * 4 + ph * 2 + pw) * 2 + hf) * 32) * 2048;      // wave-uniform
-      u32x4_t bq[4][2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rd_upc_wload(bq[q][0], bq[q][1], wph + q * 2048, wvoff);
+      // ---- half a K loop: 8 taps x 4 k-steps of 16 channels
       int abase[4], aswz[4];
       auto tap_rows = [&](int t) {
         // tap t = (td, th, tw): source offsets (pd - 1 + td, ph - 1 + th, pw - 1 + tw); the halo is in the image: always valid

@@ -56,8 +56,11 @@ def hip_critic_gates(eng, B):
 
 
 # how far from a LeakyReLU kink (in RMS of the layer's inputs) the engine's slope decision may differ from the fp64 oracle's,
-# and for what share of a layer: fp32 rounding of sums of ~1e3..1e4 terms; bf16 storage: every stored tensor rounded to 2^-9
-GATE_TOL = {"f32": dict(max_margin=2e-4, max_fraction=1e-4), "bf16": dict(max_margin=0.15, max_fraction=3e-2)}
+# and for what share of a layer: fp32 rounding of sums of ~1e3..1e4 terms; bf16 storage: every stored tensor rounded to 2^-9.
+# Round 4: set to 3x the largest values the whole -m gpu session meets (tests/conftest.py prints them and leaves them in
+# gpurun_out/gate_observed.json): fp32 margin 7.8e-7 / fraction 2.0e-5, bf16 margin 2.63e-2 / fraction 1.70e-3 (round 3 allowed
+# 2e-4 / 1e-4 and 0.15 / 3e-2 without knowing the margins).
+GATE_TOL = {"f32": dict(max_margin=2.5e-6, max_fraction=6e-5), "bf16": dict(max_margin=8e-2, max_fraction=5e-3)}
 # the largest margin / fraction any test of this process has met, per mode (printed by every helper call, and once more by
 # tests/test_hip_bf16.py::test_zz_gate_guard_headroom): the tolerances above are meant to stay within 3x of these
 GATE_OBSERVED = {"f32": {}, "bf16": {}}

@@ -75,8 +75,10 @@ def test_bf16_storage_forward_and_step_gradients(nd, B, seed):
 def test_bf16_storage_b96_production_tiles(fast):
     """B = 96: the tiles of the bs >= 256 step (k_wgrad_gemm_ws16<256, 64>, the 256x64 conv tile with bf16 operands, the
     automatic K splits), in the mode's default collapsed form and with the shared-centre form forced (resident-tile kernel)"""
-    # (the critic step does not depend on the generator's form: checked once, in the default form)
-    _check_bf16_case(16, 96, 41, fast=fast, critic=fast is None)
+    # (the critic step does not depend on the generator's form: checked once, in the default form; the forced shared-centre form --
+    # not what the mode runs by default -- at B = 40: its 256-row tiles and K splits start at 32 samples, and the fp64 oracle of a
+    # B = 96 generator step is 37 s of the GPU suite's budget)
+    _check_bf16_case(16, 96 if fast is None else 40, 41, fast=fast, critic=fast is None)
 
 
 def test_bf16_storage_shared_centre_form_small_batch():
@@ -292,16 +294,17 @@ def test_upwgrad_slab_equals_the_streaming_wgrad(B):
         eng.close()
 
 
-@pytest.mark.parametrize("B", [1, 6, 600])
-def test_d1_dgrad_fused_equals_the_column_gemm_bit_for_bit(B):
+@pytest.mark.parametrize("nd,B", [(16, 1), (16, 6), (16, 600), (32, 3), (64, 2), (48, 1)])
+def test_d1_dgrad_fused_equals_the_column_gemm_bit_for_bit(B, nd):
     """"d1_dgrad_fused" (default on at ndomain 16): dD/d(sample) of the first critic layer in one pass per sample
     (k_d1_dgrad_sample16) against the column GEMM + col2im of the same engine: the same bf16 products, summed over the channels by
     the same MFMA steps and over the taps in the same order -- the critic step (gradient penalty through dD/dx_hat) and the
-    generator step (dL/dfake feeds the whole generator backward) are equal bit for bit.  B = 600: workgroups walk two samples."""
-    eng = Engine(ndomain=16, max_batch=B)
+    generator step (dL/dfake feeds the whole generator backward) are equal bit for bit.  B = 600: workgroups walk two samples.
+    ndomain 32 / 48 / 64 (round 4): the same on tiles of 24 x 16 x 8 input voxels (k_d1_dgrad_tile16), tile and picture borders included."""
+    eng = Engine(ndomain=nd, max_batch=B)
     try:
-        g, d = _params(16, 61)
-        x, cond, z = ot.synthetic_batch(min(B, 64), 16, 52)
+        g, d = _params(nd, 61)
+        x, cond, z = ot.synthetic_batch(min(B, 64), nd, 52)
         rep = lambda a: np.concatenate([a] * (B // a.shape[0] + 1))[:B]
         x, cond, z = rep(x), rep(cond), rep(z)
         gs, ds = eng.to_slab(g), eng.to_slab(d)
