@@ -1185,6 +1185,8 @@ static bool dense_skinny_on(const rdgan_handle* h) {
   return h->a16 && h->dense16 && h->dense_skinny && h->MB <= 128 && h->bW0 && h->xcat16 && h->n_nodes % 32 == 0 && h->KP0 % 64 == 0;
 }
 static bool g9_fused_on(const rdgan_handle* h) { return h->g9_fused && h->tapgather && upconv_slab_on(h, 3); }
+// the same inside the TILED block-3 kernel (ndomain 32, 64: k_upconv_slab_t16<G9>, k_tapsum_softmax12t)
+static bool g9_fused_t_on(const rdgan_handle* h) { return h->g9_fused && h->tapgather && upconv_slab_t_on(h, 3); }
 
 // keep_h3: block 3's output and 1/l2 are needed afterwards (generator step: its backward; rdgan_gen_forward: the test hook) --
 // a critic step passes false, and with the fused last conv the 1.6 GB tensor (2048 samples) is then never written
@@ -1211,7 +1213,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   if (a16 && h->dense16 && h->dense16_ok && h->bW0)
     hipLaunchKernelGGL(k_dense_w16, dim3((h->n_nodes + 31) / 32, (h->KP0 + 31) / 32), dim3(256), 0, ws, gp + h->goff[0],
                        (unsigned short*)h->bW0, h->n_in, h->n_nodes, h->KP0);
-  if (g9_fused_on(h)) hipLaunchKernelGGL(k_g9_wimg, dim3(1), dim3(256), 0, ws, gp + h->goff[8], (unsigned short*)h->bW9I);
+  if (g9_fused_on(h) || g9_fused_t_on(h)) hipLaunchKernelGGL(k_g9_wimg, dim3(1), dim3(256), 0, ws, gp + h->goff[8], (unsigned short*)h->bW9I);
   for (int l = 1; l <= 3; ++l) {
     const float* Wl = gp + h->goff[2 * l];
     const long cc = (long)h->gch[l - 1] * h->gch[l];
@@ -1368,14 +1370,28 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     }
     if (upconv_slab_t_on(h, l)) {   // block 3, bf16 storage, planes larger than 8 x 8: (h, w) tiles with their halo resident, K in two halves
       ProfScope ps(h, RDGAN_TAG_GCONV3_FWD, st);
-      LaunchScope ls(h, pl, RD_KIND_CONV, B, plan_flops(h->plans[pl], B), st);
-      RD_KNAME(h, "k_upconv_slab_t16<bf16>");
-      h->flops_acc += plan_flops(h->plans[pl], B);
+      const bool g9t = g9_fused_t_on(h);
+      const double fl3 = plan_flops(h->plans[pl], B) + (g9t ? 2.0 * B * h->gpix[3] * 64 * 27 : 0.0);
+      LaunchScope ls(h, pl, RD_KIND_CONV, B, fl3, st);
+      RD_KNAME(h, g9t ? "k_upconv_slab_t16<bf16, +conv 64->1>" : "k_upconv_slab_t16<bf16>");
+      h->flops_acc += fl3;
       const int Hs = h->gdim[2][1], Ws = h->gdim[2][2];
       const long items = (long)B * 6 * (Hs / 8) * (Ws / 8);
-      RD_TRY(ensure_lds(h, (const void*)k_upconv_slab_t16, RD_UPT_LDS));
-      hipLaunchKernelGGL(k_upconv_slab_t16, dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_UPT_LDS, st, (const rd_bf16_t*)hs[l - 1],
-                         (const rd_bf16_t*)h->bW3T, gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B, Hs, Ws, (float*)nullptr);
+      const dim3 tg((unsigned)std::min<long>(items, 512));
+      float* nodbg = nullptr;
+      if (g9t && keep_h3) {
+        RD_TRY(ensure_lds(h, (const void*)k_upconv_slab_t16<true, true>, RD_UPT_LDS_G9));
+        hipLaunchKernelGGL((k_upconv_slab_t16<true, true>), tg, dim3(256), RD_UPT_LDS_G9, st, (const rd_bf16_t*)hs[l - 1], (const rd_bf16_t*)h->bW3T,
+                           gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B, Hs, Ws, nodbg, (const unsigned short*)h->bW9I, h->P9);
+      } else if (g9t) {
+        RD_TRY(ensure_lds(h, (const void*)k_upconv_slab_t16<true, false>, RD_UPT_LDS_G9));
+        hipLaunchKernelGGL((k_upconv_slab_t16<true, false>), tg, dim3(256), RD_UPT_LDS_G9, st, (const rd_bf16_t*)hs[l - 1], (const rd_bf16_t*)h->bW3T,
+                           gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B, Hs, Ws, nodbg, (const unsigned short*)h->bW9I, h->P9);
+      } else {
+        RD_TRY(ensure_lds(h, (const void*)k_upconv_slab_t16<false, true>, RD_UPT_LDS));
+        hipLaunchKernelGGL((k_upconv_slab_t16<false, true>), tg, dim3(256), RD_UPT_LDS, st, (const rd_bf16_t*)hs[l - 1], (const rd_bf16_t*)h->bW3T,
+                           gp + h->goff[2 * l + 1], (rd_bf16_t*)hs[l], rs[l], B, Hs, Ws, nodbg, (const unsigned short*)nullptr, (float*)nullptr);
+      }
       RD_CHECK(h, hipGetLastError());
       continue;
     }
@@ -1411,6 +1427,16 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
     hipLaunchKernelGGL((k_tapsum_softmax12<RDGAN_NHOURS>), dim3((unsigned)((ncol / 4 + 63) / 64)), dim3(256), 0, st, h->P9,
                        gp + h->goff[9], out, B, h->d_flag);
+  } else if (g9_fused_t_on(h)) {
+    // the same behind the tiled kernel: main sums per tile + the halo terms of the neighbouring tiles
+    ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
+    {
+      const int TH = h->gdim[2][1] / 8, TW = h->gdim[2][2] / 8;
+      const long nthr = (long)B * 6 * TH * TW * 24 * 32;
+      hipLaunchKernelGGL(k_g9_halo_fold, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, h->P9, B, TH, TW);
+    }
+    hipLaunchKernelGGL((k_tapsum_softmax12t<RDGAN_NHOURS>), dim3((unsigned)((ncol / 4 + 63) / 64)), dim3(256), 0, st, h->P9,
+                       gp + h->goff[9], out, B, h->gdim[2][1], h->gdim[2][2], h->d_flag);
   } else if (!a16 && h->tapgather && h->edge_kernels == 1 && g9w_mfma_ok(nd, (long)B * h->gpix[3])) {
     // fp32 storage: pipelined streaming kernel on 128-pixel tiles (rdgan_edge.hip.h), nine kw-sums per grid point
     ProfScope ps(h, RDGAN_TAG_GCONV_FWD, st);
@@ -2513,12 +2539,12 @@ extern "C" int rdgan_op_upconv_slab_t16(const float* x, const float* w, const fl
   if (rc == 0) {
     hipLaunchKernelGGL(k_collapse_weights, dim3(ew_blocks(16L * 128 * 64)), dim3(256), 0, st, w, wc, 128 * 64);
     hipLaunchKernelGGL(k_upconv_wimg_t, dim3(256), dim3(256), 0, st, wc, (unsigned short*)wi);
-    rc = ensure_lds(nullptr, (const void*)k_upconv_slab_t16, RD_UPT_LDS);
+    rc = ensure_lds(nullptr, (const void*)k_upconv_slab_t16<false, true>, RD_UPT_LDS);
   }
   if (rc == 0) {
     const long items = (long)B * 6 * (H / 8) * (W / 8);
-    hipLaunchKernelGGL(k_upconv_slab_t16, dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_UPT_LDS, st, (const rd_bf16_t*)xb,
-                       (const rd_bf16_t*)wi, bias, (rd_bf16_t*)yb, rinv, B, H, W, dbg);
+    hipLaunchKernelGGL((k_upconv_slab_t16<false, true>), dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_UPT_LDS, st, (const rd_bf16_t*)xb,
+                       (const rd_bf16_t*)wi, bias, (rd_bf16_t*)yb, rinv, B, H, W, dbg, (const unsigned short*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(ny)), dim3(256), 0, st, (const rd_bf16_t*)yb, y, ny);
     rc = (int)hipGetLastError();
   }

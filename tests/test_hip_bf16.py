@@ -379,19 +379,23 @@ def test_upconv2_slab_kernel_equals_the_streaming_gemm_to_one_bf16_ulp(B):
         eng.close()
 
 
-@pytest.mark.parametrize("B", [1, 7, 96, 200])
-def test_fused_last_conv_equals_the_separate_pass(B):
+@pytest.mark.parametrize("nd,B", [(16, 1), (16, 7), (16, 96), (16, 200), (32, 3), (64, 2), (64, 9), (48, 1)])
+def test_fused_last_conv_equals_the_separate_pass(B, nd):
     """"g9_fused" (default on with the block-3 slab kernel, ndomain 16): the tap products of the generator's last Conv3D (64 -> 1,
     T:345) come out of the slab kernel's epilogue -- the rows' bf16 values against the bf16 kernel on the matrix pipe, exactly the
     products the separate pass over h3 (k_g9_fwd) forms, summed over (kh, kw) per source parity class and over kd / the classes in
     k_tapsum_softmax12 -- instead of reading h3 back.  Same products, another fp32 summation order: logits agree to fp32
     rounding, so the fractions agree to ~1e-6 of the largest one; h3 and 1/l2 (still stored by rdgan_gen_forward and by the
     generator step) are bit-identical; the critic step, which with the fused form does not store h3 at all, gives the same
-    gradient slab up to that rounding; every path is run-to-run deterministic."""
-    eng = Engine(ndomain=16, max_batch=B)
+    gradient slab up to that rounding; every path is run-to-run deterministic.
+    ndomain 32 / 64 (round 4): the same inside the TILED block-3 kernel (k_upconv_slab_t16<G9>), whose tiles exchange their edge sums as
+    halo terms (rows, columns, corners) through k_tapsum_softmax12t; ndomain 48 (24 x 24 source planes: 3 x 3 tiles, one of them
+    interior) compares against the generic column GEMM, which multiplies the bf16 rows by the fp32 kernel where the fused form (like
+    k_g9_fwd) rounds the kernel to bf16: 2^-9 per product, 1e-3 of the largest fraction."""
+    eng = Engine(ndomain=nd, max_batch=B)
     try:
-        g, d = _params(16, 71)
-        x, cond, z = ot.synthetic_batch(min(B, 64), 16, 61)
+        g, d = _params(nd, 71)
+        x, cond, z = ot.synthetic_batch(min(B, 64), nd, 61)
         rep = lambda a: np.concatenate([a] * (B // a.shape[0] + 1))[:B]
         x, cond, z = rep(x), rep(cond), rep(z)
         gs, ds = eng.to_slab(g), eng.to_slab(d)
@@ -400,7 +404,7 @@ def test_fused_last_conv_equals_the_separate_pass(B):
         for fused in (0, 1):
             eng.set_option("g9_fused", fused)
             out = eng.gen_forward(gs, dev(z), dev(cond)).clone()
-            h3 = eng.debug_activation(3, (B, 24, 16, 16, 64)).clone()
+            h3 = eng.debug_activation(3, (B, 24, nd, nd, 64)).clone()
             assert torch.equal(out, eng.gen_forward(gs, dev(z), dev(cond)))
             cg = eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 0).clone()        # dropout off: no mask can flip
             assert torch.equal(cg, eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 0))
@@ -410,14 +414,15 @@ def test_fused_last_conv_equals_the_separate_pass(B):
         assert bool(torch.isfinite(o1).all()) and bool(torch.isfinite(c1).all()) and bool(torch.isfinite(g1).all())
         assert torch.equal(h0, h1)
         eo = float((o1 - o0).abs().max()) / float(o0.max())
-        print(f"B {B} fused vs separate last conv: fractions differ by {eo:.2e} of the largest")
-        assert eo < 2e-5, eo
+        print(f"nd {nd} B {B} fused vs separate last conv: fractions differ by {eo:.2e} of the largest")
+        assert eo < (3e-3 if nd == 48 else 2e-5), eo
+        assert not torch.equal(o0, o1)             # (another summation order: the fused path really ran)
         np.testing.assert_allclose(o1.sum(dim=1).cpu().numpy(), 1.0, rtol=0, atol=2e-6)
         for a, b, what in ((c0, c1, "critic"), (g0, g1, "generator")):
             a, b = a.cpu().numpy(), b.cpu().numpy()
             e = np.abs(a - b).max() / np.abs(a).max()
             print(f"   {what}-step slab: {e:.2e} of the largest entry")
-            assert e < 2e-3, (what, e)           # a LeakyReLU input within the logits' rounding of zero may change branch
+            assert e < (2e-2 if nd == 48 else 2e-3), (what, e)           # a LeakyReLU input within the logits' rounding of zero may change branch
     finally:
         eng.close()
 
