@@ -155,9 +155,18 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * (kh, kw) and the hour taps inside the work item; k_tapsum_softmax12 adds the source parity classes and the neighbouring items and
  * takes the softmax.  No pass over block 3's output (k_g9_fwd); a critic step does not store that output at all.  Same bf16 products
  * as 0, another fp32 summation order: fractions agree to ~3e-7 of the largest.
+ * "upconv_slab_t" (default 1; bf16 storage mode, collapsed form, ndomain > 16 whose block-3 source planes are multiples of 8 x 8:
+ * 32, 48, 64, ... -- the large-domain variant L:355-358): block 3 forward in the TILED slab kernel k_upconv_slab_t16: (h, w) tiles of
+ * 8 x 8 source positions with their halo resident in LDS, the K loop in two channel halves (rdgan_upconv16t.hip.h); with "g9_fused"
+ * the last conv's tap products leave its epilogue too, the tiles' edge sums as halo terms (k_g9_halo_fold, k_tapsum_softmax12t).
+ * One bf16 ulp from the streaming GEMM; fractions within 2e-5 of the separate pass.
+ * "dense_skinny" (default 1; bf16 storage mode with "dense16", handles of max_batch <= 128): the Dense layer by k_dense16_skinny --
+ * weights and input rows streamed in MFMA-fragment order, no LDS (the large domain's 415 MB kernel at 3.4-3.7 TB/s).  One bf16 ulp.
  * "wgrad_boxes" (default 1; with "border_boxes"): the weight gradients of critic layers 2-4 that run in the streaming kernels (fp32
  * storage: all three; bf16 storage: the layers without a slab kernel) use the border-class boxes too: per-phase tile and split
  * counts, one fold per weight tap over every phase that lists it (k_wgrad_reduce_box).  Same products, same results to ~1e-9.
+ * ("d1_dgrad_fused" at ndomain > 16, multiples of 16: the same one-pass layer-1 input gradient on tiles of 24 x 16 x 8 input voxels,
+ * k_d1_dgrad_tile16; bit-identical to the column GEMM + col2im.)
  * "d1_fwd_sample" (default 1; bf16 storage mode, ndomain 16, one condition channel): forward and second sweep of the critic's first
  * layer with a sample's input volume resident in LDS (k_d1_fwd_sample16); the second sweep then takes its gate from the 2-bit codes
  * ("d2_gate_bits"; without them it keeps the tile kernel).  One bf16 ulp from 0 in ~4e-5 of the activations.

@@ -398,13 +398,25 @@ k_g9_halo_fold(float* __restrict__ Q12, int B, int TH, int TW) {
   const int q = ((ph ^ eh) << 1) | (pw ^ ew);
   float* It = Q12 + (long)(item - (unsigned)(th * TW + tw)) * RD_UPT_QITEM;  // tile (0, 0) of this (sample, plane pair)
   float* dst = It + (long)(th * TW + tw) * RD_UPT_QITEM + tp * 1024 + p * 256 + q * 64 + ly * 8 + lx;
-  float s = *dst;
-  for (int a = (tp > 2 ? tp - 2 : 0); a <= (tp < 3 ? tp : 3); ++a) {
+  // (all loads issued before the first add: with a data-dependent loop around them the launch was a chain of round trips, 48 us)
+  float rv[4], cv[4], kv[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
     const int kd = a + 2 - tp, pd = a & 1, pl = a >> 1;
-    const int base = RD_UPT_QMAIN + ((pd * 2 + pl) * 3 + kd) * 144 + p * 36;
-    if (row) s += It[(long)(nth * TW + tw) * RD_UPT_QITEM + base + (ew ? 16 + (pw ? 0 : 1) : 0) + lx];
-    if (col) s += It[(long)(th * TW + ntw) * RD_UPT_QITEM + base + (eh ? 25 : 8) + ly];
-    if (row && col) s += It[(long)(nth * TW + ntw) * RD_UPT_QITEM + base + 16 + (pw ? 8 : 0)];
+    const bool va = kd >= 0 && kd <= 2;
+    const int base = RD_UPT_QMAIN + ((pd * 2 + pl) * 3 + (va ? kd : 0)) * 144 + p * 36;
+    rv[a] = row && va ? It[(long)(nth * TW + tw) * RD_UPT_QITEM + base + (ew ? 16 + (pw ? 0 : 1) : 0) + lx] : 0.f;
+    cv[a] = col && va ? It[(long)(th * TW + ntw) * RD_UPT_QITEM + base + (eh ? 25 : 8) + ly] : 0.f;
+    kv[a] = row && col && va ? It[(long)(nth * TW + ntw) * RD_UPT_QITEM + base + 16 + (pw ? 8 : 0)] : 0.f;
+  }
+  float s = *dst;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int kd = a + 2 - tp;
+    if (kd < 0 || kd > 2) continue;
+    if (row) s += rv[a];
+    if (col) s += cv[a];
+    if (row && col) s += kv[a];
   }
   *dst = s;
 }
