@@ -371,6 +371,10 @@ int rdgan_op_d3_wgrad_slab16(const float* x, const float* dy, float* dW, int B, 
  * gx [B,11,7,7,64] = conv3d_input_grad(gy, w) * gate(aux), as fp32; gate = LeakyReLU'(aux), and with use_drop != 0 aux is read as
  * a stored post-dropout activation: +0.0 = dropped (gate 0), anything else kept (gate LeakyReLU'(aux) / 0.75). */
 int rdgan_op_d2_dgrad_slab16(const float* gy, const float* w, const float* aux, float* gx, int B, int use_drop, void* stream);
+/* The same through the tiled kernel of the larger domains (k_d2_dgrad_slab_t16; L:291-293): gy [B,6,OH,OW,128], aux and gx
+ * [B,11,2 OH - 1,2 OW - 1,64]; OH, OW multiples of 4 (ndomain 32 / 48 / 64: 8 / 12 / 16). */
+int rdgan_op_d2_dgrad_slab_t16(const float* gy, const float* w, const float* aux, float* gx, int B, int OH, int OW, int use_drop,
+                               void* stream);
 /* PixelNormalization + LeakyReLU(0.2) forward (T:255-266, T:333) and its backward. C in {64,128,256}. */
 int rdgan_op_pixelnorm_lrelu(const float* y, float* h, float* rinv, long npix, int C, void* stream);
 int rdgan_op_pixelnorm_lrelu_bwd(const float* gh, const float* h, const float* rinv, float* dy,

@@ -1526,6 +1526,11 @@ extern "C" int rdgan_check_numerics(rdgan_handle* h, void* stream) {
 // critic
 // ------------------------------------------------------------------------------------
 static bool d2_slab_on(const rdgan_handle* h) { return h->d2_slab && h->a16 && h->nd == 16; }
+// the same on tiles of 8 x 8 destination positions (k_d2_dgrad_slab_t16): ndomain 32, 48, 64, ... (layer 2's output grid a multiple of 4 x 4)
+static bool d2_slab_t_on(const rdgan_handle* h) {
+  return h->d2_slab && h->a16 && h->nd > 16 && h->nd % 16 == 0 && h->ddim[2][1] % 4 == 0 && h->ddim[2][2] % 4 == 0 && h->ddim[2][0] == 6 &&
+         h->ddim[1][1] == 2 * h->ddim[2][1] - 1 && h->ddim[1][2] == 2 * h->ddim[2][2] - 1 && h->dpad[1][0] == 1 && h->dpad[1][1] == 1 && h->dpad[1][2] == 1;
+}
 static bool d2_fwd_slab_on(const rdgan_handle* h) { return h->d2_fwd_slab && h->a16 && h->nd == 16; }
 static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st) {
   // (skipped when the forms in the workspace were built from these very weights: see rdgan_set_weight_versions)
@@ -1552,7 +1557,7 @@ static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st)
     hipLaunchKernelGGL(k_weights3_to_bf16, dim3(8, 8, 3 * 27), dim3(256), 0, st, a);
     if (d2_fwd_slab_on(h))
       hipLaunchKernelGGL(k_d2f_wimg, dim3(RD_D2F_KSTEPS), dim3(256), 0, st, dp + h->doff[2], (unsigned short*)h->bW2F);
-    if (d2_slab_on(h))
+    if (d2_slab_on(h) || d2_slab_t_on(h))
       hipLaunchKernelGGL(k_d2s_wimg, dim3((RD_D2S_KSTEPS * 2 * 64 + 255) / 256), dim3(256), 0, st, dp + h->doff[2], (unsigned short*)h->bW2S);
     hipLaunchKernelGGL(k_w1_to_bf16, dim3(ew_blocks(64L * h->ldp1)), dim3(256), 0, st, dp + h->doff[0], (rd_bf16_t*)h->bW1B,
                        27 * h->Cin, h->ldp1);
@@ -1712,6 +1717,21 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
       hipLaunchKernelGGL(k_d2_dgrad_slab16, dim3((unsigned)std::min((NBt + 1) / 2, 512)), dim3(256), RD_D2S_LDS, st,
                          (const rd_bf16_t*)h->du[2], (const rd_bf16_t*)h->bW2S, (const rd_bf16_t*)h->dh[1], (rd_bf16_t*)h->du[1], NBt,
                          use_drop, d2_gate_bits_on(h) && d1_gemm_ok(h) ? h->g1bits : nullptr);
+      RD_CHECK(h, hipGetLastError());
+      continue;
+    }
+    if (l == 2 && d2_slab_t_on(h)) {    // the same on tiles: two samples' 6 x 5 x 5 output-gradient positions per tile resident
+      ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+      const int one = PL_D2B;               // (FLOPs of the one-phase plan: the slab kernel multiplies every (position, tap) pair that lands inside)
+      LaunchScope ls(h, one, RD_KIND_CONV, NBt, plan_flops(h->plans[one], NBt), st);
+      RD_KNAME(h, "k_d2_dgrad_slab_t16<bf16>");
+      h->flops_acc += plan_flops(h->plans[one], NBt);
+      const int OH = h->ddim[2][1], OW = h->ddim[2][2];
+      const long items = (long)((NBt + 1) / 2) * (OH / 4) * (OW / 4);
+      RD_TRY(ensure_lds(h, (const void*)k_d2_dgrad_slab_t16, RD_D2T_LDS));
+      hipLaunchKernelGGL(k_d2_dgrad_slab_t16, dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_D2T_LDS, st,
+                         (const rd_bf16_t*)h->du[2], (const rd_bf16_t*)h->bW2S, (const rd_bf16_t*)h->dh[1], (rd_bf16_t*)h->du[1], NBt,
+                         OH, OW, use_drop);
       RD_CHECK(h, hipGetLastError());
       continue;
     }
@@ -2675,6 +2695,37 @@ extern "C" int rdgan_op_d2_dgrad_slab16(const float* gy, const float* w, const f
   if (rc == 0) {
     hipLaunchKernelGGL(k_d2_dgrad_slab16, dim3((unsigned)std::min((B + 1) / 2, 512)), dim3(256), RD_D2S_LDS, st, (const rd_bf16_t*)yb,
                        (const rd_bf16_t*)wi, (const rd_bf16_t*)ab, (rd_bf16_t*)xb, B, use_drop != 0);
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(nx)), dim3(256), 0, st, (const rd_bf16_t*)xb, gx, nx);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {yb, ab, xb, wi}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// The same through the TILED kernel (k_d2_dgrad_slab_t16): gy [B,6,OH,OW,128], aux / gx [B,11,2 OH - 1,2 OW - 1,64]; OH, OW multiples of 4.
+extern "C" int rdgan_op_d2_dgrad_slab_t16(const float* gy, const float* w, const float* aux, float* gx, int B, int OH, int OW, int use_drop,
+                                          void* stream) {
+  if (!gy || !w || !aux || !gx || B < 1 || OH < 4 || OW < 4 || (OH & 3) || (OW & 3)) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const long ny = (long)B * 6 * OH * OW * 128, nx = (long)B * 11 * (2 * OH - 1) * (2 * OW - 1) * 64;
+  if (nx * 2 >= 0x7FFFFFF0L) return -2;
+  void *yb = nullptr, *ab = nullptr, *xb = nullptr, *wi = nullptr;
+  int rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc(&ab, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&wi, (long)RD_D2S_KSTEPS * 2 * 64 * 16);
+  if (rc == 0) rc = launch_to_bf16(nullptr, gy, yb, ny, st);
+  if (rc == 0) rc = launch_to_bf16(nullptr, aux, ab, nx, st);
+  if (rc == 0) rc = (int)hipMemsetAsync(xb, 0xFF, nx * 2, st);          // (NaN pattern: every destination must be written)
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_d2s_wimg, dim3((RD_D2S_KSTEPS * 2 * 64 + 255) / 256), dim3(256), 0, st, w, (unsigned short*)wi);
+    rc = ensure_lds(nullptr, (const void*)k_d2_dgrad_slab_t16, RD_D2T_LDS);
+  }
+  if (rc == 0) {
+    const long items = (long)((B + 1) / 2) * (OH / 4) * (OW / 4);
+    hipLaunchKernelGGL(k_d2_dgrad_slab_t16, dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_D2T_LDS, st, (const rd_bf16_t*)yb,
+                       (const rd_bf16_t*)wi, (const rd_bf16_t*)ab, (rd_bf16_t*)xb, B, OH, OW, use_drop != 0);
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(nx)), dim3(256), 0, st, (const rd_bf16_t*)xb, gx, nx);
     rc = (int)hipGetLastError();
   }

@@ -66,13 +66,31 @@ __constant__ int rd_d2s_tiles[4][4] = {
   {RD_D2S_T(4, 0, 2), RD_D2S_T(4, 64, 2), RD_D2S_T(6, 0, 3), RD_D2S_T(6, 96, 2)},
 };
 
+// Geometry of the TILED variant (k_d2_dgrad_slab_t16, round 4: domains larger than 16 x 16): an item is the same (h, w) tile of 8 x 8
+// destination positions of TWO samples; per sample the 6 x 5 x 5 output-gradient positions the tile's taps reach are resident
+// (150 rows; position (od, i, j) = source (od, oh0 + i, ow0 + j)), so a tap is a shifted read with strides 25 / 5 / 1.
+struct RdD2sGeom {
+  int last_h, last_w;      // the tile is the last one along h / w: 7 destination positions there (sub-grid 3 + parity instead of 4)
+  int IH, IW;              // destination grid (layer 1's output): 11 x IH x IW positions per sample
+  int h0, w0;              // first destination position of the tile (8 ti, 8 tj)
+};
+#define RD_D2T_SROWS 150                              // resident source positions per sample of an item: 6 x 5 x 5
+#define RD_D2T_IMG (RD_D2S_S * RD_D2T_SROWS * 256)
+#define RD_D2T_ZERO RD_D2T_IMG
+#define RD_D2T_LDS (RD_D2T_IMG + 256)
+
 // one tile: rows row0 .. row0 + 32 MB - 1 of phase cls, all 64 channels
-template <int MB>
+template <int MB, bool TILED = false>
 __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, unsigned wvoff, int cls, int row0, int ns, long b0,
                                             const rd_bf16_t* __restrict__ aux, rd_bf16_t* __restrict__ out, int use_drop,
-                                            int l31, int lhalf, const unsigned char* __restrict__ gbits) {
+                                            int l31, int lhalf, const unsigned char* __restrict__ gbits, const RdD2sGeom G = RdD2sGeom()) {
+  constexpr int SROWS = TILED ? RD_D2T_SROWS : RD_D2S_SROWS, SD = TILED ? 25 : 16, SH = TILED ? 5 : 4;
+  constexpr int ZERO = TILED ? RD_D2T_ZERO : RD_D2S_ZERO;
   const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
-  const int cd = 5 + pd, chh = 3 + ph, cw = 3 + pw;            // the phase's sub-grid (positions 2 l + 1 - parity)
+  // the phase's sub-grid (positions 2 l + 1 - parity): 3 + parity where the destination extent is 7, 4 in a full tile of 8
+  const int cd = 5 + pd, chh = (!TILED || G.last_h) ? 3 + ph : 4, cw = (!TILED || G.last_w) ? 3 + pw : 4;
+  const int IH = TILED ? G.IH : 7, IW = TILED ? G.IW : 7, OPOS = TILED ? 11 * G.IH * G.IW : RD_D2S_OPOS;
+  const int h0 = TILED ? G.h0 : 0, w0 = TILED ? G.w0 : 0;
   const int chw = chh * cw, cnt = cd * chw;
   const int rows = ns * cnt;
   const int ntaps = 8 >> (pd + ph + pw);
@@ -85,8 +103,8 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
     const int s = r >= cnt ? 1 : 0;
     const int p = r - s * cnt;
     const int ld = p / chw, q = p - ld * chw, lh = q / cw, lw = q - lh * cw;
-    srow[mb] = r < rows ? s * RD_D2S_SROWS + ld * 16 + lh * 4 + lw : -1;
-    orow[mb] = ((int)b0 + s) * RD_D2S_OPOS + ((2 * ld + 1 - pd) * 7 + 2 * lh + 1 - ph) * 7 + 2 * lw + 1 - pw;
+    srow[mb] = r < rows ? s * SROWS + ld * SD + lh * SH + lw : -1;
+    orow[mb] = ((int)b0 + s) * OPOS + ((2 * ld + 1 - pd) * IH + h0 + 2 * lh + 1 - ph) * IW + w0 + 2 * lw + 1 - pw;
   }
   f32x16 acc[MB][2];
 #pragma unroll
@@ -110,12 +128,12 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
     const int jh = ph ? 0 : (rem & 1); rem >>= ph ? 0 : 1;
     const int jd = pd ? 0 : (rem & 1);
     // source offset of the tap: 1 - j on an axis of parity 0, 0 on an axis of parity 1
-    const int shift = (pd ? 0 : 1 - jd) * 16 + (ph ? 0 : 1 - jh) * 4 + (pw ? 0 : 1 - jw);
+    const int shift = (pd ? 0 : 1 - jd) * SD + (ph ? 0 : 1 - jh) * SH + (pw ? 0 : 1 - jw);
     int abase[MB], aswz[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int rs = srow[mb] + shift;
-      abase[mb] = srow[mb] >= 0 ? rs * 256 : RD_D2S_ZERO;
+      abase[mb] = srow[mb] >= 0 ? rs * 256 : ZERO;
       aswz[mb] = srow[mb] >= 0 ? ((rs & 15) ^ lhalf) : lhalf;
     }
     u32x4_t afr[2][MB];
@@ -178,14 +196,14 @@ __device__ __forceinline__ void rd_d2s_tile(const char* lds, const char* wimg, u
   if (gbits) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
-      gcode[mb] = *(const u32x4_t*)(gbits + (long)(srow[mb] >= 0 ? orow[mb] : (int)b0 * RD_D2S_OPOS) * 16);
+      gcode[mb] = *(const u32x4_t*)(gbits + (long)(srow[mb] >= 0 ? orow[mb] : (int)b0 * OPOS) * 16);
   } else {
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     // 16 bytes per lane (lane half h takes the 8-channel chunks 2 P + h), then each half hands the other the four channels it
     // does not own (the inverse of the store path below): 4 instead of 8 load instructions per row block, 32 B per row and
     // instruction instead of 16
-    const rd_bf16_t* arow = aux + (long)(srow[mb] >= 0 ? orow[mb] : (int)b0 * RD_D2S_OPOS) * 64 + 8 * lhalf;
+    const rd_bf16_t* arow = aux + (long)(srow[mb] >= 0 ? orow[mb] : (int)b0 * OPOS) * 64 + 8 * lhalf;
 #pragma unroll
 #ifndef RD_D2S_ABL_NOGATE            // (diagnostic builds: no gate loads)
     for (int P = 0; P < 4; ++P) {
@@ -288,6 +306,77 @@ k_d2_dgrad_slab16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restrict_
       if (mbs == 0) break;
       if (mbs == 3) rd_d2s_tile<3>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, gbits);
       else rd_d2s_tile<2>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, gbits);
+    }
+  }
+}
+
+
+// ---- the same on tiles (round 4): domains larger than 16 x 16 (ndomain 32, 48, 64: multiples of 16; the large-domain variant
+// L:291-293 has 11 x 31 x 31 x 64 -> 6 x 16 x 16 x 128).  There the streaming kernel ran this launch at 0.13 of the bf16 roof (1.65 of a
+// 25.9 ms iteration at ndomain 64 / 64 samples).  Item = (pair of samples, tile of 8 x 8 destination positions); 2 x 150 output-gradient
+// rows resident (77 KB: two workgroups per CU), everything else -- weight stream, operand swap, gate + rounding in registers -- is
+// rd_d2s_tile.  Tiles of a phase over the item's two samples (interior tile: 5|6 x 4 x 4 positions per sample, 160 | 192 rows), dealt
+// to the four waves so that K loops (taps x row blocks) AND epilogues (row blocks, ~3.3 tap-blocks each) balance:
+// 24+6+4 / 11, 16+20+6 / 10, 20+12 / 11, 24+12 / 12.
+__constant__ int rd_d2t_tiles[4][4] = {
+  {RD_D2S_T(0, 0, 3), RD_D2S_T(7, 0, 3), RD_D2S_T(7, 96, 3), RD_D2S_T(3, 96, 2)},
+  {RD_D2S_T(0, 96, 2), RD_D2S_T(1, 0, 3), RD_D2S_T(1, 96, 2), RD_D2S_T(3, 0, 3)},
+  {RD_D2S_T(2, 0, 3), RD_D2S_T(2, 96, 2), RD_D2S_T(5, 0, 3), RD_D2S_T(5, 96, 3)},
+  {RD_D2S_T(4, 0, 3), RD_D2S_T(4, 96, 3), RD_D2S_T(6, 0, 3), RD_D2S_T(6, 96, 3)},
+};
+// gy [B][6][OH][OW][128] bf16 -> gx [B][11][IH][IW][64] bf16, IH = 2 OH - 1 = 8 TI - 1 (IW alike); aux = layer 1's stored output.
+// grid: persistent workgroups of 256 threads over ceil(B / 2) * TI * TJ items; dynamic LDS RD_D2T_LDS.
+__global__ void __launch_bounds__(256, 2)
+k_d2_dgrad_slab_t16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restrict__ wimg, const rd_bf16_t* __restrict__ aux,
+                    rd_bf16_t* __restrict__ gx, int B, int OH, int OW, int use_drop) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhalf = lane >> 5;
+  if (tid < 64) *(float*)(lds + RD_D2T_ZERO + tid * 4) = 0.f;
+  const unsigned wvoff = (unsigned)lane * 16u;
+  const int TI = OH >> 2, TJ = OW >> 2;
+  const int npair = (B + RD_D2S_S - 1) / RD_D2S_S, nitems = npair * TI * TJ;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int tj = item % TJ, ti = (item / TJ) % TI, pr = item / (TJ * TI);
+    const long b0 = (long)pr * RD_D2S_S;
+    const int ns = min(RD_D2S_S, B - (int)b0);
+    RdD2sGeom G;
+    G.last_h = ti == TI - 1; G.last_w = tj == TJ - 1; G.IH = 2 * OH - 1; G.IW = 2 * OW - 1; G.h0 = 8 * ti; G.w0 = 8 * tj;
+    __syncthreads();                                  // every wave has left the previous item (and the zero row is in)
+    {
+      // 2 x 150 rows of 256 B: 75 DMA instructions of 1 KB (4 rows), 19 per wave; chunk swizzle c ^ (row & 15) on the source side
+      const __amdgpu_buffer_rsrc_t rs = rd_make_rsrc((const float*)(gy + b0 * ((long)6 * OH * OW * 128)));
+      int lq = lane;
+      asm volatile("" : "+v"(lq));                    // (per-lane geometry recomputed per item, not kept in registers across the tiles)
+#pragma unroll 1
+      for (int k = 0; k < 19; ++k) {
+        const int i = wave + 4 * k;                   // wave-uniform
+        if (i < 75) {
+          const int row = i * 4 + (lq >> 4);          // row of the image: sample s, position (od, i5, j5)
+          const int sidx = row / RD_D2T_SROWS, rr = row - sidx * RD_D2T_SROWS;
+          const int od = rr / 25, r2 = rr - od * 25, i5 = r2 / 5, j5 = r2 - i5 * 5;
+          const int oh = 4 * ti + i5, ow = 4 * tj + j5;
+          const int c_log = (lq & 15) ^ (row & 15);
+          const bool ok = sidx < ns && oh < OH && ow < OW;
+          unsigned voff = ok ? (unsigned)((((sidx * 6 + od) * OH + oh) * OW + ow) * 256 + c_log * 16) : RD_OOB;
+          asm volatile("" : "+v"(voff));
+          rd_lds_dma16(rs, (float*)(lds + i * 1024), (int)voff, 0);
+        }
+      }
+    }
+    rd_dma_landed();
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      const int desc = rd_d2t_tiles[wave][t];
+      const int cls = desc & 15, row0 = (desc >> 4) & 255, mbs = desc >> 12;
+      // (a tile that starts behind the phase's last row -- border tiles, a single sample -- has nothing to do)
+      const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+      const int cnt = (5 + pd) * (G.last_h ? 3 + ph : 4) * (G.last_w ? 3 + pw : 4);
+      if (row0 >= ns * cnt) continue;
+      if (mbs == 3) rd_d2s_tile<3, true>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, nullptr, G);
+      else rd_d2s_tile<2, true>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, nullptr, G);
     }
   }
 }

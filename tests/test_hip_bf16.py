@@ -177,17 +177,19 @@ def test_tiled_slab_kernel_equals_the_streaming_gemm_to_one_bf16_ulp(nd, B):
         eng.close()
 
 
-@pytest.mark.parametrize("B", [5, 64])
-def test_d2_slab_kernel_equals_the_streaming_gemm(B):
+@pytest.mark.parametrize("nd,B", [(16, 5), (16, 64), (32, 3), (64, 2), (48, 1)])
+def test_d2_slab_kernel_equals_the_streaming_gemm(B, nd):
     """"d2_slab" (default on at ndomain 16): the input gradient of critic layer 2 in the slab kernel k_d2_dgrad_slab16 against the
     streaming bf16 GEMM of the same engine: the same bf16 products in the same tap and k order, fp32 accumulation, the same
     dropout counter, one rounding to bf16 -- the whole critic-step gradient slab (layer 1's weight gradient and, through the
     penalty's input gradient, everything else hangs on that tensor) and the losses agree bit for bit; so does the generator
-    step, whose critic backward runs the same launch at B samples instead of 3 B."""
-    eng = Engine(ndomain=16, max_batch=B)
+    step, whose critic backward runs the same launch at B samples instead of 3 B.
+    ndomain 32 / 48 / 64 (round 4): the same on tiles of 8 x 8 destination positions (k_d2_dgrad_slab_t16; odd 3 B: a last item of
+    one sample; interior, edge and corner tiles)."""
+    eng = Engine(ndomain=nd, max_batch=B)
     try:
-        g, d = _params(16, 57)
-        x, cond, z = ot.synthetic_batch(B, 16, 49)
+        g, d = _params(nd, 57)
+        x, cond, z = ot.synthetic_batch(B, nd, 49)
         gs, ds = eng.to_slab(g), eng.to_slab(d)
         eng.set_option("bf16", 1)
         res = {}
@@ -201,7 +203,7 @@ def test_d2_slab_kernel_equals_the_streaming_gemm(B):
         for a, b, n, what in ((res[0][0], res[1][0], eng.n_critic, "critic"), (res[0][1], res[1][1], eng.n_gen, "gen")):
             e = float((a[:n] - b[:n]).abs().max() / a[:n].abs().max())
             le = float((a[n:n + 4] - b[n:n + 4]).abs().max())
-            print(f"B {B} {what}-step gradients, d2_slab 1 vs 0: {e:.2e} of the largest entry; losses differ by {le:.2e}")
+            print(f"nd {nd} B {B} {what}-step gradients, d2_slab 1 vs 0: {e:.2e} of the largest entry; losses differ by {le:.2e}")
             assert e < 2e-3 and le < 1e-3 * (1.0 + float(a[n:n + 4].abs().max())), (what, e, le)
     finally:
         eng.close()

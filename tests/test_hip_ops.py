@@ -365,6 +365,45 @@ def test_d2_dgrad_slab_kernel_vs_oracle(B):
         np.testing.assert_array_equal(gx.cpu().numpy(), want.astype(np.float32)), tap
 
 
+@pytest.mark.parametrize("B,OH,OW", [(1, 8, 8), (3, 4, 12), (2, 16, 16), (2, 12, 4)])
+def test_d2_dgrad_slab_tiled_kernel_vs_oracle(B, OH, OW):
+    """k_d2_dgrad_slab_t16 alone (rdgan_op_d2_dgrad_slab_t16): the same input gradient on the larger domains (L:291-293: 6 x 16 x 16 x
+    128 -> 11 x 31 x 31 x 64 at ndomain 64), tiles of 8 x 8 destination positions, against the definition in fp64 on the bf16-rounded
+    operands; every destination written (the buffer starts as NaN), 2^-8 per element; rectangular grids expose a swapped axis, odd B a
+    last item of one sample; with and without dropout; one-hot probes of five taps at every position (tile and picture borders)."""
+    from oracle import rdgan_np as onp
+    rng = np.random.default_rng(400 + B + OH)
+    IH, IW = 2 * OH - 1, 2 * OW - 1
+    gy = rng.standard_normal((B, 6, OH, OW, 128)).astype(np.float32)
+    w = (0.05 * rng.standard_normal((3, 3, 3, 64, 128))).astype(np.float32)
+    aux = rng.standard_normal((B, 11, IH, IW, 64)).astype(np.float32)
+    gx_ref = onp.conv3d_input_grad(_bf16_round(gy).astype(np.float64), _bf16_round(w).astype(np.float64), (11, IH, IW), 2, (1, 1, 1))
+    slope = np.where(_bf16_round(aux) > 0, 1.0, 0.2)
+    gyd, wd = dev(gy), dev(w)
+    for seed in (0, 0x5DEECE66D):
+        want, a = gx_ref * slope, aux.copy()
+        if seed:
+            m = orng.dropout_scale_mask(seed, orng.STREAM_D1, want.shape)
+            a[m == 0] = 0.0
+            want = gx_ref * np.where(_bf16_round(a) > 0, 1.0, 0.2) * m
+        gx = torch.full((B, 11, IH, IW, 64), float("nan"), device="cuda")
+        ad = dev(a)
+        assert lib().rdgan_op_d2_dgrad_slab_t16(ptr(gyd), ptr(wd), ptr(ad), ptr(gx), B, OH, OW, int(seed != 0), stream()) == 0
+        got = gx.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(got))
+        np.testing.assert_allclose(got, want, rtol=2.0 ** -8 + 1e-5, atol=1e-5 * np.abs(want).max())
+    gy1 = np.zeros((1, 6, OH, OW, 128), np.float32); gy1[..., 77] = (np.arange(6 * OH * OW).reshape(1, 6, OH, OW) % 61) + 1
+    a1 = np.ones((1, 11, IH, IW, 64), np.float32)
+    for tap in (0, 13, 26, 5, 21):
+        w1 = np.zeros((3, 3, 3, 64, 128), np.float32); w1[tap // 9, (tap // 3) % 3, tap % 3, 9, 77] = 1.0
+        want = onp.conv3d_input_grad(gy1.astype(np.float64), w1.astype(np.float64), (11, IH, IW), 2, (1, 1, 1))
+        gx = torch.full((1, 11, IH, IW, 64), float("nan"), device="cuda")
+        g1d, w1d, a1d = dev(gy1), dev(w1), dev(a1)
+        assert lib().rdgan_op_d2_dgrad_slab_t16(ptr(g1d), ptr(w1d), ptr(a1d), ptr(gx), 1, OH, OW, 0, stream()) == 0
+        np.testing.assert_array_equal(gx.cpu().numpy(), want.astype(np.float32)), tap
+    assert lib().rdgan_op_d2_dgrad_slab_t16(ptr(g1d), ptr(w1d), ptr(a1d), ptr(gx), 1, 6, 8, 0, stream()) == -2       # OH % 4
+
+
 @pytest.mark.parametrize("B", [1, 3, 12])
 def test_upconv_wgrad_slab_kernel_vs_definition(B):
     """k_upconv_wgrad_slab16 alone (rdgan_op_upconv_wgrad_slab16): the collapsed weight gradient of generator block 3 (backward of
