@@ -881,7 +881,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         carve(p, 4L * 64 * 4 + 8); h->bW9I = p;
         carve(p, (long)RD_UP2_KSTEPS * 4 * 64 * 4 + 8); h->bW2I = p;
         carve(p, (long)RD_D2S_KSTEPS * 2 * 64 * 4 + 8); h->bW2S = p;
-        if (nd == 16) { carve(p, NB * h->dL[1] * 4 + 8); if (pass == 1) h->g1bits = (unsigned char*)p; }
+        if (nd % 16 == 0) { carve(p, NB * h->dL[1] * 4 + 8); if (pass == 1) h->g1bits = (unsigned char*)p; }     // (the domains with a layer-2 input-gradient slab kernel)
         carve(p, (long)RD_D2F_KSTEPS * 4 * 64 * 4 + 8); h->bW2F = p;
       }
       carve(h->fdU, 48L * 256 * 256); carve(h->fUT, 48L * 256 * 256);
@@ -1574,7 +1574,9 @@ static inline const float* d1_weights(const rdgan_handle* h, const float* dp) {
 
 // First critic layer as one K = 64 GEMM per tile (rdgan_edge.hip.h): one condition channel (2 floats per voxel), any ndomain
 static bool d1_gemm_ok(const rdgan_handle* h) { return h->edge_kernels && h->CP == 2 && h->Cin == 2; }
-static bool d2_gate_bits_on(const rdgan_handle* h) { return h->d2_gate_bits && h->d2_slab && h->a16 && h->nd == 16 && h->g1bits; }
+static bool d2_gate_bits_on(const rdgan_handle* h) {
+  return h->d2_gate_bits && h->d2_slab && h->a16 && (h->nd == 16 || d2_slab_t_on(h)) && h->g1bits;
+}
 static int launch_d1_fwd(rdgan_handle* h, const float* in, const float* w, const float* bias, float* out, const float* aux, int NBt,
                          int mode, int use_drop, uint32_t key, uint32_t idx_base, hipStream_t st) {
   unsigned char* gbits = mode == 0 && d2_gate_bits_on(h) ? h->g1bits : nullptr;
@@ -1731,7 +1733,7 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
       RD_TRY(ensure_lds(h, (const void*)k_d2_dgrad_slab_t16, RD_D2T_LDS));
       hipLaunchKernelGGL(k_d2_dgrad_slab_t16, dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_D2T_LDS, st,
                          (const rd_bf16_t*)h->du[2], (const rd_bf16_t*)h->bW2S, (const rd_bf16_t*)h->dh[1], (rd_bf16_t*)h->du[1], NBt,
-                         OH, OW, use_drop);
+                         OH, OW, use_drop, d2_gate_bits_on(h) && d1_gemm_ok(h) ? h->g1bits : nullptr);
       RD_CHECK(h, hipGetLastError());
       continue;
     }
@@ -2725,7 +2727,7 @@ extern "C" int rdgan_op_d2_dgrad_slab_t16(const float* gy, const float* w, const
   if (rc == 0) {
     const long items = (long)((B + 1) / 2) * (OH / 4) * (OW / 4);
     hipLaunchKernelGGL(k_d2_dgrad_slab_t16, dim3((unsigned)std::min<long>(items, 512)), dim3(256), RD_D2T_LDS, st, (const rd_bf16_t*)yb,
-                       (const rd_bf16_t*)wi, (const rd_bf16_t*)ab, (rd_bf16_t*)xb, B, OH, OW, use_drop != 0);
+                       (const rd_bf16_t*)wi, (const rd_bf16_t*)ab, (rd_bf16_t*)xb, B, OH, OW, use_drop != 0, (const unsigned char*)nullptr);
     hipLaunchKernelGGL(k_bf16_to_f32, dim3(ew_blocks(nx)), dim3(256), 0, st, (const rd_bf16_t*)xb, gx, nx);
     rc = (int)hipGetLastError();
   }

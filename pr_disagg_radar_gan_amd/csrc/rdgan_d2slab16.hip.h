@@ -328,7 +328,7 @@ __constant__ int rd_d2t_tiles[4][4] = {
 // grid: persistent workgroups of 256 threads over ceil(B / 2) * TI * TJ items; dynamic LDS RD_D2T_LDS.
 __global__ void __launch_bounds__(256, 2)
 k_d2_dgrad_slab_t16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restrict__ wimg, const rd_bf16_t* __restrict__ aux,
-                    rd_bf16_t* __restrict__ gx, int B, int OH, int OW, int use_drop) {
+                    rd_bf16_t* __restrict__ gx, int B, int OH, int OW, int use_drop, const unsigned char* __restrict__ gbits = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,8 +375,8 @@ k_d2_dgrad_slab_t16(const rd_bf16_t* __restrict__ gy, const rd_bf16_t* __restric
       const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
       const int cnt = (5 + pd) * (G.last_h ? 3 + ph : 4) * (G.last_w ? 3 + pw : 4);
       if (row0 >= ns * cnt) continue;
-      if (mbs == 3) rd_d2s_tile<3, true>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, nullptr, G);
-      else rd_d2s_tile<2, true>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, nullptr, G);
+      if (mbs == 3) rd_d2s_tile<3, true>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, gbits, G);
+      else rd_d2s_tile<2, true>(lds, (const char*)wimg, wvoff, cls, row0, ns, b0, aux, gx, use_drop, l31, lhalf, gbits, G);
     }
   }
 }

@@ -638,6 +638,29 @@ def test_d2_gate_bits_change_nothing(B):
         eng.close()
 
 
+@pytest.mark.parametrize("nd", [32, 64])
+def test_d2_gate_bits_change_nothing_tiled(nd):
+    """the same codes feed the tiled layer-2 input-gradient kernel of the larger domains (k_d2_dgrad_slab_t16): critic and
+    generator steps equal bit for bit with the codes on and off, with and without dropout"""
+    B = 3
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 79)
+        x, cond, z = ot.synthetic_batch(B, nd, 69)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res = {}
+        for on in (0, 1):
+            eng.set_option("d2_gate_bits", on)
+            res[on] = (eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 45).clone(), eng.gen_grad(ds, gs, dev(z), dev(cond), 47).clone(),
+                       eng.gen_grad(ds, gs, dev(z), dev(cond), 0).clone())
+        for a, b in zip(res[0], res[1]):
+            assert bool(torch.isfinite(b).all())
+            assert torch.equal(a, b)
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:
