@@ -17,6 +17,7 @@
 #include "rdgan_gemm.hip.h"
 #include "rdgan_gemm_ws.hip.h"
 #include "rdgan_gemm_ws16.hip.h"
+#include "rdgan_gemm_f16.hip.h"
 #include "rdgan_upconv16.hip.h"
 #include "rdgan_upconv16b.hip.h"
 #include "rdgan_upconv16t.hip.h"
@@ -69,6 +70,8 @@ struct rdgan_handle : RdGeom {     // geometry + parameter layout: rdgan_hostpla
   void *bU[4], *bUT;
   void *bWF[5], *bWB[5];
   void *bG1F[4], *bG1B, *bW1B;
+  void *fWF[5], *fWB[5], *fG1F[4], *fG1B;    // the same images in fragment order (rdgan_gemm_f16.hip.h: rd_wfrag_index), written beside them
+  int conv_f16 = 1;               // 1: bf16 storage mode: the large gather GEMMs by k_conv_gemm_f16 (weights global -> VGPR, 256 x 128 tiles)
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
   void* bW3T = nullptr;           // weight image of the TILED slab kernel of generator block 3 (rdgan_upconv16t.hip.h): 1 MB, [phase][half][tap][j]
@@ -458,13 +461,65 @@ static int launch_conv_a16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
 
 static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>((n + per - 1) / per, 8192); }
 
-// bf16-operand conv GEMM (fp32 accumulate / output): src16 = bf16 NDHWC activations, w16 = bf16 weights [tap block][N][K]
+// k_conv_gemm_f16 (rdgan_gemm_f16.hip.h): when a launch may take it
+static bool conv_f16_ok(const rdgan_handle* h, const RdPlan& hp, int B, const RdEpi& epi) {
+  if (h && !h->conv_f16) return false;
+  if (hp.s_shift || hp.SC % 64 || hp.N % 128 || ((hp.N / 128) & (hp.N / 128 - 1)) || hp.w_rows_per_tap != hp.SC) return false;
+  if (!epi.out16 || epi.addt) return false;
+  if (epi.mode == RD_EPI_BIAS_PN_LRELU ? hp.N != 128 : epi.mode > RD_EPI_GATE_AUX) return false;
+  for (int i = 0; i < hp.nphases; ++i) if (hp.ph[i].ntaps > 64) return false;
+  // 256-row tiles: enough of them to fill the chip twice over, or a test forcing the kernel (conv_f16 = 2)
+  return (h && h->conv_f16 == 2) || !h || plan_tiles(hp, B, RD_F16_BM) * (hp.N / 128) >= 512;
+}
+static int launch_conv_f16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* wfrag, float* dst,
+                           const RdEpi& epi, hipStream_t st) {
+  const bool pn = epi.mode == RD_EPI_BIAS_PN_LRELU;
+  auto kern = pn ? k_conv_gemm_f16<true> : k_conv_gemm_f16<false>;
+  int maxtaps = 0;
+  for (int i = 0; i < hp.nphases; ++i) maxtaps = std::max(maxtaps, hp.ph[i].ntaps);
+  const int tg = maxtaps <= 4 ? 4 : 8;                 // (the streaming kernel's tap groups: same chunk order, same sums)
+  RD_KNAME(h, "k_conv_gemm_f16<256,128%s>", pn ? ",+pn" : "");
+  RD_TRY(ensure_lds(h, (const void*)kern, RD_F16_LDS));
+  long tm = plan_tiles(hp, B, RD_F16_BM);
+  if (tm <= 0) return 0;
+  long minL = hp.ph[0].L;
+  for (int i = 1; i < hp.nphases; ++i) minL = std::min<long>(minL, hp.ph[i].L);
+  if (std::min<long>(B, RD_F16_BM / minL + 2) * hp.src_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: source tile span exceeds 2 GiB");
+  if (std::min<long>(B, RD_F16_BM / minL + 2) * hp.dst_sample * 4 >= 0x7FFFFFF0L) return bad_arg(h, "conv: destination tile span exceeds 2 GiB");
+  RdEpi e2 = epi;
+  e2.ksplit = 1; e2.kpart = nullptr; e2.kstride = 0;
+  const long blocks = tm * (hp.N / 128);
+  const long total = (long)B * hp.dst_sample;
+  if (h && h->ws_ksplit > 1 && !pn && hp.d_cstride == hp.N) {        // tests: force a split
+    long nch = (long)hp.ph[0].ntaps * (hp.SC / 64);
+    for (int i = 1; i < hp.nphases; ++i) nch = std::min<long>(nch, (long)hp.ph[i].ntaps * (hp.SC / 64));
+    const long best = std::min<long>(h->ws_ksplit, std::max<long>(1, nch / 4));
+    if (best > 1 && (size_t)(best * total) <= h->kpartial_cap) { e2.ksplit = (int)best; e2.kpart = h->kpartial; e2.kstride = total; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)e2.ksplit), dim3(256), RD_F16_LDS, st, dp, B, (const rd_bf16_t*)src16,
+                     (const rd_bf16_t*)wfrag, (rd_bf16_t*)dst, e2, tg);
+  if (e2.ksplit > 1)
+    hipLaunchKernelGGL(k_splitk_finish<true>, dim3((unsigned)std::min<long>((total / 4 + 255) / 256, 2048)), dim3(256), 0, st, dst, total, hp.N, e2);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+// [T][N][K] bf16 -> fragment order (the twin image k_conv_gemm_f16 reads)
+static int launch_wfrag_image(rdgan_handle* h, const void* in, void* out, long T, int N, int K, hipStream_t st) {
+  hipLaunchKernelGGL(k_wfrag_image, dim3((unsigned)std::min<long>((T * N * K / 8 + 255) / 256, 2048)), dim3(256), 0, st,
+                     (const unsigned short*)in, (unsigned short*)out, T, N, K);
+  RD_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+// bf16-operand conv GEMM (fp32 accumulate / output): src16 = bf16 NDHWC activations, w16 = bf16 weights [tap block][N][K];
+// wfrag = the same weights in fragment order, or nullptr
 static int launch_conv16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* w16,
-                         float* dst, const RdEpi& epi, hipStream_t st, int tag) {
+                         float* dst, const RdEpi& epi, hipStream_t st, int tag, const void* wfrag = nullptr) {
   ProfScope ps(h, tag, st);
   LaunchScope ls(h, plan_index(h, hp), RD_KIND_CONV, B, plan_flops(hp, B), st);
   if (h) h->flops_acc += plan_flops(hp, B);
   if (hp.s_shift || hp.SC % 64 || hp.N % 64) return bad_arg(h, "conv16: needs SC % 64 == 0, N % 64 == 0, no folded upsample");
+  if (wfrag && conv_f16_ok(h, hp, B, epi)) return launch_conv_f16(h, hp, dp, B, src16, wfrag, dst, epi, st);
   const float* s = (const float*)src16; const float* w = (const float*)w16;
   if (hp.N % 128 == 0) return launch_conv_ws_cfg<128, 128, 2, 2, true>(h, hp, dp, B, s, w, 0, dst, epi, st);
   if (hp.N == 64 && plan_tiles(hp, B, 256) >= 512) {
@@ -875,6 +930,13 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
         h->bG1F[0] = nullptr;
         for (int l = 1; l <= 3; ++l) { carve(p, 32L * gch[l - 1] * gch[l] + 8); h->bG1F[l] = p; }
         carve(p, 32L * 256 * 256 + 8); h->bG1B = p;
+        h->fWF[0] = h->fWF[1] = h->fWB[0] = h->fWB[1] = h->fG1F[0] = nullptr;
+        for (int l = 2; l <= 4; ++l) {
+          carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->fWF[l] = p;
+          carve(p, 27L * dch[l - 1] * dch[l] / 2 + 8); h->fWB[l] = p;
+        }
+        for (int l = 1; l <= 3; ++l) { carve(p, 32L * gch[l - 1] * gch[l] + 8); h->fG1F[l] = p; }
+        carve(p, 32L * 256 * 256 + 8); h->fG1B = p;
         carve(p, 32L * h->ldp1 + 8); h->bW1B = p;
         carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3I = p;
         carve(p, 64L * 8 * 2 * 64 * 4 + 8); h->bW3T = p;
@@ -965,6 +1027,10 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_wgrad16")) { h->d1_wgrad16 = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "conv_f16")) {      // (the forms are rebuilt: their fragment-order twins exist only while the option is on)
+    if (value < 0 || value > 2) return bad_arg(h, "conv_f16: 0, 1 or 2 (2: regardless of the launch size)");
+    h->conv_f16 = value; h->ccache_ver = 0; h->gcache_ver = 0; return 0;
+  }
   if (!strcmp(name, "d2_fwd_slab")) { h->d2_fwd_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
   if (!strcmp(name, "d2_gate_bits")) { h->d2_gate_bits = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d2_slab")) { h->d2_slab = value ? 1 : 0; h->ccache_ver = 0; return 0; }
@@ -1228,7 +1294,10 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       if (upconv_slab_on(h, l)) hipLaunchKernelGGL(k_upconv_wimg, dim3(256), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW3I);
       else if (upconv_slab_t_on(h, l)) hipLaunchKernelGGL(k_upconv_wimg_t, dim3(256), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW3T);
       else if (upconv2_slab_on(h, l)) hipLaunchKernelGGL(k_upconv2_wimg, dim3(RD_UP2_KSTEPS), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW2I);
-      else if (a16) RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
+      else if (a16) {
+        RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
+        if (h->conv_f16) RD_TRY(launch_wfrag_image(h, h->bG1F[l], h->fG1F[l], 64, h->gch[l], h->gch[l - 1], ws));
+      }
     }
     if (ws != st) RD_CHECK(h, hipEventRecord(h->ev_g[l], ws));
   }
@@ -1408,7 +1477,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
     }
     if (a16) {     // collapsed form (64 taps) on the bf16 matrix pipe
       RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], h->bG1F[l], hs[l], ep, st,
-                           l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
+                           l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD, h->conv_f16 ? h->fG1F[l] : nullptr));
     } else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, hs[l - 1], Wl, h->gch[l], hs[l], ep, st,
                        l == 3 ? RDGAN_TAG_GCONV3_FWD : RDGAN_TAG_GCONV_FWD));
@@ -1555,6 +1624,11 @@ static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st)
       a.K[l - 2] = h->dch[l - 1]; a.N[l - 2] = h->dch[l];
     }
     hipLaunchKernelGGL(k_weights3_to_bf16, dim3(8, 8, 3 * 27), dim3(256), 0, st, a);
+    if (h->conv_f16)
+      for (int l = 2; l <= 4; ++l) {
+        RD_TRY(launch_wfrag_image(h, h->bWF[l], h->fWF[l], 27, h->dch[l], h->dch[l - 1], st));
+        RD_TRY(launch_wfrag_image(h, h->bWB[l], h->fWB[l], 27, h->dch[l - 1], h->dch[l], st));
+      }
     if (d2_fwd_slab_on(h))
       hipLaunchKernelGGL(k_d2f_wimg, dim3(RD_D2F_KSTEPS), dim3(256), 0, st, dp + h->doff[2], (unsigned short*)h->bW2F);
     if (d2_slab_on(h) || d2_slab_t_on(h))
@@ -1679,7 +1753,8 @@ static int critic_forward_impl(rdgan_handle* h, const float* dp, int NBt, uint64
                          (const rd_bf16_t*)h->bW2F, dp + h->doff[3], (rd_bf16_t*)h->dh[2], NBt, use_drop, ep.key, 0u);
       RD_CHECK(h, hipGetLastError());
     } else if (a16)
-      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->bWF[l], h->dh[l], ep, st, RDGAN_TAG_CRITIC_GEMM));
+      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, NBt, in, h->bWF[l], h->dh[l], ep, st, RDGAN_TAG_CRITIC_GEMM,
+                           h->conv_f16 ? h->fWF[l] : nullptr));
     else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
                        h->dch[l], h->dh[l], ep, st, RDGAN_TAG_CRITIC_GEMM));
@@ -1738,7 +1813,8 @@ static int critic_dgrad_chain(rdgan_handle* h, const float* dp, int NBt, int B, 
       continue;
     }
     if (a16)
-      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->bWB[l], h->du[l - 1], ep, st, RDGAN_TAG_CRITIC_GEMM));
+      RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->bWB[l], h->du[l - 1], ep, st, RDGAN_TAG_CRITIC_GEMM,
+                           h->conv_f16 ? h->fWB[l] : nullptr));
     else
     RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, NBt, h->du[l], h->DWT[l], h->dch[l - 1], h->du[l - 1], ep, st,
                        RDGAN_TAG_CRITIC_GEMM));
@@ -1882,7 +1958,8 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
         RD_TRY(launch_conv_a16(h, h->plans[pl], h->d_plans + pl, B, in, d1_weights(h, dp), h->dch[l], dst, ep, st,
                                RDGAN_TAG_CRITIC_GEMM, false, true));
       else if (a16)
-        RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, in, h->bWF[l], dst, ep, st, RDGAN_TAG_CRITIC_GEMM));
+        RD_TRY(launch_conv16(h, h->plans[pl], h->d_plans + pl, B, in, h->bWF[l], dst, ep, st, RDGAN_TAG_CRITIC_GEMM,
+                             h->conv_f16 ? h->fWF[l] : nullptr));
       else
       RD_TRY(launch_conv(h, h->plans[pl], h->d_plans + pl, B, in, l == 1 ? d1_weights(h, dp) : dp + h->doff[2 * (l - 1)],
                          h->dch[l], dst, ep, st, RDGAN_TAG_CRITIC_GEMM));
@@ -2223,9 +2300,11 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
         collapsed_dgrad_slice_map(map.src);
         hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 64), dim3(256), 0, st,
                            h->GWC[l], (unsigned short*)h->bG1B, cc, map);
+        if (h->conv_f16) RD_TRY(launch_wfrag_image(h, h->bG1B, h->fG1B, 64, h->gch[l - 1], h->gch[l], st));
         RdEpi eb = epi_make(RD_EPI_PLAIN);
         eb.out16 = 1;
-        RD_TRY(launch_conv16(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->bG1B, gups[l], eb, st, RDGAN_TAG_GCONV_DGRAD));
+        RD_TRY(launch_conv16(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->bG1B, gups[l], eb, st, RDGAN_TAG_GCONV_DGRAD,
+                             h->conv_f16 ? h->fG1B : nullptr));
       } else
       RD_TRY(launch_conv(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->GWD[l], h->gch[l - 1], gups[l],
                          epi_make(RD_EPI_PLAIN), st, RDGAN_TAG_GCONV_DGRAD));
@@ -2352,10 +2431,17 @@ extern "C" int rdgan_op_conv3d_bf16(const float* x, const float* w, const float*
   if (rc == 0) rc = launch_weights_to_bf16_t(nullptr, w, wb, 27, Cin, Cout, st);
   RdEpi ep = epi_make(bias ? RD_EPI_BIAS : RD_EPI_PLAIN, bias);
   ep.out16 = out_bf16 ? 1 : 0;
-  if (rc == 0) rc = launch_conv16(nullptr, tp.host, tp.dev, B, xb, wb, y, ep, st, -1);
+  void* wf = nullptr;
+  if (out_bf16 == 2) {       // the fragment kernel (k_conv_gemm_f16), which must accept the launch
+    if (!conv_f16_ok(nullptr, tp.host, B, ep)) rc = -2;
+    if (rc == 0) rc = (int)hipMalloc(&wf, nw * 2);
+    if (rc == 0) rc = launch_wfrag_image(nullptr, wb, wf, 27, Cout, Cin, st);
+  }
+  if (rc == 0) rc = launch_conv16(nullptr, tp.host, tp.dev, B, xb, wb, y, ep, st, -1, wf);
   if (rc == 0) rc = (int)hipStreamSynchronize(st);
   if (xb) (void)hipFree(xb);
   if (wb) (void)hipFree(wb);
+  if (wf) (void)hipFree(wf);
   return rc;
 }
 

@@ -37,9 +37,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT_LIB = os.path.join(ROOT, "pr_disagg_radar_gan_amd", "librdgan_hip.so")
 
 # kernels whose loads are issued from inline asm with hand-counted waits (rule II applies to SALU writers there too)
-HAND_SCHEDULED = re.compile(r"k_upconv_slab16|k_upconv2_slab16|k_d2_dgrad_slab16|k_d2_dgrad_slab_t16|k_d2_fwd_slab16|k_upconv_slab_t16|k_upconv2_slab_t16")
+HAND_SCHEDULED = re.compile(r"k_conv_gemm_f16|k_upconv_slab16|k_upconv2_slab16|k_d2_dgrad_slab16|k_d2_dgrad_slab_t16|k_d2_fwd_slab16|k_upconv_slab_t16|k_upconv2_slab_t16")
 # kernels DESIGN.md states run without scratch (sections 4.6-4.11): a spill there is a performance bug that looks like a result
-NO_SPILL = re.compile(r"k_upconv_slab16|k_upconv2_slab16|k_d2_dgrad_slab16|k_d2_dgrad_slab_t16|k_d2_fwd_slab16|k_upconv_wgrad_slab16|k_upconv2_wgrad_slab16|"
+NO_SPILL = re.compile(r"k_conv_gemm_f16|k_upconv_slab16|k_upconv2_slab16|k_d2_dgrad_slab16|k_d2_dgrad_slab_t16|k_d2_fwd_slab16|k_upconv_wgrad_slab16|k_upconv2_wgrad_slab16|"
                       r"k_d2_wgrad_slab16|k_d3_wgrad_slab16|k_d1_fwd_sample16|k_g9_bwd_mfma16|k_d1_dgrad_sample16|k_d1_wgrad16|"
                       r"k_upconv_slab_t16|k_upconv2_slab_t16")
 # scratch a NO_SPILL kernel may still use, with the reason (bytes)

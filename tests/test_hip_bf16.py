@@ -661,6 +661,47 @@ def test_d2_gate_bits_change_nothing_tiled(nd):
         eng.close()
 
 
+@pytest.mark.parametrize("nd,B,ksplit", [(16, 20, 0), (16, 70, 3), (8, 37, 0), (32, 5, 0), (64, 2, 0), (48, 1, 0)])
+def test_fragment_gemm_equals_the_streaming_gemm(nd, B, ksplit):
+    """"conv_f16" (default on; 2 = regardless of the launch size): the gather GEMMs of the bf16 mode with N % 128 == 0 by
+    k_conv_gemm_f16 -- 256 x 128 tiles, weights global -> VGPR from fragment-order images, epilogue in registers -- against
+    k_conv_gemm_ws of the same engine.  Same chunk order and k order, so every accumulator sees the same sequence of products:
+    forward output, critic step (LeakyReLU + dropout epilogues forward, gate epilogues backward, border boxes, parity phases) and
+    generator step are equal BIT FOR BIT wherever no PixelNorm runs inside the kernel (ndomain 8 / 16: block 2 is a slab kernel or has
+    its own pass); at ndomain 32 / 48 / 64 block 2's fused PixelNorm adds its 128 squares in another order (1/l2 differs by an ulp),
+    so those compare to one bf16 ulp forward and within the mode's noise in the steps.  ksplit: both kernels with K split three
+    ways through the partial slabs."""
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 81)
+        x, cond, z = ot.synthetic_batch(B, nd, 71)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        if ksplit:
+            eng.set_option("ws_ksplit", ksplit)
+        res, kernels = {}, {}
+        eng.profile_launches(True)
+        for v in (0, 2):
+            eng.set_option("conv_f16", v)
+            res[v] = (eng.gen_forward(gs, dev(z), dev(cond)).clone(), eng.critic_forward(ds, dev(x), dev(cond), 44).clone(),
+                      eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 45).clone(), eng.gen_grad(ds, gs, dev(z), dev(cond), 47).clone(),
+                      eng.gen_grad(ds, gs, dev(z), dev(cond), 0).clone())
+            kernels[v] = {r["kernel"] for r in eng.launch_table()}
+            eng.profile_launches(True)           # (resets the table)
+        assert not any("k_conv_gemm_f16" in k for k in kernels[0])
+        assert any("k_conv_gemm_f16" in k for k in kernels[2]), kernels[2]
+        exact = nd <= 16
+        for k, (a, b) in enumerate(zip(res[0], res[2])):
+            assert bool(torch.isfinite(b).all())
+            if exact or k == 1:                  # (the critic alone has no PixelNorm)
+                assert torch.equal(a, b), k
+            else:
+                scale = float(a.abs().max())
+                assert float((a - b).abs().max()) <= (1e-3 if k == 0 else 1e-1) * scale, (k, float((a - b).abs().max()), scale)
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:

@@ -74,6 +74,13 @@ def test_conv3d_bf16_operands(g):
     rc = lib().rdgan_op_conv3d_bf16(ptr(xd), ptr(wd), ptr(bd), ptr(y16), B, *dims, cin, cout, *od, stride, *pad, 1, stream())
     assert rc == 0
     assert torch.equal(y16, y.bfloat16())
+    # the same launch through the fragment kernel (k_conv_gemm_f16: weights global -> VGPR in fragment order, 256 x 128 tiles,
+    # epilogue in registers): same chunk and k order, so the same bits
+    if cout % 128 == 0:
+        y16f = torch.full((B,) + od + (cout,), float("nan"), device="cuda", dtype=torch.bfloat16)
+        rc = lib().rdgan_op_conv3d_bf16(ptr(xd), ptr(wd), ptr(bd), ptr(y16f), B, *dims, cin, cout, *od, stride, *pad, 2, stream())
+        assert rc == 0
+        assert torch.equal(y16f, y16)
 
 
 @pytest.mark.parametrize("g", GEOMS, ids=[g[0] for g in GEOMS])
