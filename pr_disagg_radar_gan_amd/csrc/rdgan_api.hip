@@ -468,8 +468,9 @@ static bool conv_f16_ok(const rdgan_handle* h, const RdPlan& hp, int B, const Rd
   if (!epi.out16 || epi.addt) return false;
   if (epi.mode == RD_EPI_BIAS_PN_LRELU ? hp.N != 128 : epi.mode > RD_EPI_GATE_AUX) return false;
   for (int i = 0; i < hp.nphases; ++i) if (hp.ph[i].ntaps > 64) return false;
-  // 256-row tiles: enough of them to fill the chip twice over, or a test forcing the kernel (conv_f16 = 2)
-  return (h && h->conv_f16 == 2) || !h || plan_tiles(hp, B, RD_F16_BM) * (hp.N / 128) >= 512;
+  // 256-row tiles, 512 resident at a time: below ~640 workgroups the streaming kernel (half the tile, its own K split) was the
+  // faster one on every launch measured (scratch/f16_ab.py); conv_f16 = 2 (tests): regardless
+  return (h && h->conv_f16 == 2) || !h || plan_tiles(hp, B, RD_F16_BM) * (hp.N / 128) >= 640;
 }
 static int launch_conv_f16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* wfrag, float* dst,
                            const RdEpi& epi, hipStream_t st) {
@@ -478,7 +479,7 @@ static int launch_conv_f16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   int maxtaps = 0;
   for (int i = 0; i < hp.nphases; ++i) maxtaps = std::max(maxtaps, hp.ph[i].ntaps);
   const int tg = maxtaps <= 4 ? 4 : 8;                 // (the streaming kernel's tap groups: same chunk order, same sums)
-  RD_KNAME(h, "k_conv_gemm_f16<256,128%s>", pn ? ",+pn" : "");
+  RD_KNAME(h, "k_conv_gemm_f16<256,128,bf16%s>", pn ? ",+pn" : "");
   RD_TRY(ensure_lds(h, (const void*)kern, RD_F16_LDS));
   long tm = plan_tiles(hp, B, RD_F16_BM);
   if (tm <= 0) return 0;

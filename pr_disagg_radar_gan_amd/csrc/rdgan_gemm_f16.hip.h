@@ -12,10 +12,9 @@
 //   * the weights (B) never touch LDS: each wave streams ITS fragments global -> VGPR from an image in fragment order
 //     (rd_wfrag_index: 1 KB per (32 columns, 16 k), one coalesced dwordx4 per lane), a queue of four k-steps = one chunk ahead,
 //     counted vmcnt waits, inline asm (see rd_upc_wload in rdgan_upconv16.hip.h for why);
-//   * operands swapped (D[n][m] = W-fragment x row-fragment), so a lane holds 4 consecutive channels of ONE row per register
-//     quad: bias / LeakyReLU / dropout / gate / PixelNorm run in registers, pairs of quads are exchanged between the wave halves
-//     (v_permlane32_swap) and leave as 16-byte stores.  No output tile in LDS, no row loop, the other workgroup of the CU is the
-//     only thing that has to cover this epilogue.
+//   * the epilogue is per WAVE: each wave turns its four 32 x 64 accumulator tiles through 8 KB of LDS of its own (no block
+//     barrier) and applies bias / LeakyReLU / dropout / gate / PixelNorm on rows, 4 rows x 128 contiguous bytes per load and
+//     store instruction; the destination offsets of its rows were read in the prologue.
 // Per MFMA the kernel reads 0.5 KB of row fragments from LDS (the streaming kernel: 1 KB) and writes 0.25 KB of DMA into it (0.5 KB).
 // Same chunk order (tap group, channel chunk, tap), same k order inside a chunk as the streaming kernel: the accumulators see the
 // same sequence of products, results are bit-identical except through PixelNorm (another order of the 128 squares).
@@ -59,7 +58,7 @@ __device__ __forceinline__ void rd_f16_barrier() { asm volatile("s_waitcnt vmcnt
 #define RD_F16_BM 256
 #define RD_F16_BN 128
 #define RD_F16_STAGE (RD_F16_BM * 128)                   // bytes per A stage: 256 rows of 64 bf16
-#define RD_F16_LDS (2 * RD_F16_STAGE + 2048)             // + the PixelNorm exchange (256 rows x 2 column halves x 4 bytes)
+#define RD_F16_LDS (2 * RD_F16_STAGE + 3 * 2048)         // + destination offsets and 1/l2 of the rows, the PixelNorm exchange (256 rows x 2 halves)
 
 template <bool PN>
 __global__ void __launch_bounds__(256, 2)
@@ -144,6 +143,27 @@ k_conv_gemm_f16(const RdPlan* __restrict__ plan, int B, const rd_bf16_t* __restr
       rbits[k] = ok ? ey[k] : 0;
     }
   }
+  // ---- where this lane's four accumulator rows (wm*128 + i*32 + l31) go: read here so that no memory round trip stands between
+  // the last MFMA and the epilogue.  Element offset in the window based at sample b0; RD_OOB: no such row
+  const int dsample = (int)plan->dst_sample;
+  unsigned rb[4];
+  {
+    int rl[4], rbb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wm * 128 + i * 32 + l31;
+      int l = l0 + row, bb = 0;
+      if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
+      else { bb = l / L; l -= bb * L; }
+      rl[i] = m0 + row < rows ? l : 0;
+      rbb[i] = bb;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int z = tab[rl[i]].z;
+      rb[i] = m0 + wm * 128 + i * 32 + l31 < rows ? (unsigned)(rbb[i] * dsample + z) : RD_OOB;
+    }
+  }
   // ---- weights: this wave's two N blocks of 32 columns; a tap block holds N / 32 x wrpt / 16 fragments of 1 KB
   const char* const wbase = (const char*)(wfrag + P.w_off) + (long)((n0 + wn * 64) >> 5) * (wrpt >> 4) * 1024;
   const unsigned wv0 = (unsigned)lane * 16u, wv1 = wv0 + (unsigned)(wrpt >> 4) * 1024u;
@@ -168,6 +188,11 @@ k_conv_gemm_f16(const RdPlan* __restrict__ plan, int B, const rd_bf16_t* __restr
     const int tap = n_g * tg + n_t;
     const int tm = __builtin_amdgcn_readlane(tp_mask, tap), td = __builtin_amdgcn_readlane(tp_delta, tap);
     char* As = lds + stage * RD_F16_STAGE + wave * 64 * 128;
+#ifdef RD_F16_ABL_NODMA              // (diagnostic builds, scratch/f16_abl.py: the kernel without its row gather; vmcnt bookkeeping kept by dummies)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rd_lds_dma16(rsA, (float*)(As + k * 1024), (int)RD_OOB, 0);
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       unsigned voff = ((rbits[k] & tm) == tm) ? (unsigned)(roff[k] + td) : RD_OOB;
@@ -214,6 +239,10 @@ k_conv_gemm_f16(const RdPlan* __restrict__ plan, int B, const rd_bf16_t* __restr
       // k-steps 0 .. kk-1: 14 loads behind the two waited for; LAST: 2 (3 - kk)
       if constexpr (LAST) rd_f16_wait<2 * (3 - kk)>(wq[kk][0], wq[kk][1]);
       else rd_f16_wait<14>(wq[kk][0], wq[kk][1]);
+#ifdef RD_F16_ABL_NOMFMA             // (diagnostic build: loads and waits only)
+      if (kk == 0) { acc[0][0][0] += __builtin_bit_cast(float, wq[kk][0].x ^ afr[kk & 1][0].x); }
+      if constexpr (false)
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, wq[kk][0]),
@@ -244,44 +273,30 @@ k_conv_gemm_f16(const RdPlan* __restrict__ plan, int B, const rd_bf16_t* __restr
     chunk(nchunks - 1, std::true_type{});
   }
 
-  // ---- epilogue, in registers.  Accumulator register r of lane (l31, lhalf), tile (i, j): row wm*128 + i*32 + l31, column
-  // wn*64 + j*32 + 8 (r >> 2) + 4 lhalf + (r & 3)
-  const int dsample = (int)plan->dst_sample;
+#ifdef RD_F16_ABL_NOEPI               // (diagnostic build: nothing is stored)
+  if (acc[0][0][0] != 12345.678f && acc[3][1][15] != 12345.678f) return;
+#endif
+  // ---- epilogue.  Accumulator register r of lane (l31, lhalf), tile (i, j): row wm*128 + i*32 + l31, column wn*64 + j*32 + 8 (r >> 2) +
+  // 4 lhalf + (r & 3): a lane holds ONE row's columns, so loads and stores straight from this layout touch 32 rows per instruction,
+  // 16-32 bytes of each (a first version did: with 64 KB of destination rows per workgroup going through a 32 KB L1 the gate's
+  // `aux` reads and the stores cost 0.10 of critic layer 3's 0.19 ms input gradient).  Each wave therefore turns its 32 x 64 tile
+  // i through 8 KB of LDS of its own -- in the A stage the last chunk did not use, no barrier -- and works on rows: lane
+  // (rq = lane >> 4, cq = lane & 15) takes columns 4 cq .. 4 cq + 3 of rows 4 p + rq, p = 0 .. 7: every load and store instruction
+  // covers 4 rows x 128 contiguous bytes, the bias quad is one register quad per lane for the whole tile.
   const long dbase = (long)b0 * dsample;
-  unsigned rb[4];                               // element offset of the row in the window based at sample b0, RD_OOB: no such row
+  unsigned* const rbs = (unsigned*)(lds + 2 * RD_F16_STAGE) + wave * 128;        // [128 rows of the wave] destination offsets
+  float* const ris = (float*)(lds + 2 * RD_F16_STAGE + 2048) + wave * 128;       // PixelNorm: 1/l2 of the wave's rows
+  if (lhalf == 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wm * 128 + i * 32 + l31;
-    int l = l0 + row, bb = 0;
-    if (L >= BM) { if (l >= L) { l -= L; bb = 1; } }
-    else { bb = l / L; l -= bb * L; }
-    const bool ok = m0 + row < rows;
-    const int z = tab[ok ? l : 0].z;
-    rb[i] = ok ? (unsigned)(bb * dsample + z) : RD_OOB;
-  }
-  const int ncol = n0 + wn * 64 + 4 * lhalf;                      // + j*32 + 8*quad: first column of a quad
-  if (ksplit > 1) {
-    const __amdgpu_buffer_rsrc_t rsK = rd_make_rsrc(epi.kpart + (long)blockIdx.y * epi.kstride + dbase);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          rd_buf_store4(rsK, (rb[i] & RD_OOB) | ((rb[i] + (unsigned)(ncol + j * 32 + 8 * g)) * 4u), v);
-        }
-    return;
+    for (int i = 0; i < 4; ++i) rbs[i * 32 + l31] = rb[i];
   }
   const int mode = epi.mode;
   const bool has_bias = mode == RD_EPI_BIAS || mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP || mode == RD_EPI_BIAS_PN_LRELU;
-  const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc((const float*)(dst + dbase));
-  const __amdgpu_buffer_rsrc_t rsX = rd_make_rsrc(mode == RD_EPI_GATE_AUX ? (const float*)((const rd_bf16_t*)epi.aux + dbase) : (const float*)dst);
-  float ri[4] = {1.f, 1.f, 1.f, 1.f};
   if constexpr (PN) {
     // PixelNormalization over the row's 128 columns: 32 squares per lane, the other half of the wave, the other column half of the
     // tile (wave wn ^ 1) through LDS
-    float* xs = (float*)(lds + 2 * RD_F16_STAGE);
+    float* xs = (float*)(lds + 2 * RD_F16_STAGE + 4096);
+    const int ncol = n0 + wn * 64 + 4 * lhalf;
     float ss[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -310,57 +325,79 @@ k_conv_gemm_f16(const RdPlan* __restrict__ plan, int B, const rd_bf16_t* __restr
     for (int i = 0; i < 4; ++i) {
       const int row = wm * 128 + i * 32 + l31;
       const float tot = wn == 0 ? ss[i] + xs[row * 2 + 1] : xs[row * 2] + ss[i];       // (column half 0 first in both waves)
-      ri[i] = __builtin_amdgcn_rsqf(tot * (1.0f / BN) + 1.0e-8f);
-      if (epi.rinv && wn == 0 && lhalf == 0) rd_buf_store1(rsR, (rb[i] & RD_OOB) | ((rb[i] / BN) * 4u), ri[i]);
+      const float ri = __builtin_amdgcn_rsqf(tot * (1.0f / BN) + 1.0e-8f);
+      if (lhalf == 0) ris[i * 32 + l31] = ri;
+      if (epi.rinv && wn == 0 && lhalf == 0) rd_buf_store1(rsR, (rb[i] & RD_OOB) | ((rb[i] / BN) * 4u), ri);
     }
   }
+  char* const Ts = lds + (nchunks & 1) * RD_F16_STAGE + wave * 8192;             // (nchunks == 0: both stages are free)
+  const int rq = lane >> 4, cq = lane & 15;
+  const unsigned colq = (unsigned)(n0 + wn * 64 + cq * 4);
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (has_bias && ksplit == 1) bias4 = *(const f32x4*)(epi.bias + colq);
+  const __amdgpu_buffer_rsrc_t rsK = rd_make_rsrc(ksplit > 1 ? epi.kpart + (long)blockIdx.y * epi.kstride + dbase : (const float*)dst);
+  const __amdgpu_buffer_rsrc_t rsD = rd_make_rsrc((const float*)(dst + dbase));
+  const __amdgpu_buffer_rsrc_t rsX = rd_make_rsrc(mode == RD_EPI_GATE_AUX ? (const float*)((const rd_bf16_t*)epi.aux + dbase) : (const float*)dst);
+  const bool drop = mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop;
+  const uint32_t ibase = (uint32_t)dbase + epi.idx_base + colq;
+  // destination offsets of the 8 x 4 rows of tile i and -- gate mode -- their `aux` quads, fetched one tile AHEAD of the stores:
+  // hipcc cannot move a load above an earlier store through another buffer descriptor, so a load issued per pass behind the
+  // previous pass's store is one memory round trip per pass (32 per tile: 0.10 of critic layer 3's 0.19 ms input gradient)
+  unsigned rbv[2][8];
+  rd_u32x2 ax[2][8];
+  const bool gate = mode == RD_EPI_GATE_AUX && ksplit == 1;
+  auto fetch = [&](int i, int slot) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int p = 0; p < 8; ++p) rbv[slot][p] = rbs[i * 32 + p * 4 + rq];
+    if (gate) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+        ax[slot][p] = __builtin_bit_cast(rd_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)((rbv[slot][p] & RD_OOB) | ((rbv[slot][p] + colq) * 2u)), 0, 0));
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // tile i -> LDS [32 rows][64 columns] fp32; the 16-byte slot s of row r sits at slot s ^ (r & 7) (conflict-free both ways)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int pq = 0; pq < 2; ++pq) {             // quads 2pq, 2pq + 1 -> one 16-byte store per lane
-        unsigned lo[2], hi[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int g = 2 * pq + u;
-          const int col = ncol + j * 32 + 8 * g;
-          float t[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = acc[i][j][4 * g + e];
-          if constexpr (PN) {
-            const f32x4 b4 = *(const f32x4*)(epi.bias + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float v = (t[e] + b4[e]) * ri[i]; t[e] = fmaxf(v, RD_LRELU_ALPHA * v); }
-          } else {
-            if (has_bias) {
-              const f32x4 b4 = *(const f32x4*)(epi.bias + col);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) t[e] += b4[e];
-            }
-            if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
-              const bool drop = mode == RD_EPI_BIAS_LRELU_DROP && epi.use_drop;
-              const uint32_t word = drop ? rd_drop_word(epi.key, (uint32_t)dbase + epi.idx_base + rb[i] + (uint32_t)col) : 0u;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float x = rd_lrelu(t[e]);
-                if (drop) x = rd_drop_apply_w(x, word, e);
-                t[e] = x;
-              }
-            } else if (mode == RD_EPI_GATE_AUX) {
-              const f32x4 a4 = rd_buf_load4_bf16(rsX, (rb[i] & RD_OOB) | ((rb[i] + (unsigned)col) * 2u));
-#pragma unroll
-              for (int e = 0; e < 4; ++e) t[e] *= rd_gate_from_out(a4[e], epi.use_drop);
-            }
-          }
-          lo[u] = rd_pack_bf16(t[0], t[1]); hi[u] = rd_pack_bf16(t[2], t[3]);
-        }
-        // lanes 0-31 keep their quad 2pq and take the upper half's quad 2pq (columns +4 .. +7); lanes 32-63 take the lower
-        // half's quad 2pq + 1 and keep their own: 8 consecutive columns 16 pq + 8 lhalf .. of the N block either way
-        const auto sx = __builtin_amdgcn_permlane32_swap(lo[0], lo[1], false, false);
-        const auto sy = __builtin_amdgcn_permlane32_swap(hi[0], hi[1], false, false);
-        const u32x4_t o = {sx[0], sy[0], sx[1], sy[1]};
-        const unsigned col8 = (unsigned)(n0 + wn * 64 + j * 32 + 16 * pq + 8 * lhalf);
-        rd_buf_store4(rsD, (rb[i] & RD_OOB) | ((rb[i] + col8) * 2u), __builtin_bit_cast(f32x4, o));
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        *(f32x4*)(Ts + l31 * 256 + (((j * 8 + 2 * g + lhalf) ^ (l31 & 7)) << 4)) = v;
       }
+    if (i + 1 < 4) fetch(i + 1, (i + 1) & 1);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int row = p * 4 + rq;
+      f32x4 v = *(const f32x4*)(Ts + row * 256 + ((cq ^ (row & 7)) << 4));
+      const unsigned rbvp = rbv[i & 1][p];
+      const unsigned oob = rbvp & RD_OOB;
+      if (ksplit > 1) {
+        rd_buf_store4(rsK, oob | ((rbvp + colq) * 4u), v);
+        continue;
+      }
+      if constexpr (PN) {
+        const float ri = ris[i * 32 + row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float x = (v[e] + bias4[e]) * ri; v[e] = fmaxf(x, RD_LRELU_ALPHA * x); }
+      } else {
+        v += bias4;
+        if (mode == RD_EPI_BIAS_LRELU || mode == RD_EPI_BIAS_LRELU_DROP) {
+          const uint32_t word = drop ? rd_drop_word(epi.key, ibase + rbvp) : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = rd_lrelu(v[e]);
+            if (drop) x = rd_drop_apply_w(x, word, e);
+            v[e] = x;
+          }
+        } else if (mode == RD_EPI_GATE_AUX) {
+          const f32x4 a4 = rd_unpack_bf16x4(ax[i & 1][p]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= rd_gate_from_out(a4[e], epi.use_drop);
+        }
+      }
+      rd_buf_store4_bf16(rsD, oob | ((rbvp + colq) * 2u), v);
+    }
+  }
 }
