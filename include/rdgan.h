@@ -160,6 +160,12 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * 8 x 8 source positions with their halo resident in LDS, the K loop in two channel halves (rdgan_upconv16t.hip.h); with "g9_fused"
  * the last conv's tap products leave its epilogue too, the tiles' edge sums as halo terms (k_g9_halo_fold, k_tapsum_softmax12t).
  * One bf16 ulp from the streaming GEMM; fractions within 2e-5 of the separate pass.
+ * "conv_f16" (default 1; bf16 storage mode): the gather GEMMs with N % 128 == 0 and a bf16 destination that launch >= 640 workgroups
+ * of 256 x 128 -- generator blocks 1 / 2 forward and input gradients, critic layers 2-4 forward and input gradients where no slab
+ * kernel takes them -- by k_conv_gemm_f16 (rdgan_gemm_f16.hip.h): four waves and no loader waves, weights global -> VGPR from
+ * fragment-order twin images (written beside the [tap][N][K] ones), gathered rows by LDS-DMA one 64-k chunk ahead, per-wave epilogue.
+ * Same chunk and k order as the streaming kernel: bit-identical results except through a fused PixelNorm (one ulp of 1/l2).
+ * 0 = k_conv_gemm_ws everywhere; 2 (tests) = regardless of the launch size.
  * "dense_skinny" (default 1; bf16 storage mode with "dense16", handles of max_batch <= 128): the Dense layer by k_dense16_skinny --
  * weights and input rows streamed in MFMA-fragment order, no LDS (the large domain's 415 MB kernel at 3.4-3.7 TB/s).  One bf16 ulp.
  * "wgrad_boxes" (default 1; with "border_boxes"): the weight gradients of critic layers 2-4 that run in the streaming kernels (fp32
@@ -301,7 +307,8 @@ int rdgan_op_conv3d(const float* x, const float* w, const float* bias, float* y,
 /* the same contraction with bf16 operands (x and w rounded to nearest-even bf16 on the device, fp32 accumulation;
  * v_mfma_f32_32x32x16_bf16): the GEMM of the "bf16" storage mode.  out_bf16 = 0: y is fp32 (the arithmetic, checked at
  * 1e-5 against the oracle on bf16-rounded operands); 1: y is bf16 (2 bytes per element), the accumulator rounded once
- * after the epilogue, as the storage mode writes it.  No folded upsample; Cin, Cout % 64 == 0. */
+ * after the epilogue, as the storage mode writes it; 2: as 1 through k_conv_gemm_f16 ("conv_f16"; Cout % 128 == 0, else -2).
+ * No folded upsample; Cin, Cout % 64 == 0. */
 int rdgan_op_conv3d_bf16(const float* x, const float* w, const float* bias, float* y, int B, int D, int H,
                          int W, int Cin, int Cout, int Do, int Ho, int Wo, int stride, int pad_d,
                          int pad_h, int pad_w, int out_bf16, void* stream);

@@ -24,9 +24,11 @@ pytestmark = pytest.mark.gpu
 FWD_TOL, GRAD_TOL = 2e-2, 3e-2      # observed: forward 2-4e-3; gradients 2e-3 ... 1.5e-2 (both steps)
 
 
-def _check_bf16_case(nd, B, seed, fast=None, critic=True):
+def _check_bf16_case(nd, B, seed, fast=None, critic=True, opts=None):
     eng = Engine(ndomain=nd, max_batch=B)
     try:
+        for k, v in (opts or {}).items():
+            eng.set_option(k, v)
         if fast is not None:            # default: the collapsed form in the bf16 mode; 1 = the shared-centre form forced
             eng.set_option("fast_fwd", fast); eng.set_option("fast_bwd", fast)
         g, d = _params(nd, 51)
@@ -69,6 +71,14 @@ def _check_bf16_case(nd, B, seed, fast=None, critic=True):
 def test_bf16_storage_forward_and_step_gradients(nd, B, seed):
     """small and odd batches (partial tiles everywhere) and the large domain"""
     _check_bf16_case(nd, B, seed)
+
+
+@pytest.mark.parametrize("nd,B,seed", [(16, 5, 33), (32, 2, 35)])
+def test_bf16_storage_fragment_gemm_vs_oracle(nd, B, seed):
+    """the same oracle comparison with every eligible gather GEMM forced onto k_conv_gemm_f16 ("conv_f16" = 2; by default the
+    kernel takes launches of >= 640 workgroups, i.e. the full-size tests): forward, generator step and critic step with its gradient
+    penalty double backward against the fp64 oracle on the branch the engine took"""
+    _check_bf16_case(nd, B, seed, opts={"conv_f16": 2})
 
 
 @pytest.mark.parametrize("fast", [None, 1])
