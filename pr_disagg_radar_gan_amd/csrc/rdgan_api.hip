@@ -535,8 +535,9 @@ static int launch_to_bf16(rdgan_handle* h, const float* in, void* out, long n, h
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
-static int launch_weights_to_bf16_t(rdgan_handle* h, const float* in, void* out, int T, int K, int N, hipStream_t st) {
-  hipLaunchKernelGGL(k_weights_to_bf16_t, dim3((N + 31) / 32, (K + 31) / 32, T), dim3(256), 0, st, in, (unsigned short*)out, K, N);
+static int launch_weights_to_bf16_t(rdgan_handle* h, const float* in, void* out, int T, int K, int N, hipStream_t st, void* outf = nullptr) {
+  hipLaunchKernelGGL(k_weights_to_bf16_t, dim3((N + 31) / 32, (K + 31) / 32, T), dim3(256), 0, st, in, (unsigned short*)out, K, N,
+                     (unsigned short*)outf);
   RD_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -1296,8 +1297,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
       else if (upconv_slab_t_on(h, l)) hipLaunchKernelGGL(k_upconv_wimg_t, dim3(256), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW3T);
       else if (upconv2_slab_on(h, l)) hipLaunchKernelGGL(k_upconv2_wimg, dim3(RD_UP2_KSTEPS), dim3(256), 0, ws, h->GWC[l], (unsigned short*)h->bW2I);
       else if (a16) {
-        RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws));
-        if (h->conv_f16) RD_TRY(launch_wfrag_image(h, h->bG1F[l], h->fG1F[l], 64, h->gch[l], h->gch[l - 1], ws));
+        RD_TRY(launch_weights_to_bf16_t(h, h->GWC[l], h->bG1F[l], 64, h->gch[l - 1], h->gch[l], ws, h->conv_f16 ? h->fG1F[l] : nullptr));
       }
     }
     if (ws != st) RD_CHECK(h, hipEventRecord(h->ev_g[l], ws));
@@ -1622,14 +1622,10 @@ static int prep_critic_weights(rdgan_handle* h, const float* dp, hipStream_t st)
     for (int l = 2; l <= 4; ++l) {
       a.in[l - 2] = dp + h->doff[2 * (l - 1)];
       a.outT[l - 2] = (unsigned short*)h->bWF[l]; a.outC[l - 2] = (unsigned short*)h->bWB[l];
+      a.outTf[l - 2] = h->conv_f16 ? (unsigned short*)h->fWF[l] : nullptr; a.outCf[l - 2] = h->conv_f16 ? (unsigned short*)h->fWB[l] : nullptr;
       a.K[l - 2] = h->dch[l - 1]; a.N[l - 2] = h->dch[l];
     }
     hipLaunchKernelGGL(k_weights3_to_bf16, dim3(8, 8, 3 * 27), dim3(256), 0, st, a);
-    if (h->conv_f16)
-      for (int l = 2; l <= 4; ++l) {
-        RD_TRY(launch_wfrag_image(h, h->bWF[l], h->fWF[l], 27, h->dch[l], h->dch[l - 1], st));
-        RD_TRY(launch_wfrag_image(h, h->bWB[l], h->fWB[l], 27, h->dch[l - 1], h->dch[l], st));
-      }
     if (d2_fwd_slab_on(h))
       hipLaunchKernelGGL(k_d2f_wimg, dim3(RD_D2F_KSTEPS), dim3(256), 0, st, dp + h->doff[2], (unsigned short*)h->bW2F);
     if (d2_slab_on(h) || d2_slab_t_on(h))
@@ -2300,8 +2296,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
         RdSliceMap map;
         collapsed_dgrad_slice_map(map.src);
         hipLaunchKernelGGL(k_blocks_to_bf16, dim3((unsigned)std::min<long>((cc / 8 + 255) / 256, 64), 64), dim3(256), 0, st,
-                           h->GWC[l], (unsigned short*)h->bG1B, cc, map);
-        if (h->conv_f16) RD_TRY(launch_wfrag_image(h, h->bG1B, h->fG1B, 64, h->gch[l - 1], h->gch[l], st));
+                           h->GWC[l], (unsigned short*)h->bG1B, cc, map, h->conv_f16 ? (unsigned short*)h->fG1B : nullptr, h->gch[l]);
         RdEpi eb = epi_make(RD_EPI_PLAIN);
         eb.out16 = 1;
         RD_TRY(launch_conv16(h, h->plans[plb], h->d_plans + plb, B, dys[l], h->bG1B, gups[l], eb, st, RDGAN_TAG_GCONV_DGRAD,

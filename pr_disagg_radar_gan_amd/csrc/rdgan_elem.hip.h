@@ -1030,8 +1030,10 @@ __global__ void k_to_bf16(const float* __restrict__ in, unsigned short* __restri
     *(u32x4_t*)(out + 8 * i) = o;
   }
 }
-// out[t][n][k] = bf16(in[t][k][n]): the weight layout of the bf16 conv GEMM (K contiguous); grid (N/32, K/32, T)
-__global__ void k_weights_to_bf16_t(const float* __restrict__ in, unsigned short* __restrict__ out, int K, int N) {
+// out[t][n][k] = bf16(in[t][k][n]): the weight layout of the bf16 conv GEMM (K contiguous); grid (N/32, K/32, T).  outf (may be
+// null): the same tap blocks in fragment order
+__global__ void k_weights_to_bf16_t(const float* __restrict__ in, unsigned short* __restrict__ out, int K, int N,
+                                    unsigned short* __restrict__ outf = nullptr) {
   __shared__ float tile[32][33];
   const long t = blockIdx.z;
   const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -1046,6 +1048,7 @@ __global__ void k_weights_to_bf16_t(const float* __restrict__ in, unsigned short
     if (n < N && k < K) {
       const __bf16 v = (__bf16)tile[tx][i];
       out[(t * N + n) * K + k] = __builtin_bit_cast(unsigned short, v);
+      if (outf) outf[t * N * K + rd_wfrag_index(n, k, K)] = __builtin_bit_cast(unsigned short, v);
     }
   }
 }
@@ -1068,7 +1071,8 @@ __global__ void k_dense_w16(const float* __restrict__ in, unsigned short* __rest
 // The critic's layers 2-4 in one launch: per layer l (blockIdx.z / 27) and tap (blockIdx.z % 27) the transposed bf16 image
 // outT[tap][n][k] (forward GEMMs) AND the plain bf16 copy outC[tap][k][n] (input-gradient GEMMs) of in[tap][k][n]; 32 x 32 tiles
 // through LDS, grid (8, 8, 81) covers K, N <= 256 in tile-strided loops
-struct RdW3 { const float* in[3]; unsigned short* outT[3]; unsigned short* outC[3]; int K[3], N[3]; };
+// outTf / outCf (may be null): the two images again in fragment order
+struct RdW3 { const float* in[3]; unsigned short* outT[3]; unsigned short* outC[3]; unsigned short* outTf[3]; unsigned short* outCf[3]; int K[3], N[3]; };
 __global__ void k_weights3_to_bf16(RdW3 a) {
   __shared__ float tile[32][33];
   const int l = blockIdx.z / 27;
@@ -1077,6 +1081,8 @@ __global__ void k_weights3_to_bf16(RdW3 a) {
   const float* in = a.in[l];
   unsigned short* outT = a.outT[l];
   unsigned short* outC = a.outC[l];
+  unsigned short* outTf = a.outTf[l];
+  unsigned short* outCf = a.outCf[l];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k0 = blockIdx.y * 32; k0 < K; k0 += gridDim.y * 32)
     for (int n0 = blockIdx.x * 32; n0 < N; n0 += gridDim.x * 32) {
@@ -1085,23 +1091,35 @@ __global__ void k_weights3_to_bf16(RdW3 a) {
         const int k = k0 + i, n = n0 + tx;
         const float v = (k < K && n < N) ? in[(t * K + k) * N + n] : 0.f;
         tile[i][tx] = v;
-        if (k < K && n < N) outC[(t * K + k) * N + n] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        if (k < K && n < N) {
+          outC[(t * K + k) * N + n] = __builtin_bit_cast(unsigned short, (__bf16)v);
+          if (outCf) outCf[t * K * N + rd_wfrag_index(k, n, N)] = __builtin_bit_cast(unsigned short, (__bf16)v);     // ([N' = K][K' = N])
+        }
       }
       __syncthreads();
       for (int i = ty; i < 32; i += 8) {
         const int n = n0 + i, k = k0 + tx;
-        if (n < N && k < K) outT[(t * N + n) * K + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][i]);
+        if (n < N && k < K) {
+          outT[(t * N + n) * K + k] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][i]);
+          if (outTf) outTf[t * N * K + rd_wfrag_index(n, k, K)] = __builtin_bit_cast(unsigned short, (__bf16)tile[tx][i]);
+        }
       }
     }
 }
 // out[q][:] = bf16(in[map[q]][:]) for q < gridDim.y, cc floats per block (cc % 8 == 0): the input-gradient weight forms of the
 // bf16 conv GEMM are the forward forms U themselves ([Cin][Cout] = [N][K] of that GEMM), re-ordered by tap
-__global__ void k_blocks_to_bf16(const float* __restrict__ in, unsigned short* __restrict__ out, long cc, RdSliceMap map) {
+// outf (may be null; K = the blocks' row length, K % 16 == 0): the same blocks in fragment order
+__global__ void k_blocks_to_bf16(const float* __restrict__ in, unsigned short* __restrict__ out, long cc, RdSliceMap map,
+                                 unsigned short* __restrict__ outf = nullptr, int K = 0) {
   const long q = blockIdx.y, t = map.src[blockIdx.y];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < cc / 8; i += (long)gridDim.x * blockDim.x) {
     const f32x4 a = *(const f32x4*)(in + t * cc + 8 * i), b = *(const f32x4*)(in + t * cc + 8 * i + 4);
     u32x4_t o = {rd_pack_bf16(a.x, a.y), rd_pack_bf16(a.z, a.w), rd_pack_bf16(b.x, b.y), rd_pack_bf16(b.z, b.w)};
     *(u32x4_t*)(out + q * cc + 8 * i) = o;
+    if (outf) {
+      const int n = (int)(8 * i / K), k = (int)(8 * i - (long)n * K);
+      *(u32x4_t*)(outf + q * cc + rd_wfrag_index(n, k, K)) = o;
+    }
   }
 }
 

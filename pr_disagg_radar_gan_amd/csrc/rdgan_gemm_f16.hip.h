@@ -22,11 +22,7 @@
 // Not here (the host falls back to the streaming kernel): fp32 destinations, the shared-centre T term, N % 128 != 0.
 #pragma once
 
-// element offset of W[n][k] inside one tap block [N][K] of a fragment-order image (K % 16 == 0, N % 32 == 0)
-__host__ __device__ __forceinline__ long rd_wfrag_index(int n, int k, int K) {
-  return ((long)(n >> 5) * (K >> 4) + (k >> 4)) * 512 + ((((k >> 3) & 1) << 5) + (n & 31)) * 8 + (k & 7);
-}
-
+// (rd_wfrag_index, the element order of a fragment-order image: rdgan_plan.h)
 // [T][N][K] bf16 (the streaming kernel's weight image) -> the same tap blocks in fragment order; one thread per 8 k (16 bytes)
 __global__ void k_wfrag_image(const unsigned short* __restrict__ in, unsigned short* __restrict__ out, long T, int N, int K) {
   const long per = (long)N * K / 8, total = T * per;

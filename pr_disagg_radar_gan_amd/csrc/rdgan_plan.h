@@ -120,5 +120,12 @@ RD_PLAN_HD int rd_wgrad_phase_rt(const RdWgradTiling& T, int ntaps) {
   return T.tiles_per_tap > 0 ? ntaps * T.tiles_per_tap : (ntaps + T.taps_per_tile - 1) >> T.tpt_log2;
 }
 
+// element offset of W[n][k] inside one tap block [N][K] of a FRAGMENT-ORDER bf16 weight image (rdgan_gemm_f16.hip.h; K % 16 == 0,
+// N % 32 == 0): fragment (n / 32, k / 16) = 512 contiguous elements = one MFMA operand of a wave, lane (k % 16 / 8) * 32 + n % 32
+// holds its 8 consecutive k
+RD_PLAN_HD long rd_wfrag_index(int n, int k, int K) {
+  return ((long)(n >> 5) * (K >> 4) + (k >> 4)) * 512 + ((((k >> 3) & 1) << 5) + (n & 31)) * 8 + (k & 7);
+}
+
 // shared-centre form (rdgan_elem.hip.h: k_weight_transform): U[u] = sum_k c[u][k] W[k], c in {-1, 0, 1}
 struct RdWeightMap { int8_t c[48][27]; };

@@ -25,3 +25,7 @@ for v in 0 1; do
 timeout -k 10 300 python bench.py --config 3 --steps 5 --warmup 2 --no-cpu-baseline --opt conv_f16=$v > $O/cfg3_f$v.json 2> $O/cfg3.err || { tail -5 $O/cfg3.err; exit 1; }
 show $O/cfg3_f$v.json
 done
+for v in 0 1; do
+timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --opt bf16=1 --opt conv_f16=$v > $O/bs256_f$v.json 2> $O/bs256.err || { tail -5 $O/bs256.err; exit 1; }
+show $O/bs256_f$v.json
+done
