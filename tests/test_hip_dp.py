@@ -169,7 +169,7 @@ def test_bench_strong_scaling_configs_rehearsal(config, batch, ex):
     """`bench.py --gpus 2 --config 5|4` (BASELINE configs[4] / configs[3]: bf16 storage, n_critic 5) rehearsed on one GPU over
     gloo with a small per-rank batch: at ndomain 64 the 837 MB generator slab takes the sharded exchange by default
     (reduce-scatter, Adam on the owned half, all-gather), the 11.6 MB critic slab the all-reduce."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "2",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "1",
            "--warmup", "1", "--config", str(config), "--batch", str(batch), "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, timeout=900)
