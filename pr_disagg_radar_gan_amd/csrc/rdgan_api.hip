@@ -459,7 +459,20 @@ static int launch_conv_a16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, 
   return bad_arg(h, "conv (bf16 storage): unsupported fp32-pipe GEMM");
 }
 
-static inline int ew_blocks(long n, int per = 256) { return (int)std::min<long>((n + per - 1) / per, 8192); }
+static inline int ew_blocks(long n, int per = 256);
+// critic input (k_build_critic_input): the four-voxel kernel where the layout allows it
+static void launch_build_critic_input(rdgan_handle* h, const float* real, const float* fake, const float* cond, int B, int mode,
+                                      uint32_t akey, uint32_t abase, hipStream_t st) {
+  const int D = h->ddim[0][0], HW = h->nd * h->nd;
+  const long total = (long)B * D * HW;
+  if (h->nc == 1 && h->CP == 2 && HW % 4 == 0 && total < 0x7FFFFFFFL)
+    hipLaunchKernelGGL(k_build_critic_input_v4, dim3(ew_blocks(total / 4)), dim3(256), 0, st, real, fake, cond, h->cin, B, D, HW, mode,
+                       akey, abase);
+  else
+    hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks(total)), dim3(256), 0, st, real, fake, cond, h->cin, B, D, HW, h->nc, h->CP,
+                       mode, akey, abase);
+}
+static inline int ew_blocks(long n, int per) { return (int)std::min<long>((n + per - 1) / per, 8192); }
 
 // k_conv_gemm_f16 (rdgan_gemm_f16.hip.h): when a launch may take it
 static bool conv_f16_ok(const rdgan_handle* h, const RdPlan& hp, int B, const RdEpi& epi) {
@@ -1871,8 +1884,7 @@ extern "C" int rdgan_critic_forward(rdgan_handle* h, const float* critic_params,
     hipLaunchKernelGGL(k_pad_w1, dim3(27), dim3(256), 0, st, critic_params + h->doff[0], h->W1P, h->Cin, h->CP);
     h->ccache_ptr = nullptr; h->ccache_ver = 0; h->ccache_cfg = -1;
   }
-  hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, sample,
-                     (const float*)nullptr, cond, h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 2, 0u, 0u);
+  launch_build_critic_input(h, sample, nullptr, cond, B, 2, 0u, 0u, st);
   RD_TRY(critic_forward_impl(h, critic_params, B, seed, st));
   RD_CHECK(h, hipMemcpyAsync(out, h->v, sizeof(float) * B, hipMemcpyDeviceToDevice, st));
   return 0;
@@ -1904,9 +1916,7 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
   const bool a16 = h->a16 != 0;
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, x_real, h->fake, cond,
-                       h->cin, B, h->ddim[0][0], h->nd * h->nd, h->nc, h->CP, 0, rd_make_key(seed, RD_STREAM_ALPHA),
-                       (uint32_t)h->sample_offset);
+    launch_build_critic_input(h, x_real, h->fake, cond, B, 0, rd_make_key(seed, RD_STREAM_ALPHA), (uint32_t)h->sample_offset, st);
   }
   RD_TRY(critic_forward_impl(h, dp, NBt, seed, st));           // T:372,373,379 as one batch
   RD_TRY(critic_dgrad_chain(h, dp, NBt, B, 0, seed, st));       // dL/dh for real|fake, dD/dh for x_hat
@@ -2053,8 +2063,7 @@ extern "C" int rdgan_gen_grad_after(rdgan_handle* h, const float* dp, const floa
   RD_TRY(side_join(h, st, h->ev_cw));
   {
     ProfScope ps(h, RDGAN_TAG_ELEMENTWISE, st);
-    hipLaunchKernelGGL(k_build_critic_input, dim3(ew_blocks((long)B * h->dL[0])), dim3(256), 0, st, (const float*)nullptr,
-                       h->fake, cond, h->cin, B, h->ddim[0][0], nd * nd, h->nc, h->CP, 1, 0u, 0u);
+    launch_build_critic_input(h, nullptr, h->fake, cond, B, 1, 0u, 0u, st);
   }
   RD_TRY(critic_forward_impl(h, dp, B, seed, st));              // critic frozen, dropout active (T:395,405)
   RD_TRY(critic_dgrad_chain(h, dp, B, B, 1, seed, st));

@@ -549,6 +549,33 @@ __global__ void k_build_critic_input(const float* __restrict__ real, const float
   }
 }
 
+// The same for one condition channel (CP = 2, nc = 1), four voxels per thread: 16-byte loads of real / fake / cond, two 16-byte
+// stores per destination, 32-bit index arithmetic (the kernel above divides two 64-bit numbers per voxel and moves 4 bytes per
+// instruction: 4.4 TB/s at 6144 samples).  HW % 4 == 0, B * D * HW < 2^31.
+__global__ void k_build_critic_input_v4(const float* __restrict__ real, const float* __restrict__ fake,
+                                        const float* __restrict__ cond, float* __restrict__ out, int B, int D, int HW,
+                                        int mode, uint32_t alpha_key, uint32_t alpha_base) {
+  const unsigned per4 = (unsigned)(D * HW) / 4u, hw4 = (unsigned)HW / 4u, total4 = (unsigned)B * per4;
+  for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += gridDim.x * blockDim.x) {
+    const unsigned b = q / per4, r = q - b * per4, h4 = r % hw4;
+    const f32x4 c = *(const f32x4*)(cond + ((long)b * hw4 + h4) * 4);
+    auto put = [&](long q4, f32x4 x) {
+      float* o = out + q4 * 8;
+      *(f32x4*)o = (f32x4){x.x, c.x, x.y, c.y};
+      *(f32x4*)(o + 4) = (f32x4){x.z, c.z, x.w, c.w};
+    };
+    if (mode == 0) {
+      const f32x4 rl = *(const f32x4*)(real + (long)q * 4), fk = *(const f32x4*)(fake + (long)q * 4);
+      const float a = rd_uniform(alpha_key, alpha_base + b);
+      put(q, rl); put((long)total4 + q, fk); put(2L * total4 + q, a * rl + (1.0f - a) * fk);
+    } else if (mode == 1) {
+      put(q, *(const f32x4*)(fake + (long)q * 4));
+    } else {
+      put(q, *(const f32x4*)(real + (long)q * 4));
+    }
+  }
+}
+
 // D6 (T:303-304): v[b] = h4[b,:] . w + bias; one block per sample.
 template <typename T = float>
 __global__ void k_critic_dense_fwd(const T* __restrict__ h4, const float* __restrict__ w, const float* __restrict__ bias,
