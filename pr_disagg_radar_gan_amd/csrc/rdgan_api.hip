@@ -71,6 +71,7 @@ struct rdgan_handle : RdGeom {     // geometry + parameter layout: rdgan_hostpla
   void *bWF[5], *bWB[5];
   void *bG1F[4], *bG1B, *bW1B;
   void *fWF[5], *fWB[5], *fG1F[4], *fG1B;    // the same images in fragment order (rdgan_gemm_f16.hip.h: rd_wfrag_index), written beside them
+  int wgrad_wide = 1;             // 1: bf16 weight gradients of N % 128 == 0 layers with >= 32768 rows on 256 x 128 tiles, three stages (k_wgrad_gemm_ws16<256,128>)
   int conv_f16 = 1;               // 1: bf16 storage mode: the large gather GEMMs by k_conv_gemm_f16 (weights global -> VGPR, 256 x 128 tiles)
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
@@ -669,7 +670,7 @@ static int launch_wgrad(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int
 template <int BR, int BN>
 static int launch_wgrad16_cfg(rdgan_handle* h, const RdPlan* dp, int nphases, int B, const void* src16, const void* dy16,
                               float* partial, const RdWgradTiling& T, int nsplit, hipStream_t st) {
-  constexpr size_t lds_loop = 2 * (size_t)(64 * BR * 2 + 64 * BN * 2);
+  constexpr size_t lds_loop = ((BR == 256 && BN == 128) ? 3 : 2) * (size_t)(64 * BR * 2 + 64 * BN * 2);
   constexpr size_t lds_epi = (size_t)BR * BN * sizeof(float);
   constexpr size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
   auto kern = k_wgrad_gemm_ws16<BR, BN>;
@@ -686,6 +687,7 @@ static bool wgrad16_ok(const RdPlan& hp, int B) {
   wgrad_tiling(hp, B, BR, BN, nsplit);
   return BR >= 128;
 }
+static bool wgrad16_wide(const rdgan_handle* h) { return !h || h->wgrad_wide; }
 static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* dy16,
                           float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);
@@ -696,7 +698,7 @@ static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, i
   for (int i = 1; i < hp.nphases; ++i)
     if (hp.ph[i].ntaps != hp.ph[0].ntaps || hp.ph[i].L != hp.ph[0].L) return bad_arg(h, "wgrad: phases must be congruent");
   int BR, BN, nsplit;
-  RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
+  RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit, wgrad16_wide(h));
   size_t need = T.box ? (size_t)T.RT * BR * hp.N : (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
   if (need > partial_cap) return bad_arg(h, "wgrad: partial workspace too small");
   long minL16 = hp.ph[0].L;
@@ -704,7 +706,8 @@ static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, i
   if (std::min<long>(B, T.rows_per_split / minL16 + 2) * std::max(hp.src_sample, hp.dst_sample) * 2 >= 0x7FFFFFF0L)
     return bad_arg(h, "wgrad: split span exceeds 2 GiB");
   const int np = hp.nphases;
-  if (BR == 256) RD_TRY((launch_wgrad16_cfg<256, 64>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
+  if (BR == 256 && BN == 128) RD_TRY((launch_wgrad16_cfg<256, 128>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
+  else if (BR == 256) RD_TRY((launch_wgrad16_cfg<256, 64>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
   else if (BN == 128) RD_TRY((launch_wgrad16_cfg<128, 128>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
   else RD_TRY((launch_wgrad16_cfg<128, 64>(h, dp, np, B, src16, dy16, partial_ws, T, nsplit, st)));
   if (T.box) {      // per weight tap: the slabs of every phase that lists it
@@ -1042,6 +1045,7 @@ extern "C" int rdgan_set_option(rdgan_handle* h, const char* name, int value) {
   if (!strcmp(name, "upwgrad_slab")) { h->upwgrad_slab = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_dgrad_fused")) { h->d1_dgrad_fused = value ? 1 : 0; return 0; }
   if (!strcmp(name, "d1_wgrad16")) { h->d1_wgrad16 = value ? 1 : 0; return 0; }
+  if (!strcmp(name, "wgrad_wide")) { h->wgrad_wide = value ? 1 : 0; return 0; }
   if (!strcmp(name, "conv_f16")) {      // (the forms are rebuilt: their fragment-order twins exist only while the option is on)
     if (value < 0 || value > 2) return bad_arg(h, "conv_f16: 0, 1 or 2 (2: regardless of the launch size)");
     h->conv_f16 = value; h->ccache_ver = 0; h->gcache_ver = 0; return 0;
@@ -2401,7 +2405,7 @@ extern "C" int rdgan_op_conv3d_wgrad_bf16(const float* x, const float* gy, float
   RD_TRY(tp.upload());
   if (!wgrad16_ok(tp.host, B)) return -2;
   const long nx = (long)B * D * H * W * Cin, ng = (long)B * Do * Ho * Wo * Cout;
-  size_t need = wgrad_partial_need(tp.host, B);
+  size_t need = std::max(wgrad_partial_need(tp.host, B), wgrad_partial_need(tp.host, B, true));
   void *xb = nullptr, *gb = nullptr; float* partial = nullptr;
   hipError_t e = hipMalloc(&xb, nx * 2);
   if (e == hipSuccess) e = hipMalloc(&gb, ng * 2);
@@ -2535,7 +2539,7 @@ extern "C" int rdgan_op_fastd_wgrad(const float* src, const float* dy, float* dU
   TmpPlan tp;
   tp.host = plan_fastd_wgrad(D, H, W, Cin, Cout, g);
   RD_TRY(tp.upload());
-  size_t need = wgrad_partial_need(tp.host, B);
+  size_t need = std::max(wgrad_partial_need(tp.host, B), wgrad_partial_need(tp.host, B, true));
   float* partial = nullptr;
   void *xb = nullptr, *gb = nullptr;
   hipError_t e = hipMalloc((void**)&partial, need * sizeof(float));

@@ -23,8 +23,18 @@ __device__ __forceinline__ rd_bf16x8 rd_tr_frag(const char* lds, int off0, int o
   return __builtin_bit_cast(rd_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// <256, 128> (round 4, "wgrad_wide"): THREE stages of 48 KB, one workgroup per CU (compute waves: 128 accumulator registers).  The
+// streaming weight gradient is bound by the gathered bytes it can keep in flight over the memory latency (LDS capacity: 2
+// workgroups x 1 stage of 32 KB being filled = 64 KB per CU, 512 B per MFMA -> 0.20-0.29 of the bf16 roof whatever the tile does
+// inside); this shape keeps two stages = 96 KB in flight and needs 384 B per MFMA.  The loader waves then publish chunk q + 1
+// while chunk q + 2's DMAs stay in flight: a counted wait (the row-table loads of chunk q + 3 are issued BEFORE chunk q + 2's
+// DMAs, so those DMAs are exactly the youngest NI_A + NI_B vector-memory operations) and a bare s_barrier in one asm statement --
+// hipcc's own wait in front of __syncthreads() covers every DMA it has issued.
+template <int N>
+__device__ __forceinline__ void rd_ws16_barrier() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(N) : "memory"); }
+
 template <int BR, int BN>
-__global__ void __launch_bounds__(512, 4)
+__global__ void __launch_bounds__(512, (BR == 256 && BN == 128) ? 2 : 4)
 k_wgrad_gemm_ws16(const RdPlan* __restrict__ plan, int B, const unsigned short* __restrict__ src,
                   const unsigned short* __restrict__ dy, float* __restrict__ partial, RdWgradTiling T) {
   constexpr int BKP = 64;                                   // positions per chunk (four 16-deep MFMA steps)
@@ -36,6 +46,7 @@ k_wgrad_gemm_ws16(const RdPlan* __restrict__ plan, int B, const unsigned short* 
   constexpr int B_L = RBB / 16, B_PPI = 64 / B_L;
   constexpr int NI_B = BKP / B_PPI / 4;
   constexpr int NV = A_PPI == 2 ? 2 : 1;                    // distinct (position & 3) patterns of a lane over the instructions
+  constexpr int NST = (BR == 256 && BN == 128) ? 3 : 2;     // LDS stages
   static_assert(BR >= 128 && (BR == 128 || BR == 256) && (BN == 64 || BN == 128), "tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* lds = (char*)smem;
@@ -143,11 +154,70 @@ k_wgrad_gemm_ws16(const RdPlan* __restrict__ plan, int B, const unsigned short* 
       }
       fetch_rows();
     };
+    if constexpr (NST == 3) {
+      // two sets of row-table registers: set c & 1 holds chunk c's entries (and its sample indices) from the moment chunk c - 1's
+      // DMAs have been issued
+      int sx[2][NI_A], sy[2][NI_A], sab[2][NI_A], sz[2][NI_B], sgb[2][NI_B];
+      auto fetch = [&](int set) {                        // entries of the cursor's chunk -> set; the cursor moves on
+#pragma unroll
+        for (int k = 0; k < NI_A; ++k) { sx[set][k] = tab[al[k]].x; sy[set][k] = tab[al[k]].y; sab[set][k] = ab[k]; }
+#pragma unroll
+        for (int j = 0; j < NI_B; ++j) { sz[set][j] = tab[gl[j]].z; sgb[set][j] = gb[j]; }
+#pragma unroll
+        for (int k = 0; k < NI_A; ++k) {
+          al[k] += BKP;
+          if (L >= BKP) { if (al[k] >= L) { al[k] -= L; ab[k] += 1; } }
+          else { int qd = al[k] / L; al[k] -= qd * L; ab[k] += qd; }
+        }
+#pragma unroll
+        for (int j = 0; j < NI_B; ++j) {
+          gl[j] += BKP;
+          if (L >= BKP) { if (gl[j] >= L) { gl[j] -= L; gb[j] += 1; } }
+          else { int qd = gl[j] / L; gl[j] -= qd * L; gb[j] += qd; }
+        }
+      };
+      auto dma = [&](int c, int set) {                   // chunk c from set -> stage c % 3: NI_A + NI_B instructions
+        const int mb = mbeg + c * BKP, stage = c % 3;
+        float* As = (float*)(lds + stage * STAGE) + wl * NI_A * 256;
+        float* Bs = (float*)(lds + stage * STAGE + BKP * RBA) + wl * NI_B * 256;
+#pragma unroll
+        for (int k = 0; k < NI_A; ++k) {
+          const int v = k & (NV - 1);
+          const int m = mb + (wl * NI_A + k) * A_PPI + lane / A_L;
+          const int off = (sab[set][k] * ssample + sx[set][k]) * 2 + a_const[v];
+          unsigned voff = (m < mend && (sy[set][k] & tmask[v]) == tmask[v]) ? (unsigned)off : RD_OOB;
+          asm volatile("" : "+v"(voff));
+          rd_lds_dma16(rsA, As + k * 256, (int)voff, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NI_B; ++j) {
+          const int m = mb + (wl * NI_B + j) * B_PPI + lane / B_L;
+          unsigned voff = m < mend ? (unsigned)((sgb[set][j] * dsample + sz[set][j]) * 2 + b_const) : RD_OOB;
+          asm volatile("" : "+v"(voff));
+          rd_lds_dma16(rsB, Bs + j * 256, (int)voff, 0);
+        }
+      };
+      // (fetch_rows() above left chunk 0's entries in ex / ey / ez: not used here -- the sets are filled from the cursor, which
+      // still points at chunk 0)
+      fetch(0); fetch(1);
+      if (nchunks > 0) dma(0, 0);
+      fetch(0);                                          // chunk 2
+      if (nchunks > 1) { dma(1, 1); rd_ws16_barrier<NI_A + NI_B>(); }        // chunk 0 has landed; chunk 1 may be in flight
+      else rd_ws16_barrier<0>();
+      for (int q = 0; q < nchunks; ++q) {
+        if (q + 2 < nchunks) {
+          fetch((q + 3) & 1);                            // chunk q + 3 (its set was last read by chunk q + 1's DMAs)
+          dma(q + 2, q & 1);
+          rd_ws16_barrier<NI_A + NI_B>();                // chunk q + 1 has landed
+        } else rd_ws16_barrier<0>();
+      }
+    } else {
     if (nchunks > 0) load_chunk(mbeg, 0);
     __syncthreads();
     for (int q = 0; q < nchunks; ++q) {
       if (q + 1 < nchunks) load_chunk(mbeg + (q + 1) * BKP, (q + 1) & 1);
       __syncthreads();
+    }
     }
   } else {
     const int wm = wave >> 1, wn = wave & 1;
@@ -173,7 +243,7 @@ k_wgrad_gemm_ws16(const RdPlan* __restrict__ plan, int B, const unsigned short* 
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
     for (int q = 0; q < nchunks; ++q) {
-      const char* st = lds + (q & 1) * STAGE;
+      const char* st = lds + (NST == 3 ? q % 3 : q & 1) * STAGE;
       rd_bf16x8 fa[2][TM], fb[2][TN];
       auto load_frag = [&](int slot, int kk) {
 #pragma unroll

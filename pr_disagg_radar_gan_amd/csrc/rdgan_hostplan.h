@@ -474,7 +474,10 @@ static long wgrad_target_wgs() {
   static const long v = [] { const char* e = getenv("RDGAN_WGRAD_WGS"); long x = e ? atol(e) : 0; return x >= 64 && x <= 8192 ? x : 1024L; }();
   return v;
 }
-static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int& nsplit) {
+// wide16 (bf16 kernels only, k_wgrad_gemm_ws16<256, 128>): N % 128 == 0 layers with plenty of rows take 256 x 128 tiles -- three
+// stages of 48 KB, one workgroup per CU: 96 KB of gathered rows in flight per CU instead of 64 and 384 B of them per MFMA instead of
+// 512 (the streaming weight-gradient kernels are bound by bytes in flight over memory latency)
+static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int& nsplit, bool wide16 = false) {
   RdWgradTiling T; memset(&T, 0, sizeof(T));
   const RdPhase& q = p.ph[0];
   BR = p.SC >= 128 ? 128 : 64;
@@ -483,6 +486,11 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   // 64x64 tile (4 fragment reads per 4 MFMAs instead of 3 per 2)
   if (p.SC == 64 && BN == 128 && q.ntaps >= 2 && (p.nphases == 1 || p.boxes) && !p.s_shift) BR = 128;
   if (BN == 64 && p.SC == 128 && q.ntaps % 2 == 0 && (long)B * q.L >= 65536) BR = 256;   // two taps per tile, 4 accumulators per wave
+  if (wide16 && BR == 128 && BN == 128 && !p.s_shift && p.SC % 64 == 0 && (p.SC >= 256 ? p.SC % 256 == 0 : true)) {
+    long rows_all = 0, taps_min = q.ntaps;
+    for (int i = 0; i < p.nphases; ++i) { rows_all += (long)B * p.ph[i].L; taps_min = std::min<long>(taps_min, p.ph[i].ntaps); }
+    if (rows_all >= 32768 && taps_min * p.SC >= 256) BR = 256;
+  }
   if (p.SC >= BR) {
     T.tiles_per_tap = (p.SC + BR - 1) / BR; T.cw = BR; T.taps_per_tile = 1; T.RT = q.ntaps * T.tiles_per_tap;
   } else {
@@ -522,9 +530,9 @@ static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int&
   return T;
 }
 
-static size_t wgrad_partial_need(const RdPlan& hp, int B) {
+static size_t wgrad_partial_need(const RdPlan& hp, int B, bool wide16 = false) {
   int BR, BN, nsplit;
-  RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit);
+  RdWgradTiling T = wgrad_tiling(hp, B, BR, BN, nsplit, wide16);
   if (T.box) return (size_t)T.RT * BR * hp.N;
   return (size_t)hp.nphases * nsplit * T.RT * BR * hp.N;
 }
@@ -540,9 +548,13 @@ static bool wgrad_box_ok(const RdPlan& hp) {
 // is chosen the launch has at most wgrad_target_wgs() * 5 / 4 workgroups = that many BR x BN slab tiles; the need is below
 // both.  One-phase / congruent plans: nsplit <= want, which depends on B only through the 128 -> 256 row-tile switch, so the
 // bound is taken over both tile choices.  tests/host/plan_check.cpp compares it with the need of EVERY B.
-static size_t wgrad_partial_bound(const RdPlan& hp, int maxB) {
+static size_t wgrad_partial_bound1(const RdPlan& hp, int maxB, bool wide16);
+static size_t wgrad_partial_bound(const RdPlan& hp, int maxB) {      // (both tilings of the bf16 kernels: one workspace)
+  return std::max(wgrad_partial_bound1(hp, maxB, false), wgrad_partial_bound1(hp, maxB, true));
+}
+static size_t wgrad_partial_bound1(const RdPlan& hp, int maxB, bool wide16) {
   int BR, BN, nsplit;
-  RdWgradTiling T = wgrad_tiling(hp, maxB, BR, BN, nsplit);
+  RdWgradTiling T = wgrad_tiling(hp, maxB, BR, BN, nsplit, wide16);
   if (T.box) {
     size_t slabs5 = 0;
     for (int i = 0; i < hp.nphases; ++i)
@@ -555,7 +567,7 @@ static size_t wgrad_partial_bound(const RdPlan& hp, int maxB) {
   }
   size_t bound = 0;
   for (int B : {1, maxB}) {          // (the two row-tile choices: below / above the 65536-row switch)
-    T = wgrad_tiling(hp, B, BR, BN, nsplit);
+    T = wgrad_tiling(hp, B, BR, BN, nsplit, wide16);
     const long tiles = (long)T.RT * T.NT * hp.nphases;
     const long want = std::max(1L, (wgrad_target_wgs() + tiles - 1) / tiles);
     const long maxs = std::max(1L, ((long)maxB * hp.ph[0].L + 127) / 128);

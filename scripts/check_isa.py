@@ -46,8 +46,11 @@ NO_SPILL = re.compile(r"k_conv_gemm_f16|k_upconv_slab16|k_upconv2_slab16|k_d2_dg
 SCRATCH_ALLOWED = {
     r"^k_upconv2_slab16$": 16,     # three per-sample addresses stored in the prologue and reloaded once per sample, outside the K loop
 }
-# rule III exceptions: kernel regex -> why an LDS-DMA may be in flight at a barrier
+# rule III exceptions: kernel regex -> (K, why): LDS-DMA loads may be in flight at a barrier if every one of them is among the K
+# youngest vector-memory operations of the wave (a stage ring: the barrier publishes an OLDER stage; the counted wait in front of
+# it is what the rule then checks, on every path)
 DMA_ACROSS_BARRIER = {
+    r"k_wgrad_gemm_ws16ILi256ELi128E": (12, "three LDS stages: chunk q + 2's 8 + 4 DMAs stay in flight while the barrier publishes chunk q + 1"),
 }
 
 
@@ -229,7 +232,8 @@ def check_kernel(name, insns, hand=False, dma_ok=None):
             return True
         changed = False
         for key, age in st.items():
-            if key not in cur or cur[key] > age:
+            # the YOUNGEST age of a key wins (it retires last); "dma_old" = age of the oldest DMA in flight: the OLDEST wins
+            if key not in cur or (cur[key] < age if key == "dma_old" else cur[key] > age):
                 cur[key] = age
                 changed = True
         return changed
@@ -254,7 +258,10 @@ def check_kernel(name, insns, hand=False, dma_ok=None):
                 m = re.search(r"vmcnt\((\d+)\)", ins.text)
                 if m:
                     keep = int(m.group(1))
+                    old = st.get("dma_old")
                     st = {key: age for key, age in st.items() if age < keep}
+                    if old is not None and old >= keep and "dma" in st:
+                        st["dma_old"] = keep - 1              # (the DMAs still in flight are among the `keep` youngest operations)
             elif is_vmem(ins):
                 kind = vmem_kind(ins)
                 dest = vmem_dest(ins)
@@ -268,9 +275,14 @@ def check_kernel(name, insns, hand=False, dma_ok=None):
                 st = {key: age + 1 for key, age in st.items() if age + 1 < AGE_CAP}
                 if kind == "dma":
                     st["dma"] = 0
+                    st.setdefault("dma_old", 0)
                 for r in dest:
                     st[r] = 0
             elif ins.mn == "s_barrier":
+                if "dma" in st and dma_ok and st.get("dma_old", AGE_CAP) >= dma_ok[0] and (ins.addr, "b") not in reported:
+                    reported.add((ins.addr, "b"))
+                    issues.append(("III", ins.addr, f"s_barrier with an LDS-DMA load in flight that is not among the {dma_ok[0]} youngest vector-memory "
+                                                    f"operations (oldest: {st.get('dma_old')} younger than it): the counted wait is missing on some path"))
                 if "dma" in st and not dma_ok and (ins.addr, "b") not in reported:
                     reported.add((ins.addr, "b"))
                     issues.append(("III", ins.addr, f"s_barrier with an LDS-DMA load still in flight ({st['dma']} vector-memory operation(s) "
@@ -345,7 +357,7 @@ def lint(dis, notes, verbose=False):
     for sym, insns in kernels.items():
         name = demangled_name(sym)
         hand = bool(HAND_SCHEDULED.search(name))
-        dma_ok = next((why for rx, why in DMA_ACROSS_BARRIER.items() if re.search(rx, name)), None)
+        dma_ok = next((why for rx, why in DMA_ACROSS_BARRIER.items() if re.search(rx, name) or re.search(rx, sym)), None)
         for rule, addr, msg in check_kernel(sym, insns, hand=hand, dma_ok=dma_ok):
             bad.append(f"[rule {rule}] {name} ({sym}) @0x{addr:x}: {msg}")
         md = meta.get(sym)

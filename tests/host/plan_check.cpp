@@ -85,10 +85,15 @@ static void check_boxes(const RdPlan& one, const RdPlan& box, const std::vector<
 }
 
 // host copy of rd_wgrad_box_decode (rdgan_gemm.hip.h): every slab must be reached by exactly NT workgroups
+static void check_wgrad1(const RdPlan& p, int B, size_t bound, const char* name, bool full_decode, bool wide16);
 static void check_wgrad(const RdPlan& p, int B, size_t bound, const char* name, bool full_decode) {
+  check_wgrad1(p, B, bound, name, full_decode, false);
+  check_wgrad1(p, B, bound, name, full_decode, true);       // (the 256 x 128 tiling of the bf16 kernels where it applies)
+}
+static void check_wgrad1(const RdPlan& p, int B, size_t bound, const char* name, bool full_decode, bool wide16) {
   int BR, BN, nsplit;
-  RdWgradTiling T = wgrad_tiling(p, B, BR, BN, nsplit);
-  const size_t need = wgrad_partial_need(p, B);
+  RdWgradTiling T = wgrad_tiling(p, B, BR, BN, nsplit, wide16);
+  const size_t need = wgrad_partial_need(p, B, wide16);
   CHECK(need <= bound, "%s B=%d: partial slabs need %zu floats, workspace bound %zu", name, B, need, bound);
   CHECK(p.N % BN == 0 || p.N < BN, "%s: N %d vs BN %d", name, p.N, BN);
   if (!T.box) {

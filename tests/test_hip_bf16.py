@@ -711,6 +711,33 @@ def test_fragment_gemm_equals_the_streaming_gemm(nd, B, ksplit):
         eng.close()
 
 
+def test_wide_wgrad_tiles_equal_the_128_row_tiles():
+    """"wgrad_wide" (default on): the streaming bf16 weight gradients of N % 128 == 0 layers with >= 32768 gathered rows on 256 x 128
+    tiles with three LDS stages (k_wgrad_gemm_ws16<256, 128>) against the 128 x 128 tiles of the same engine: the same bf16 products,
+    other splits and another fp32 order.  ndomain 32 with 30 samples: critic layers 2 (border boxes, 64 channels: four taps per row
+    tile) and 3 and generator block 2 take the wide tiles."""
+    nd, B = 32, 30
+    eng = Engine(ndomain=nd, max_batch=B)
+    try:
+        g, d = _params(nd, 83)
+        x, cond, z = ot.synthetic_batch(B, nd, 73)
+        gs, ds = eng.to_slab(g), eng.to_slab(d)
+        eng.set_option("bf16", 1)
+        res, kernels = {}, {}
+        for v in (0, 1):
+            eng.set_option("wgrad_wide", v)
+            eng.profile_launches(True)
+            res[v] = (eng.critic_grad(ds, gs, dev(x), dev(cond), dev(z), 45).clone(), eng.gen_grad(ds, gs, dev(z), dev(cond), 47).clone())
+            kernels[v] = {r["kernel"] for r in eng.launch_table()}
+        assert not any("ws16<256,128>" in k for k in kernels[0])
+        assert any("ws16<256,128>" in k for k in kernels[1]), kernels[1]
+        for a, b in zip(res[0], res[1]):
+            assert bool(torch.isfinite(b).all())
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (float((a - b).abs().max()), float(a.abs().max()))
+    finally:
+        eng.close()
+
+
 def test_bf16_storage_needs_the_fast_forms():
     eng = Engine(ndomain=16, max_batch=2)
     try:

@@ -119,6 +119,11 @@ def test_conv3d_dgrad_bf16_operands(g):
 
 
 _WG16 = [g for g in GEOMS if not g[8] and (g[3] % 128 == 0 or (g[3] == 64 and g[4] % 128 == 0))]   # tiles of 128+ rows
+# >= 32768 gathered rows and N % 128 == 0: the 256 x 128 tiles on three LDS stages (k_wgrad_gemm_ws16<256, 128>, "wgrad_wide"):
+# 64 input channels (four taps per row tile, 27 -> 28 tap slots), 128 (two per tile, a partial last split), 256 (one tile per tap)
+_WG16 += [("D2_nd64_wide", 22, (11, 31, 31), 64, 128, (6, 16, 16), 2, (1, 1, 1), 0),
+          ("D3_nd64_wide", 171, (6, 16, 16), 128, 256, (3, 8, 8), 2, (0, 0, 0), 0),
+          ("plain_256_wide", 157, (5, 6, 7), 256, 128, (5, 6, 7), 1, (1, 1, 1), 0)]
 
 
 @pytest.mark.parametrize("g", _WG16, ids=[g[0] for g in _WG16])
