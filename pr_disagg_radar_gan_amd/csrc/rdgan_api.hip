@@ -71,7 +71,7 @@ struct rdgan_handle : RdGeom {     // geometry + parameter layout: rdgan_hostpla
   void *bWF[5], *bWB[5];
   void *bG1F[4], *bG1B, *bW1B;
   void *fWF[5], *fWB[5], *fG1F[4], *fG1B;    // the same images in fragment order (rdgan_gemm_f16.hip.h: rd_wfrag_index), written beside them
-  int wgrad_wide = 1;             // 1: bf16 weight gradients of N % 128 == 0 layers with >= 32768 rows on 256 x 128 tiles, three stages (k_wgrad_gemm_ws16<256,128>)
+  int wgrad_wide = 0;             // 1: bf16 weight gradients of N % 128 == 0 layers with >= 32768 rows on 256 x 128 tiles, three stages (k_wgrad_gemm_ws16<256,128>): measured SLOWER, default off
   int conv_f16 = 1;               // 1: bf16 storage mode: the large gather GEMMs by k_conv_gemm_f16 (weights global -> VGPR, 256 x 128 tiles)
   void* bW3I;                     // weight image of the slab kernel of generator block 3 (rdgan_upconv16.hip.h): 1 MB, MFMA-fragment order
   int upconv_slab = 1;            // 1: bf16 storage mode, ndomain 16: block 3 forward (collapsed form) by the slab kernel k_upconv_slab16
@@ -687,7 +687,7 @@ static bool wgrad16_ok(const RdPlan& hp, int B) {
   wgrad_tiling(hp, B, BR, BN, nsplit);
   return BR >= 128;
 }
-static bool wgrad16_wide(const rdgan_handle* h) { return !h || h->wgrad_wide; }
+static bool wgrad16_wide(const rdgan_handle* h) { return !h || h->wgrad_wide; }     // (op-level entries: on, so that the tile stays tested)
 static int launch_wgrad16(rdgan_handle* h, const RdPlan& hp, const RdPlan* dp, int B, const void* src16, const void* dy16,
                           float* dW, float* partial_ws, size_t partial_cap, hipStream_t st, int tag) {
   ProfScope ps(h, tag, st);

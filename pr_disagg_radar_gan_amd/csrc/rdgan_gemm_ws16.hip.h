@@ -23,10 +23,14 @@ __device__ __forceinline__ rd_bf16x8 rd_tr_frag(const char* lds, int off0, int o
   return __builtin_bit_cast(rd_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// <256, 128> (round 4, "wgrad_wide"): THREE stages of 48 KB, one workgroup per CU (compute waves: 128 accumulator registers).  The
-// streaming weight gradient is bound by the gathered bytes it can keep in flight over the memory latency (LDS capacity: 2
-// workgroups x 1 stage of 32 KB being filled = 64 KB per CU, 512 B per MFMA -> 0.20-0.29 of the bf16 roof whatever the tile does
-// inside); this shape keeps two stages = 96 KB in flight and needs 384 B per MFMA.  The loader waves then publish chunk q + 1
+// <256, 128> (round 4, "wgrad_wide", DEFAULT OFF): THREE stages of 48 KB, one workgroup per CU (compute waves: 128 accumulator
+// registers).  The idea: the streaming weight gradient keeps one 32 KB stage per workgroup in flight (64 KB per CU) at 512 B per
+// MFMA and runs at 0.20-0.29 of the bf16 roof; this shape keeps two stages = 96 KB in flight and needs 384 B per MFMA.  MEASURED
+// (scripts/gpu_r04_o.sh, ndomain 64, bs 64): critic layer 2 0.250 -> 0.417 ms, layer 3 0.125 -> 0.195, generator block 2 0.527 -> 1.036
+// -- the third time a one-workgroup-per-CU variant of a producer/consumer kernel loses (512 x 64 conv tiles; 4.6: the
+// first slab kernel): with one compute wave per SIMD, all of them phase-locked by the chunk barrier, nobody's MFMAs cover anybody's
+// transposed fragment reads.  Kept behind the option with its tests (correct: 1e-5 against the oracle); what would have to change is
+// the structure, as in k_conv_gemm_f16 (no loader waves, two workgroups per CU).  The loader waves here publish chunk q + 1
 // while chunk q + 2's DMAs stay in flight: a counted wait (the row-table loads of chunk q + 3 are issued BEFORE chunk q + 2's
 // DMAs, so those DMAs are exactly the youngest NI_A + NI_B vector-memory operations) and a bare s_barrier in one asm statement --
 // hipcc's own wait in front of __syncthreads() covers every DMA it has issued.

@@ -474,9 +474,8 @@ static long wgrad_target_wgs() {
   static const long v = [] { const char* e = getenv("RDGAN_WGRAD_WGS"); long x = e ? atol(e) : 0; return x >= 64 && x <= 8192 ? x : 1024L; }();
   return v;
 }
-// wide16 (bf16 kernels only, k_wgrad_gemm_ws16<256, 128>): N % 128 == 0 layers with plenty of rows take 256 x 128 tiles -- three
-// stages of 48 KB, one workgroup per CU: 96 KB of gathered rows in flight per CU instead of 64 and 384 B of them per MFMA instead of
-// 512 (the streaming weight-gradient kernels are bound by bytes in flight over memory latency)
+// wide16 (bf16 kernels only, k_wgrad_gemm_ws16<256, 128>, option "wgrad_wide", default off: measured slower): N % 128 == 0 layers
+// with plenty of rows take 256 x 128 tiles on three stages of 48 KB, one workgroup per CU
 static RdWgradTiling wgrad_tiling(const RdPlan& p, int B, int& BR, int& BN, int& nsplit, bool wide16 = false) {
   RdWgradTiling T; memset(&T, 0, sizeof(T));
   const RdPhase& q = p.ph[0];

@@ -712,7 +712,7 @@ def test_fragment_gemm_equals_the_streaming_gemm(nd, B, ksplit):
 
 
 def test_wide_wgrad_tiles_equal_the_128_row_tiles():
-    """"wgrad_wide" (default on): the streaming bf16 weight gradients of N % 128 == 0 layers with >= 32768 gathered rows on 256 x 128
+    """"wgrad_wide" (default OFF -- correct but slower, see k_wgrad_gemm_ws16's header): the streaming bf16 weight gradients of N % 128 == 0 layers with >= 32768 gathered rows on 256 x 128
     tiles with three LDS stages (k_wgrad_gemm_ws16<256, 128>) against the 128 x 128 tiles of the same engine: the same bf16 products,
     other splits and another fp32 order.  ndomain 32 with 30 samples: critic layers 2 (border boxes, 64 channels: four taps per row
     tile) and 3 and generator block 2 take the wide tiles."""
