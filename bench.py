@@ -430,7 +430,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ((("k_upconv_slab16<1, true, *> (last conv's tap products in its epilogue, their FLOPs not counted; critic steps do not store the output)"
                                                       if opts.get("g9_fused", "1") != "0" and opts.get("tapgather", "1") != "0" else "k_upconv_slab16<1>")
                                                      if (bf16 and taps == 8 and ND == 16 and opts.get("upconv_slab", "1") != "0") else
-                                                     "k_conv_gemm_ws<256, 64, 4, 1, %d, %s, 1>" % (8 if taps == 8 else 4, "true" if bf16 else "false")))
+                                                     ("k_upconv_slab_t16<*, *> (8 x 8 tiles with their halo resident; last conv's tap products in its epilogue, "
+                                                      "their FLOPs not counted)"
+                                                      if (bf16 and taps == 8 and ND > 16 and ND % 16 == 0 and opts.get("upconv_slab_t", "1") != "0") else
+                                                      "k_conv_gemm_ws<256, 64, 4, 1, %d, %s, 1>" % (8 if taps == 8 else 4, "true" if bf16 else "false"))))
                                                     + " (own symbol: this launch only), generator block 3 forward, "
                                                     + ("collapsed form (8 parity phases x 8 taps + bias + PixelNorm + LeakyReLU in the epilogue)"
                                                        if taps == 8 else
