@@ -20,6 +20,8 @@
 // same sequence of products, results are bit-identical except through PixelNorm (another order of the 128 squares).
 // Everything the plans describe is kept: phases, interleave, boxes, split-K partial slabs (k_splitk_finish), bf16 destinations.
 // Not here (the host falls back to the streaming kernel): fp32 destinations, the shared-centre T term, N % 128 != 0.
+// (Measured and not kept: s_setprio 3 around prologue and epilogue as in k_conv_gemm_ws -- no launch faster, critic layer 2's
+// forward 3 % slower, scratch/f16_ab.py.)
 #pragma once
 
 // (rd_wfrag_index, the element order of a fragment-order image: rdgan_plan.h)
