@@ -198,6 +198,9 @@ def main():
                     help="weak: --batch per GPU; strong: the configuration's global batch divided over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="exchange + Adam on the compute stream (A/B)")
+    ap.add_argument("--grad-transport", choices=("fp32", "bf16"), default="fp32",
+                    help="sharded exchange: gradients on the wire as fp32 (default) or rounded to bf16 for the reduce-scatter (optional "
+                         "data point: changes the arithmetic of the update)")
     ap.add_argument("--exchange", choices=("auto", "allreduce", "sharded"), default="auto",
                     help="gradient exchange per slab: one all-reduce, or reduce-scatter + Adam on the owned 1/N + all-gather; "
                          "auto = sharded for slabs of at least 128 MB (the ndomain-64 generator)")
@@ -269,7 +272,8 @@ def main():
     rng = np.random.default_rng(0)                  # identical initial weights on every rank
     trainer = WGANGPTrainer(eng, W.init_generator(rng, ND), W.init_critic(rng, ND), n_disc=n_critic,
                             process_group=pg, world_size=world, rank=rank, base_seed=1234 + 1000 * args.config,
-                            overlap=False if args.no_overlap else None, exchange=args.exchange)
+                            overlap=False if args.no_overlap else None, exchange=args.exchange,
+                            grad_transport=args.grad_transport)
     # synthetic inputs resident in HBM; per-rank seeds 1234 + 1000*config + rank
     nbuf = 4 if B * ND * ND <= 256 * 16 * 16 * 8 else 2
     data = []
@@ -422,6 +426,7 @@ def main():
                                        for k, v in sorted(trainer.exchange.items()))
                                     + (", on a side stream beside the next generator forward" if trainer.overlap else ", on the compute stream")),
                        "exchange_by_slab": None if world == 1 else dict(trainer.exchange),
+                       "grad_transport": None if world == 1 else trainer.grad_transport,
                        "rccl_verified": None if world == 1 else (args.backend == "nccl"),
                        "weights": "random init (RandomNormal 0.02 / glorot_uniform), dropout 0.25 active"},
             "iteration_ms": {"median": round(med, 4), "p10": round(float(np.percentile(it_ms, 10)), 4),

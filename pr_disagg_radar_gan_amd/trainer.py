@@ -36,16 +36,26 @@ class WGANGPTrainer:
       None/"auto"  "sharded" for a slab of at least SHARD_THRESHOLD_BYTES (the 837 MB generator of ndomain 64, whose Dense
                    kernel is 99.6 % of it), else "allreduce" (the 11-16 MB slabs of ndomain 16 are latency-bound: one
                    collective beats two).
-    Replicas stay bit-identical either way (every rank receives the same bytes)."""
+    Replicas stay bit-identical either way (every rank receives the same bytes).
+
+    grad_transport ("fp32" | "bf16", sharded exchange only; SURVEY 8e "optional bf16 gradient transport"): "bf16" rounds the
+    gradient slab to bfloat16 for the reduce-scatter -- half the bytes of that half of the exchange (the all-gather carries fp32
+    master weights either way), i.e. a quarter off the exposed ring time of ndomain 64's 837 MB generator slab.  The sum is then
+    formed in bf16 by the collective (relative error ~2^-8 per addend), the loss tail travels in a separate 8-float fp32
+    all-reduce; replicas still receive identical bytes.  Off by default: it changes the arithmetic of the update."""
 
     def __init__(self, engine, gen_arrays, critic_arrays, n_disc=5, lr=1e-4, beta2=0.9, eps=1e-7,
-                 process_group=None, world_size=1, rank=0, base_seed=1234, overlap=None, comm_hook=None, exchange=None):
+                 process_group=None, world_size=1, rank=0, base_seed=1234, overlap=None, comm_hook=None, exchange=None,
+                 grad_transport="fp32"):
         self.eng = engine
         self.n_disc = int(n_disc)
         self.lr, self.beta2, self.eps = lr, beta2, eps
         self.pg, self.world, self.rank = process_group, int(world_size), int(rank)
         if exchange not in (None, "auto", "allreduce", "sharded"):
             raise ValueError(f"exchange must be 'allreduce', 'sharded' or None, not {exchange!r}")
+        if grad_transport not in ("fp32", "bf16"):
+            raise ValueError(f"grad_transport must be 'fp32' or 'bf16', not {grad_transport!r}")
+        self.grad_transport = grad_transport
         g0, d0 = engine.to_slab(gen_arrays), engine.to_slab(critic_arrays)
         self.exchange = {}
         self._pad = {}
@@ -139,6 +149,28 @@ class WGANGPTrainer:
             per = out.numel()
             out.copy_(inp[self.rank * per:(self.rank + 1) * per])
 
+    def _reduce_scatter_bf16(self, gsh, grad, n, per, P):
+        """the reduce-scatter of the sharded exchange with the gradients rounded to bf16 on the wire; the 8 loss sums behind the
+        gradients go through their own fp32 all-reduce and are put back where the fp32 path leaves them"""
+        import torch.distributed as dist
+        if self.comm_hook is not None:
+            self.comm_hook(grad[:P])
+        tail = grad[n:n + LOSS_SLOTS].clone()
+        self._allreduce_plain(tail)
+        g16 = grad[:P].to(torch.bfloat16)
+        if self._native():
+            sh16 = torch.empty(per, dtype=torch.bfloat16, device=grad.device)
+            dist.reduce_scatter_tensor(sh16, g16, op=dist.ReduceOp.SUM, group=self.pg)
+            gsh.copy_(sh16)
+        else:                      # gloo rehearsal: the same rounding of the addends, the sum in fp32 and rounded once
+            r32 = g16.float()
+            dist.all_reduce(r32, op=dist.ReduceOp.SUM, group=self.pg)
+            gsh.copy_(r32[self.rank * per:(self.rank + 1) * per].to(torch.bfloat16))
+        lo = self.rank * per
+        a, b = max(lo, n), min(lo + per, n + LOSS_SLOTS)
+        if b > a:
+            gsh[a - lo:b - lo].copy_(tail[a - n:b - n])
+
     def _all_gather(self, out, shard):
         import torch.distributed as dist
         if self._native():
@@ -171,8 +203,20 @@ class WGANGPTrainer:
             # all-reduce of a copy (one extra collective, once) and fails loudly instead of training on a mixed-up shard
             check = grad[:P].clone()
             self._allreduce_plain(check)
-        self._reduce_scatter(gsh, grad[:P])                # this rank's 1/world of the summed slab (loss tail included)
-        if first_native:
+        if self.grad_transport == "bf16":
+            self._reduce_scatter_bf16(gsh, grad, n, per, P)
+        else:
+            self._reduce_scatter(gsh, grad[:P])            # this rank's 1/world of the summed slab (loss tail included)
+        if first_native and self.grad_transport == "bf16":
+            want = check[self.rank * per:(self.rank + 1) * per]
+            tol = 0.05 * float(want.abs().max()) + 1e-30       # (a sum of `world` bf16-rounded addends formed in bf16)
+            bad = (~((gsh - want).abs() <= tol).all()).float().reshape(1)
+            self._allreduce_plain(bad)
+            if float(bad) != 0:
+                raise RuntimeError(f"sharded exchange (bf16 transport): reduce_scatter_tensor of slab '{which}' is off by more than "
+                                   f"bf16 rounding on rank {self.rank}; use grad_transport='fp32'")
+            del check, want
+        elif first_native:
             want = check[self.rank * per:(self.rank + 1) * per]
             tol = 1e-5 * float(want.abs().max()) + 1e-30       # (ring order of the two collectives may differ: not bitwise)
             bad = (~((gsh - want).abs() <= tol).all()).float().reshape(1)

@@ -44,7 +44,8 @@ def global_batches(data_seed):
     return (x, c, z), (c2, z2)
 
 
-def run_iteration(engine, world, rank, pg, data_seed=21, overlap=None, comm_hook=None, collect_gates=False, exchange=None):
+def run_iteration(engine, world, rank, pg, data_seed=21, overlap=None, comm_hook=None, collect_gates=False, exchange=None,
+                  grad_transport=None):
     """critic step + generator step on this rank's shard of a global batch of N_GLOBAL; returns the all-reduced, 1/world
     scaled gradient slabs (what Adam consumed), the reported losses and the updated weights, all on the CPU.
     collect_gates (real HIP engine only): also the LeakyReLU slope patterns of both steps on this shard ("cgates": critic
@@ -57,6 +58,8 @@ def run_iteration(engine, world, rank, pg, data_seed=21, overlap=None, comm_hook
     per = sl.stop - sl.start
     engine.set_option("sample_offset", sl.start)
     kw = {} if exchange is None else {"exchange": exchange}
+    if grad_transport is not None:
+        kw["grad_transport"] = grad_transport
     tr = WGANGPTrainer(engine, g, d, n_disc=1, process_group=pg, world_size=world, rank=rank, overlap=overlap,
                        comm_hook=comm_hook, **kw)
     dev = tr.gparams.device

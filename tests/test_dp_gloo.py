@@ -55,7 +55,7 @@ def test_two_ranks_identical_shards_equal_single_process(tmp_path):
     assert not torch.equal(gp, torch.from_numpy(np.zeros(1, np.float32)).expand_as(gp))
 
 
-def _worker_shards(rank, world, port, out_dir, exchange=None):
+def _worker_shards(rank, world, port, out_dir, exchange=None, grad_transport=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -64,7 +64,7 @@ def _worker_shards(rank, world, port, out_dir, exchange=None):
     from tests.fake_engine import FakeEngine
     torch.set_num_threads(3)
     res = dp_case.run_iteration(FakeEngine(dp_case.NDOMAIN, dtype=torch.float64), world, rank, dist.group.WORLD,
-                                exchange=exchange)
+                                exchange=exchange, grad_transport=grad_transport)
     torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -123,6 +123,37 @@ def test_sharded_exchange_equals_the_allreduce_exchange(tmp_path):
         assert torch.equal(a[k], b[k]), k
     assert float(a["dv"].abs().max()) > 0 and float(a["gv"].abs().max()) > 0
     assert float(a["dl"][:4].abs().max()) > 0
+
+
+def test_sharded_exchange_with_bf16_gradient_transport(tmp_path):
+    """grad_transport="bf16" (optional): the reduce-scatter half of the sharded exchange carries the gradients rounded
+    to bfloat16.  World 2 over gloo against the fp32 transport of the same run: replicas bit-identical, the reported losses
+    EQUAL (they travel in their own fp32 all-reduce), the summed gradients within bf16 rounding of the fp32 sum per tensor, the
+    weights one Adam step apart by at most ~2 lr."""
+    from tests import dp_case
+    from pr_disagg_radar_gan_amd import weights as W
+    runs = {}
+    for i, gt in enumerate(("bf16", "fp32")):
+        out = tmp_path / gt
+        out.mkdir()
+        port = 35500 + (os.getpid() % 2000) + i
+        mp.spawn(_worker_shards, args=(2, port, str(out), "sharded", gt), nprocs=2, join=True)
+        r0, r1 = torch.load(out / "rank0.pt"), torch.load(out / "rank1.pt")
+        for k in ("dgrad", "ggrad", "dl", "gl", "dparams", "gparams", "dv", "gv"):
+            assert torch.equal(r0[k], r1[k]), (gt, k)      # replicas bit-identical
+        runs[gt] = r0
+    a, b = runs["bf16"], runs["fp32"]
+    assert torch.equal(a["dl"], b["dl"])                   # critic losses: same weights, fp32 tail
+    nd_, ng_ = a["dparams"].numel(), a["gparams"].numel()
+    errs = dp_case.grad_errors(a["dgrad"][:nd_], b["dgrad"][:nd_], W.critic_param_shapes(dp_case.NDOMAIN))
+    assert 1e-5 < max(errs.values()) < 1e-2, errs          # really rounded, and only rounded (2^-8 per addend, relative to a tensor's largest)
+    assert float((a["dparams"] - b["dparams"]).abs().max()) <= 2.1e-4
+    assert float((a["gparams"] - b["gparams"]).abs().max()) <= 2.1e-4
+    with pytest.raises(ValueError, match="grad_transport"):
+        from pr_disagg_radar_gan_amd.trainer import WGANGPTrainer
+        from tests.fake_engine import FakeEngine
+        rng = np.random.default_rng(0)
+        WGANGPTrainer(FakeEngine(8), W.init_generator(rng, 8), W.init_critic(rng, 8), grad_transport="fp8")
 
 
 def _worker_train_script(rank, world, port, out_dir):
