@@ -396,8 +396,8 @@ def selftest(lib):
         return 1
     failures = []
 
-    def expect(label, sym, insns, rule, hand=True):
-        got = [r for r, _, _ in check_kernel(sym, insns, hand=hand)]
+    def expect(label, sym, insns, rule, hand=True, dma_ok=None):
+        got = [r for r, _, _ in check_kernel(sym, insns, hand=hand, dma_ok=dma_ok)]
         if rule not in got:
             failures.append(f"{label}: rule {rule} not raised (got {got})")
         else:
@@ -429,6 +429,35 @@ def selftest(lib):
     bar = next(k for k in range(last_dma, len(mut)) if mut[k].mn == "s_barrier")
     mut = mut[:last_dma + 1] + [i for i in mut[last_dma + 1:bar] if not (i.mn == "s_waitcnt" and "vmcnt" in i.text)] + mut[bar:]
     expect("(4) barrier with an LDS-DMA tile still in flight", sym9, mut, "III", hand=False)
+
+    # round 4's kernels with counted waits:
+    # (5) k_conv_gemm_f16: the weight queue's wait weakened by one k-step (vmcnt(14) -> vmcnt(16)): an MFMA reads a fragment in flight
+    symf, insnsf = next((s_, i_) for s_, i_ in kernels.items() if "k_conv_gemm_f16ILb0E" in s_)
+    mut = _clone(insnsf)
+    n14 = 0
+    for i in mut:
+        if i.mn == "s_waitcnt" and "vmcnt(14)" in i.text:
+            i.text = i.text.replace("vmcnt(14)", "vmcnt(16)"); n14 += 1
+    assert n14 >= 4, "selftest: k_conv_gemm_f16 has no vmcnt(14) waits (the weight queue changed?)"
+    expect("(5) fragment GEMM: weight-queue wait one k-step short", symf, mut, "I")
+    # (6) its barrier publishing the next chunk's rows behind vmcnt(12) instead of vmcnt(8): four DMAs may still be in flight
+    mut = _clone(insnsf)
+    n8 = 0
+    for k, i in enumerate(mut):
+        if i.mn == "s_barrier" and mut[k - 1].mn == "s_waitcnt" and "vmcnt(8)" in mut[k - 1].text:
+            mut[k - 1].text = mut[k - 1].text.replace("vmcnt(8)", "vmcnt(12)"); n8 += 1
+    assert n8 >= 2, "selftest: k_conv_gemm_f16 has no vmcnt(8) + s_barrier pair"
+    expect("(6) fragment GEMM: barrier with the chunk's DMAs not covered", symf, mut, "III")
+    # (7) the three-stage weight-gradient kernel: the counted wait in front of its barrier weakened (vmcnt(12) -> vmcnt(20))
+    symw, insnsw = next((s_, i_) for s_, i_ in kernels.items() if "k_wgrad_gemm_ws16ILi256ELi128E" in s_)
+    okw = DMA_ACROSS_BARRIER[r"k_wgrad_gemm_ws16ILi256ELi128E"]
+    mut = _clone(insnsw)
+    n12 = 0
+    for k, i in enumerate(mut):
+        if i.mn == "s_barrier" and mut[k - 1].mn == "s_waitcnt" and "vmcnt(12)" in mut[k - 1].text:
+            mut[k - 1].text = mut[k - 1].text.replace("vmcnt(12)", "vmcnt(20)"); n12 += 1
+    assert n12 >= 1, "selftest: k_wgrad_gemm_ws16<256,128> has no vmcnt(12) + s_barrier pair"
+    expect("(7) stage ring: an older stage's DMAs not covered at the barrier", symw, mut, "III", hand=False, dma_ok=okw)
 
     # (IV) scratch in a kernel that claims none: the metadata record of the block-3 slab kernel with 304 bytes of private segment
     marker = f".name:           {sym}\n    .private_segment_fixed_size: 0"
