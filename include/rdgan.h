@@ -368,6 +368,10 @@ int rdgan_op_d2_fwd_slab16(const float* x, const float* w, const float* bias, fl
  * the slab kernel of the bf16 storage mode alone (k_d2_wgrad_slab16): x [B,11,7,7,64] (layer 1's output) and dy [B,6,4,4,128] are
  * rounded to bf16 on the device; dW [3,3,3,64,128] fp32 = sum over samples and output positions o of x[2 o + tap - 1] (outer) dy[o]. */
 int rdgan_op_d2_wgrad_slab16(const float* x, const float* dy, float* dW, int B, void* stream);
+/* the same through the tiled kernel of the larger domains (k_d2_wgrad_slab_t16: work items = 4 x 4 tiles of output positions with the
+ * layer-1 positions their taps reach, one halo position per odd class): x [B,11,2 OH - 1,2 OW - 1,64], dy [B,6,OH,OW,128], OH and OW
+ * multiples of 4 (ndomain 32 / 48 / 64: OH = ndomain / 4). */
+int rdgan_op_d2_wgrad_slab_t16(const float* x, const float* dy, float* dW, int B, int OH, int OW, void* stream);
 /* Weight gradient of the critic's third layer (backward of T:295, Conv3D(256, 3x3x3, stride 2, 'same') on 6 x 4 x 4 x 128 ->
  * 3 x 2 x 2 x 256) through the slab kernel of the bf16 storage mode alone (k_d3_wgrad_slab16): x [B,6,4,4,128] (layer 2's output) and
  * dy [B,3,2,2,256] are rounded to bf16 on the device; dW [3,3,3,128,256] fp32 = sum over samples and o of x[2 o + tap] (outer) dy[o]. */

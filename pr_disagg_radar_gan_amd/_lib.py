@@ -71,6 +71,7 @@ SIGNATURES = {
     "rdgan_op_d2_fwd_slab16": (ctypes.c_int, [c_f32p] * 4 + [ctypes.c_int, ctypes.c_uint64, c_stream]),
     "rdgan_op_d3_wgrad_slab16": (ctypes.c_int, [c_f32p] * 3 + [ctypes.c_int, c_stream]),
     "rdgan_op_d2_wgrad_slab16": (ctypes.c_int, [c_f32p] * 3 + [ctypes.c_int, c_stream]),
+    "rdgan_op_d2_wgrad_slab_t16": (ctypes.c_int, [c_f32p] * 3 + [ctypes.c_int] * 3 + [c_stream]),
     "rdgan_op_d2_dgrad_slab16": (ctypes.c_int, [c_f32p] * 4 + [ctypes.c_int, ctypes.c_int, c_stream]),
     "rdgan_op_d2_dgrad_slab_t16": (ctypes.c_int, [c_f32p] * 4 + [ctypes.c_int] * 4 + [c_stream]),
     "rdgan_op_pixelnorm_lrelu": (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_long, ctypes.c_int, c_stream]),

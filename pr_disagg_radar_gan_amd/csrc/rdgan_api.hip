@@ -865,7 +865,7 @@ extern "C" int rdgan_create(rdgan_handle** out, int ndomain, int n_cond_channels
   if (g9w_mfma_ok(nd, (long)MB * h->gpix[3]))                              // k_g9_wgrad_mfma: [27][64] per persistent workgroup
     wneed = std::max(wneed, (size_t)std::min<long>(((long)MB * h->gpix[3] + 127) / 128, 768) * 1728);
   if (nd == 16) wneed = std::max(wneed, (size_t)16 * 27 * RD_D3W_TILE);    // k_d3_wgrad_slab16: [16 groups][27][128][256]
-  if (nd == 16) wneed = std::max(wneed, (size_t)64 * 27 * RD_D2W_TILE);    // k_d2_wgrad_slab16: [64 groups][27][64][128]
+  if (nd % 16 == 0) wneed = std::max(wneed, (size_t)64 * 27 * RD_D2W_TILE);    // k_d2_wgrad_slab16 / _t16: [64 groups][27][64][128]
   if (nd == 16) wneed = std::max(wneed, (size_t)8 * 64 * RD_UW2_TILE);      // k_upconv2_wgrad_slab16: [8 groups][64][256][128]
   if (nd == 16) wneed = std::max(wneed, (size_t)32 * 64 * RD_UWG_TILE);     // k_upconv_wgrad_slab16: [32 groups][64][128][64]
   h->wpartial_cap = wneed;
@@ -1662,6 +1662,13 @@ static inline const float* d1_weights(const rdgan_handle* h, const float* dp) {
 
 // First critic layer as one K = 64 GEMM per tile (rdgan_edge.hip.h): one condition channel (2 floats per voxel), any ndomain
 static bool d1_gemm_ok(const rdgan_handle* h) { return h->edge_kernels && h->CP == 2 && h->Cin == 2; }
+// critic layer 2's weight gradient on tiles of 4 x 4 output positions (k_d2_wgrad_slab_t16): the geometry of 'valid' layer 1 +
+// stride-2 'same' layer 2 on an ndomain that is a multiple of 16 (11 x (2 OH - 1)^2 -> 6 x OH^2, OH % 4 == 0)
+static bool d2_wgrad_slab_t_on(const rdgan_handle* h) {
+  return h->d2_wgrad_slab && h->a16 && h->nd > 16 && h->nd % 16 == 0 && h->ddim[1][0] == 11 && h->ddim[2][0] == 6 &&
+         h->ddim[2][1] % 4 == 0 && h->ddim[2][2] % 4 == 0 && h->ddim[1][1] == 2 * h->ddim[2][1] - 1 && h->ddim[1][2] == 2 * h->ddim[2][2] - 1 &&
+         h->dch[1] == 64 && h->dch[2] == 128;
+}
 static bool d2_gate_bits_on(const rdgan_handle* h) {
   return h->d2_gate_bits && h->d2_slab && h->a16 && (h->nd == 16 || d2_slab_t_on(h)) && h->g1bits;
 }
@@ -1995,6 +2002,20 @@ extern "C" int rdgan_critic_grad_after(rdgan_handle* h, const float* dp, const f
       RD_TRY(ensure_lds(h, (const void*)k_d2_wgrad_slab16, RD_D2W_LDS));
       hipLaunchKernelGGL(k_d2_wgrad_slab16, dim3(4 * G), dim3(512), RD_D2W_LDS, st, (const rd_bf16_t*)in, (const rd_bf16_t*)h->du[2],
                          h->wpartial, NBt, G);
+      hipLaunchKernelGGL(k_d2_wgrad_fold, dim3((27 * RD_D2W_TILE / 4 + 255) / 256), dim3(256), 0, st, h->wpartial, G, grad + h->doff[2]);
+      RD_CHECK(h, hipGetLastError());
+    } else if (a16 && l == 2 && d2_wgrad_slab_t_on(h)) {
+      // the same on (h, w) tiles of 4 x 4 output positions (ndomain 32 / 48 / 64)
+      ProfScope ps(h, RDGAN_TAG_CRITIC_GEMM, st);
+      LaunchScope ls(h, pl, RD_KIND_WGRAD, NBt, plan_flops(h->plans[pl], NBt), st);
+      RD_KNAME(h, "k_d2_wgrad_slab_t16<bf16>");
+      h->flops_acc += plan_flops(h->plans[pl], NBt);
+      const RdD2wGeom geo = {h->ddim[1][1], h->ddim[1][2], h->ddim[2][1], h->ddim[2][2], h->ddim[2][1] / 4, h->ddim[2][2] / 4};
+      const int G = (long)NBt * geo.TH * geo.TW >= 64 ? 64 : 8;
+      if ((size_t)G * 27 * RD_D2W_TILE > h->wpartial_cap) return bad_arg(h, "d2 wgrad: partial workspace too small");
+      RD_TRY(ensure_lds(h, (const void*)k_d2_wgrad_slab_t16, RD_D2WT_LDS));
+      hipLaunchKernelGGL(k_d2_wgrad_slab_t16, dim3(4 * G), dim3(512), RD_D2WT_LDS, st, (const rd_bf16_t*)in, (const rd_bf16_t*)h->du[2],
+                         h->wpartial, NBt, G, geo);
       hipLaunchKernelGGL(k_d2_wgrad_fold, dim3((27 * RD_D2W_TILE / 4 + 255) / 256), dim3(256), 0, st, h->wpartial, G, grad + h->doff[2]);
       RD_CHECK(h, hipGetLastError());
     } else if (a16 && l == 3 && h->d3_wgrad_slab && h->nd == 16) {
@@ -2761,6 +2782,30 @@ extern "C" int rdgan_op_d2_wgrad_slab16(const float* x, const float* dy, float* 
   if (rc == 0) rc = ensure_lds(nullptr, (const void*)k_d2_wgrad_slab16, RD_D2W_LDS);
   if (rc == 0) {
     hipLaunchKernelGGL(k_d2_wgrad_slab16, dim3(4 * G), dim3(512), RD_D2W_LDS, st, (const rd_bf16_t*)xb, (const rd_bf16_t*)yb, part, B, G);
+    hipLaunchKernelGGL(k_d2_wgrad_fold, dim3((27 * RD_D2W_TILE / 4 + 255) / 256), dim3(256), 0, st, part, G, dW);
+    rc = (int)hipGetLastError();
+  }
+  if (rc == 0) rc = (int)hipStreamSynchronize(st);
+  for (void* p : {xb, yb, (void*)part}) if (p) (void)hipFree(p);
+  return rc;
+}
+
+// The same through the tiled kernel (k_d2_wgrad_slab_t16): x [B,11,2 OH - 1,2 OW - 1,64], dy [B,6,OH,OW,128], OH and OW multiples of 4.
+extern "C" int rdgan_op_d2_wgrad_slab_t16(const float* x, const float* dy, float* dW, int B, int OH, int OW, void* stream) {
+  if (!x || !dy || !dW || B < 1 || OH < 4 || OW < 4 || OH % 4 || OW % 4) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const RdD2wGeom geo = {2 * OH - 1, 2 * OW - 1, OH, OW, OH / 4, OW / 4};
+  const long nx = (long)B * 11 * geo.IH * geo.IW * 64, ny = (long)B * 6 * OH * OW * 128;
+  const int G = (long)B * geo.TH * geo.TW >= 64 ? 64 : 8;
+  void *xb = nullptr, *yb = nullptr; float* part = nullptr;
+  int rc = (int)hipMalloc(&xb, nx * 2);
+  if (rc == 0) rc = (int)hipMalloc(&yb, ny * 2);
+  if (rc == 0) rc = (int)hipMalloc((void**)&part, (size_t)G * 27 * RD_D2W_TILE * sizeof(float));
+  if (rc == 0) rc = launch_to_bf16(nullptr, x, xb, nx, st);
+  if (rc == 0) rc = launch_to_bf16(nullptr, dy, yb, ny, st);
+  if (rc == 0) rc = ensure_lds(nullptr, (const void*)k_d2_wgrad_slab_t16, RD_D2WT_LDS);
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_d2_wgrad_slab_t16, dim3(4 * G), dim3(512), RD_D2WT_LDS, st, (const rd_bf16_t*)xb, (const rd_bf16_t*)yb, part, B, G, geo);
     hipLaunchKernelGGL(k_d2_wgrad_fold, dim3((27 * RD_D2W_TILE / 4 + 255) / 256), dim3(256), 0, st, part, G, dW);
     rc = (int)hipGetLastError();
   }

@@ -244,15 +244,16 @@ def test_d3_wgrad_slab_equals_the_streaming_wgrad(B):
         eng.close()
 
 
-@pytest.mark.parametrize("B", [2, 30])
-def test_d2_wgrad_slab_equals_the_streaming_wgrad(B):
-    """"d2_wgrad_slab" (default on at ndomain 16): critic layer 2's weight gradient in the slab kernel k_d2_wgrad_slab16 against
+@pytest.mark.parametrize("B,nd", [(2, 16), (30, 16), (3, 32), (2, 64), (1, 48)])
+def test_d2_wgrad_slab_equals_the_streaming_wgrad(B, nd):
+    """"d2_wgrad_slab" (default on at ndomain 16, 32, 48, 64): critic layer 2's weight gradient in the slab kernel k_d2_wgrad_slab16
+    (ndomain 16: a sample per item) / k_d2_wgrad_slab_t16 (larger domains: a 4 x 4 tile of output positions per item) against
     k_wgrad_gemm_ws16<128,128> of the same engine over the 3 B batch [real; fake; second-sweep r1]: the same bf16 products summed in
     fp32 in another order -- that kernel gradient within 2e-5 of its largest entry, the rest of the critic-step slab bit for bit."""
-    eng = Engine(ndomain=16, max_batch=B)
+    eng = Engine(ndomain=nd, max_batch=B)
     try:
-        g, d = _params(16, 65)
-        x, cond, z = ot.synthetic_batch(B, 16, 56)
+        g, d = _params(nd, 65)
+        x, cond, z = ot.synthetic_batch(B, nd, 56)
         gs, ds = eng.to_slab(g), eng.to_slab(d)
         eng.set_option("bf16", 1)
         res = {}

@@ -473,6 +473,48 @@ def test_d2_wgrad_slab_kernel_vs_definition(B):
     assert torch.equal(out, out2)                                   # deterministic
 
 
+@pytest.mark.parametrize("B,OH,OW", [(3, 8, 8), (2, 16, 16), (5, 12, 8), (70, 4, 4)])
+def test_d2_wgrad_slab_tiled_kernel_vs_definition(B, OH, OW):
+    """k_d2_wgrad_slab_t16 alone (rdgan_op_d2_wgrad_slab_t16): the same weight gradient with work items = 4 x 4 tiles of output
+    positions (ndomain 32 / 48 / 64: 8, 12, 16 output positions a side; 4 x 4 = one tile whose halo lies wholly outside the picture)
+    against torch autograd of the definition in fp64 on the bf16-rounded operands, 2e-5 of the largest entry; then a one-hot probe:
+    ONE output-gradient position at a tile corner and one layer-1 position at a time -- every tap that joins them across the tile
+    border must pick it up, no other tap may."""
+    IH, IW = 2 * OH - 1, 2 * OW - 1
+    g = torch.Generator(); g.manual_seed(500 + B + OH)
+    x = torch.randn((B, 11, IH, IW, 64), generator=g)
+    dy = torch.randn((B, 6, OH, OW, 128), generator=g)
+    xr, dyr = x.bfloat16().double(), dy.bfloat16().double()
+    w = torch.zeros((3, 3, 3, 64, 128), dtype=torch.float64, requires_grad=True)
+    y = ot._conv3d_tf(xr, w, torch.zeros(128, dtype=torch.float64), 2, (1, 1, 1), (6, OH, OW))
+    (ref,) = torch.autograd.grad((y * dyr).sum(), w)
+    ref = ref.numpy()
+    xd, dyd = dev(x.numpy()), dev(dy.numpy())
+    out = torch.full((3, 3, 3, 64, 128), float("nan"), device="cuda")
+    assert lib().rdgan_op_d2_wgrad_slab_t16(ptr(xd), ptr(dyd), ptr(out), B, OH, OW, stream()) == 0
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(got))
+    err = np.abs(got - ref).max(axis=(3, 4)) / np.abs(ref).max()
+    assert err.max() < 2e-5, err
+    out2 = torch.empty_like(out)
+    assert lib().rdgan_op_d2_wgrad_slab_t16(ptr(xd), ptr(dyd), ptr(out2), B, OH, OW, stream()) == 0
+    assert torch.equal(out, out2)                                   # deterministic
+    if OH < 8:
+        return
+    # one-hot: output position (od, oh, ow) = (2, 4, 3) sits at a tile border along h (tiles of 4) and at a tile's last column
+    dy1 = torch.zeros((1, 6, OH, OW, 128)); dy1[0, 2, 4, 3, 5] = 1.0
+    for (id_, ih, iw) in ((3, 7, 5), (4, 8, 6), (5, 9, 7), (3, 7, 7), (4, 9, 5), (3, 6, 6)):
+        x1 = torch.zeros((1, 11, IH, IW, 64)); x1[0, id_, ih, iw, 9] = 1.0
+        o1 = torch.full((3, 3, 3, 64, 128), float("nan"), device="cuda")
+        x1d, dy1d = dev(x1.numpy()), dev(dy1.numpy())
+        assert lib().rdgan_op_d2_wgrad_slab_t16(ptr(x1d), ptr(dy1d), ptr(o1), 1, OH, OW, stream()) == 0
+        want = np.zeros((3, 3, 3, 64, 128), np.float32)
+        td, th, tw = id_ - 2 * 2 + 1, ih - 2 * 4 + 1, iw - 2 * 3 + 1          # input = 2 o + tap - 1
+        if 0 <= td < 3 and 0 <= th < 3 and 0 <= tw < 3:
+            want[td, th, tw, 9, 5] = 1.0
+        assert np.array_equal(o1.cpu().numpy(), want), (id_, ih, iw)
+
+
 @pytest.mark.parametrize("B", [1, 3, 520])
 def test_upconv2_slab_kernel_vs_oracle(B):
     """k_upconv2_slab16 alone (rdgan_op_upconv2_slab16): generator block 2 of the bf16 storage mode -- UpSampling3D(2) + Conv3D(256
