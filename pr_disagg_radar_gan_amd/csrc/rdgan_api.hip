@@ -1291,7 +1291,7 @@ static int gen_forward_impl(rdgan_handle* h, const float* gp, const float* z, co
   // W9T [64][32] = W9[tap][ci]^T (zero padded taps 27..31)
   RD_TRY(launch_transpose(h, gp + h->goff[8], h->W9T, 1, 27, 64, 32, ws));
   if (dense_skinny_on(h)) {
-    const long nimg = (long)(h->n_nodes / 32) * dense_skinny_ks(h) * 64;
+    const long nimg = (long)(h->n_nodes / 32) * dense_skinny_ks(h) * 16;      // (threads: four lanes' fragments each)
     hipLaunchKernelGGL(k_dense_wimg, dim3((unsigned)((nimg + 255) / 256)), dim3(256), 0, ws, gp + h->goff[0], (unsigned short*)h->bW0,
                        h->n_in, h->n_nodes, dense_skinny_ks(h));
   } else

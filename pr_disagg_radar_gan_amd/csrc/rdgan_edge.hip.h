@@ -1041,18 +1041,25 @@ k_d1_wgrad_fold(const float* __restrict__ partial, int G, float* __restrict__ dw
 // Weight image: [n-block = N / 32][k-step = KP / 16][lane][8 bf16] = W[16 ks + 8 (lane >> 5) + e][32 nb + (lane & 31)] (zero for
 // k >= K); input image: [k-step][row block][lane][8 bf16] = x[32 rb + (lane & 31)][16 ks + 8 (lane >> 5) + e] (zero rows / columns).
 // ------------------------------------------------------------------------------------------------------------------------------
+// One thread per (n-block, k-step, k half, group of 4 columns): eight 16-byte loads (rows k0 .. k0 + 7, columns n .. n + 3) and the four
+// lanes' 16-byte outputs, which are 64 contiguous bytes of the image (a first version read 4 bytes per lane and instruction: the 825 MB
+// kernel of ndomain 64 came in at 3.8 TB/s)
 __global__ void k_dense_wimg(const float* __restrict__ W /* [K][N] */, unsigned short* __restrict__ img, int K, int N, int KS) {
-  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;       // (nb, ks, lane)
-  if (idx >= (long)(N / 32) * KS * 64) return;
-  const int lane = (int)(idx & 63);
-  const long t = idx >> 6;
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;       // (nb, ks, half, q)
+  if (idx >= (long)(N / 32) * KS * 16) return;
+  const int q = (int)(idx & 7), half = (int)((idx >> 3) & 1);
+  const long t = idx >> 4;
   const int ks = (int)(t % KS), nb = (int)(t / KS);
-  const int n = nb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
-  float v[8];
+  const int n = nb * 32 + q * 4, k0 = ks * 16 + half * 8;
+  f32x4 v[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = k0 + e < K ? W[(long)(k0 + e) * N + n] : 0.f;
-  u32x4_t o = {rd_pack_bf16(v[0], v[1]), rd_pack_bf16(v[2], v[3]), rd_pack_bf16(v[4], v[5]), rd_pack_bf16(v[6], v[7])};
-  *(u32x4_t*)(img + idx * 8) = o;
+  for (int e = 0; e < 8; ++e) v[e] = k0 + e < K ? *(const f32x4*)(W + (long)(k0 + e) * N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned short* o = img + ((t * 64) + half * 32 + q * 4) * 8;       // lane = half * 32 + (n & 31)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32x4_t w = {rd_pack_bf16(v[0][j], v[1][j]), rd_pack_bf16(v[2][j], v[3][j]), rd_pack_bf16(v[4][j], v[5][j]), rd_pack_bf16(v[6][j], v[7][j])};
+    *(u32x4_t*)(o + j * 8) = w;
+  }
 }
 // the rows [z | cond] of k_concat as that input image, RB row blocks (rows >= B and columns >= nz + nc are zero)
 __global__ void k_concat16f(const float* __restrict__ z, const float* __restrict__ cond, unsigned short* __restrict__ img, int B, int nz,
