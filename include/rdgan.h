@@ -166,6 +166,9 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * fragment-order twin images (written beside the [tap][N][K] ones), gathered rows by LDS-DMA one 64-k chunk ahead, per-wave epilogue.
  * Same chunk and k order as the streaming kernel: bit-identical results except through a fused PixelNorm (one ulp of 1/l2).
  * 0 = k_conv_gemm_ws everywhere; 2 (tests) = regardless of the launch size.
+ * "wgrad_wide" (default 0; bf16 storage mode): the streaming weight gradients of N % 128 == 0 layers with >= 32768 gathered rows on
+ * 256 x 128 tiles with three LDS stages, one workgroup per CU (k_wgrad_gemm_ws16<256, 128>).  Correct and SLOWER (1.6-2x): kept for
+ * the record and its tests.
  * "dense_skinny" (default 1; bf16 storage mode with "dense16", handles of max_batch <= 128): the Dense layer by k_dense16_skinny --
  * weights and input rows streamed in MFMA-fragment order, no LDS (the large domain's 415 MB kernel at 3.4-3.7 TB/s).  One bf16 ulp.
  * "wgrad_boxes" (default 1; with "border_boxes"): the weight gradients of critic layers 2-4 that run in the streaming kernels (fp32
@@ -193,6 +196,7 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * k_d2_fwd_slab16: a sample's layer-1 output (69 KB) resident in LDS for all 27 taps, the four waves of a workgroup split the 128
  * output channels and stream their own weight fragments, bias + LeakyReLU + dropout in registers (rdgan_d2fwd16.hip.h); the
  * penalty's second sweep keeps the streaming GEMM.  Same dropout counter as 0 = k_conv_gemm_ws<128, 128, ..., bf16>.
+ * ("d2_slab" at ndomain 32 / 48 / 64: k_d2_dgrad_slab_t16, the same on 8 x 8 tiles of destination positions of two samples.)
  * "d2_slab" (default 1; bf16 storage mode, ndomain 16): the input gradient of the critic's second layer (128 -> 64 channels onto
  * the 11 x 7 x 7 grid, eight parity phases of 8 ... 1 taps) runs in the slab kernel k_d2_dgrad_slab16: two samples' output
  * gradient resident in LDS for all phases and taps, weights streamed in MFMA-fragment order, LeakyReLU' x dropout gate + bf16
@@ -200,7 +204,8 @@ int rdgan_critic_param_layout(const rdgan_handle* h, long* offsets, long* sizes)
  * "d2_wgrad_slab" (default 1; bf16 storage mode, ndomain 16): the weight gradient of the critic's second layer runs in the slab
  * kernel k_d2_wgrad_slab16: a wave owns one of the 27 taps and keeps its 64 x 128 product in registers over the workgroup's share
  * of the batch; by input parity the taps fall into 8 classes, each a dense sub-grid of layer 1's output on which its taps are shifts
- * (rdgan_d2wgrad16.hip.h).  0 = k_wgrad_gemm_ws16<128,128>.
+ * (rdgan_d2wgrad16.hip.h).  0 = k_wgrad_gemm_ws16<128,128>.  At ndomain 32 / 48 / 64 the same kernel body with work items = 4 x 4 tiles
+ * of output positions and one halo position per odd class (k_d2_wgrad_slab_t16).
  * "d3_wgrad_slab" (default 1; same conditions): critic layer 3's weight gradient the same way (k_d3_wgrad_slab16: a wave owns a tap
  * and a quarter of the 256 output channels; a sample has 12 output positions, so an item is four samples); 0 = k_wgrad_gemm_ws16.
  * "upwgrad_slab" (default 1; bf16 storage mode, ndomain 16, collapsed form): the weight gradient of generator block 3 runs in the slab
